@@ -1,0 +1,137 @@
+/* recometrics_hip.h -- C-ABI of librecometrics_hip.so: the MI355X (gfx950) drop-in for the hot path of
+ * david-cortes/recometrics.
+ *
+ * Boundary replaced (reference files, relative to the reference repository root):
+ *   src/recometrics_signatures.hpp:46       bool get_has_openmp()
+ *   src/recometrics_signatures.hpp:48-72    void calc_metrics_double(...30 parameters...)
+ *   src/recometrics_signatures.hpp:74-98    void calc_metrics_float(...30 parameters...)
+ * which recometrics/wrapper.pyx:282-304,381-403 (Cython) calls today and which src/Rwrapper.cpp:250-274 (Rcpp)
+ * reaches through the template src/recometrics.hpp:359.  The entry points below keep the reference's PARAMETER
+ * ORDER and meaning one-for-one; the differences are the ones a C-ABI needs: `bool` -> `int`, C linkage, and an
+ * `int` status return (0 = ok) instead of C++ exceptions (std::bad_alloc / std::runtime_error in the reference,
+ * src/recometrics.hpp:395-397,:171).  rm_last_error() returns the message for the calling thread.
+ *
+ * Ownership (same as the reference, src/recometrics.hpp:193-358): the caller owns every buffer; outputs are
+ * pre-allocated by the binding ([m] or row-major [m x k_metrics] when `cumulative`); a NULL output pointer means
+ * "metric not requested"; inputs are never modified; users that cannot be evaluated get NaN in every requested
+ * output, so outputs need no initialisation.  CSR is 0-based int32 with sorted, unique indices inside a row.
+ * `nthreads` and `seed` are accepted for signature compatibility: the device path has no host thread pool, and
+ * the tie-breaking noise stream (reference :531-534) is not emulated ("tie noise").
+ *
+ * No torch / HIP types appear in any signature: pointers, sizes and scalars only.
+ */
+#ifndef RECOMETRICS_HIP_H
+#define RECOMETRICS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes */
+#define RM_OK 0
+#define RM_ERR_INVALID 1     /* bad argument (null pointer, non-positive size, k_metrics > n ...) */
+#define RM_ERR_HIP 2         /* HIP runtime failure (message has the hipError string) */
+#define RM_ERR_NOMEM 3       /* device or host allocation failed (the reference throws std::bad_alloc) */
+#define RM_ERR_UNSUPPORTED 4 /* shape outside what the kernels are built for (message says which) */
+
+/* replaces calc_metrics_float  (src/recometrics_signatures.hpp:74-98).  ALL pointers are HOST pointers. */
+int rm_calc_metrics_f32(
+    const float *A, size_t lda, const float *B, size_t ldb,
+    int32_t m, int32_t n, int32_t k,
+    const int32_t *Xtrain_csr_p, const int32_t *Xtrain_csr_i,
+    const int32_t *Xtest_csr_p, const int32_t *Xtest_csr_i, const float *Xtest_csr,
+    int32_t k_metrics, int cumulative, int break_ties_with_noise,
+    float *p_at_k, float *tp_at_k, float *r_at_k, float *ap_at_k, float *tap_at_k,
+    float *ndcg_at_k, float *hit_at_k, float *rr_at_k, float *roc_auc, float *pr_auc,
+    int consider_cold_start, int32_t min_items_pool, int32_t min_pos_test,
+    int32_t nthreads, uint64_t seed);
+
+/* replaces calc_metrics_double (src/recometrics_signatures.hpp:48-72).  ALL pointers are HOST pointers. */
+int rm_calc_metrics_f64(
+    const double *A, size_t lda, const double *B, size_t ldb,
+    int32_t m, int32_t n, int32_t k,
+    const int32_t *Xtrain_csr_p, const int32_t *Xtrain_csr_i,
+    const int32_t *Xtest_csr_p, const int32_t *Xtest_csr_i, const double *Xtest_csr,
+    int32_t k_metrics, int cumulative, int break_ties_with_noise,
+    double *p_at_k, double *tp_at_k, double *r_at_k, double *ap_at_k, double *tap_at_k,
+    double *ndcg_at_k, double *hit_at_k, double *rr_at_k, double *roc_auc, double *pr_auc,
+    int consider_cold_start, int32_t min_items_pool, int32_t min_pos_test,
+    int32_t nthreads, uint64_t seed);
+
+/* Same contracts with every pointer a DEVICE pointer on the current device (inputs already resident in HBM,
+ * outputs written to HBM); `stream` is a hipStream_t passed as void* (NULL = default stream).  Asynchronous
+ * apart from one small plan read-back; the caller synchronises the stream before reading the outputs.
+ * `nnz_train` / `nnz_test` are the lengths of the index arrays (the host variants read them from indptr[m]). */
+int rm_calc_metrics_dev_f32(
+    const float *A, size_t lda, const float *B, size_t ldb,
+    int32_t m, int32_t n, int32_t k,
+    const int32_t *Xtrain_csr_p, const int32_t *Xtrain_csr_i, int64_t nnz_train,
+    const int32_t *Xtest_csr_p, const int32_t *Xtest_csr_i, const float *Xtest_csr, int64_t nnz_test,
+    int32_t k_metrics, int cumulative, int break_ties_with_noise,
+    float *p_at_k, float *tp_at_k, float *r_at_k, float *ap_at_k, float *tap_at_k,
+    float *ndcg_at_k, float *hit_at_k, float *rr_at_k, float *roc_auc, float *pr_auc,
+    int consider_cold_start, int32_t min_items_pool, int32_t min_pos_test,
+    uint64_t seed, void *stream);
+
+int rm_calc_metrics_dev_f64(
+    const double *A, size_t lda, const double *B, size_t ldb,
+    int32_t m, int32_t n, int32_t k,
+    const int32_t *Xtrain_csr_p, const int32_t *Xtrain_csr_i, int64_t nnz_train,
+    const int32_t *Xtest_csr_p, const int32_t *Xtest_csr_i, const double *Xtest_csr, int64_t nnz_test,
+    int32_t k_metrics, int cumulative, int break_ties_with_noise,
+    double *p_at_k, double *tp_at_k, double *r_at_k, double *ap_at_k, double *tap_at_k,
+    double *ndcg_at_k, double *hit_at_k, double *rr_at_k, double *roc_auc, double *pr_auc,
+    int consider_cold_start, int32_t min_items_pool, int32_t min_pos_test,
+    uint64_t seed, void *stream);
+
+/* Ranking introspection (host pointers): the ordered top-K item ids / scores per user ([m x k_metrics], -1 / NaN
+ * padded), the 1-based position of every test item in the user's FULL candidate ranking ([nnz_test], 0 when the
+ * item is masked by the train row or the user is skipped) and status[m] (0 = ranked, 1 = user skipped).  These are
+ * the quantities the parity contract pins bit-exactly (top-K index sets, hit counts, positive ranks). */
+int rm_rank_f32(
+    const float *A, size_t lda, const float *B, size_t ldb, int32_t m, int32_t n, int32_t k,
+    const int32_t *Xtrain_csr_p, const int32_t *Xtrain_csr_i,
+    const int32_t *Xtest_csr_p, const int32_t *Xtest_csr_i,
+    int32_t k_metrics, int break_ties_with_noise, int consider_cold_start,
+    int32_t min_items_pool, int32_t min_pos_test, uint64_t seed,
+    int32_t *topk_idx, float *topk_score, int64_t *pos_rank, int32_t *status);
+
+int rm_rank_f64(
+    const double *A, size_t lda, const double *B, size_t ldb, int32_t m, int32_t n, int32_t k,
+    const int32_t *Xtrain_csr_p, const int32_t *Xtrain_csr_i,
+    const int32_t *Xtest_csr_p, const int32_t *Xtest_csr_i,
+    int32_t k_metrics, int break_ties_with_noise, int consider_cold_start,
+    int32_t min_items_pool, int32_t min_pos_test, uint64_t seed,
+    int32_t *topk_idx, double *topk_score, int64_t *pos_rank, int32_t *status);
+
+/* Dense score matrix out[m x n] (host) computed by the sweep's own MFMA contraction -- test hook that pins the
+ * "bit-identical to the k-ordered fma chain" claim (reference src/recometrics.hpp:99-112). */
+int rm_debug_scores_f32(const float *A, size_t lda, const float *B, size_t ldb,
+                        int32_t m, int32_t n, int32_t k, float *out);
+int rm_debug_scores_f64(const double *A, size_t lda, const double *B, size_t ldb,
+                        int32_t m, int32_t n, int32_t k, double *out);
+
+/* replaces get_has_openmp (src/recometrics_signatures.hpp:46): host threads are irrelevant here; always 1 so that
+ * the reference's "built without multi-threading" warning (recometrics/__init__.py:524-529) never fires. */
+int rm_has_openmp(void);
+
+const char *rm_last_error(void);       /* message of the last failing call on this thread ("" if none) */
+int rm_device_count(void);             /* visible HIP devices (0 when there is no GPU / driver) */
+int rm_set_device(int device);         /* device used by subsequent calls on this thread */
+
+/* Timings of the most recent successful call on this thread, milliseconds measured with HIP events on the call's
+ * stream: out[0] plan+pack+positives, out[1] sweep kernel, out[2] finalize, out[3] whole device section;
+ * out[4] = launches of the sweep kernel, out[5] = item splits, out[6] = sweep blocks, out[7] = dynamic LDS bytes.
+ * Forces a synchronisation of that stream.  Returns the number of values written. */
+int rm_get_timings(double *out, int n);
+
+/* Releases the cached device workspace of the current device. */
+int rm_release_workspace(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECOMETRICS_HIP_H */

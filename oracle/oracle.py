@@ -130,6 +130,17 @@ class Oracle(_Lib):
         return {"topk_idx": idx, "topk_score": sc, "pos_rank": pr, "status": st}
 
 
+    def scores(self, A, B, dtype=np.float32):
+        A = np.ascontiguousarray(A, dtype=dtype)
+        B = np.ascontiguousarray(B, dtype=dtype)
+        out = np.empty((A.shape[0], B.shape[0]), dtype=dtype)
+        fn = self.lib.rmo_scores_f32 if dtype == np.float32 else self.lib.rmo_scores_f64
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        fn(_ptr(A), A.shape[1], _ptr(B), B.shape[1], A.shape[0], B.shape[0], A.shape[1], _ptr(out))
+        return out
+
+
 class Reference(_Lib):
     """The real reference (C++-linkage symbols called through their mangled names)."""
 

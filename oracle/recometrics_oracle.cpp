@@ -372,6 +372,22 @@ extern "C" int rmo_rank_##SUFFIX(                                               
 RMO_DEFINE(f32, float)
 RMO_DEFINE(f64, double)
 
+/* dense score matrix out[m x n] with the canonical chain (test hook for the MFMA bit-exactness check) */
+extern "C" int rmo_scores_f32(const float *A, size_t lda, const float *B, size_t ldb, int32_t m, int32_t n, int32_t k, float *out)
+{
+    #pragma omp parallel for schedule(static)
+    for (int32_t u = 0; u < m; u++)
+        for (int32_t j = 0; j < n; j++) out[(size_t)u * n + j] = chain_dot(A + (size_t)u * lda, B + (size_t)j * ldb, k);
+    return 0;
+}
+extern "C" int rmo_scores_f64(const double *A, size_t lda, const double *B, size_t ldb, int32_t m, int32_t n, int32_t k, double *out)
+{
+    #pragma omp parallel for schedule(static)
+    for (int32_t u = 0; u < m; u++)
+        for (int32_t j = 0; j < n; j++) out[(size_t)u * n + j] = chain_dot(A + (size_t)u * lda, B + (size_t)j * ldb, k);
+    return 0;
+}
+
 extern "C" int rmo_has_openmp(void)
 {
 #ifdef _OPENMP

@@ -1,0 +1,171 @@
+"""ctypes binding of include/recometrics_hip.h (the C-ABI of librecometrics_hip.so).
+
+Plays the role of the reference's Cython layer (recometrics/wrapper.pyx:226-495): pulls the raw buffers out of
+the NumPy / SciPy objects, pre-allocates the outputs (size 0 == "not requested" == NULL pointer,
+wrapper.pyx:208-224,:270-280) and turns status codes into the exceptions `except +` produces there.
+There is NO fallback: if the HIP library is missing or there is no device, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "librecometrics_hip.so")
+_lib = None
+
+METRIC_ORDER = ("p", "tp", "r", "ap", "tap", "ndcg", "hit", "rr", "roc", "pr")
+EXPORTS = (
+    "rm_calc_metrics_f32", "rm_calc_metrics_f64", "rm_calc_metrics_dev_f32", "rm_calc_metrics_dev_f64",
+    "rm_rank_f32", "rm_rank_f64", "rm_debug_scores_f32", "rm_debug_scores_f64", "rm_has_openmp",
+    "rm_last_error", "rm_device_count", "rm_set_device", "rm_get_timings", "rm_release_workspace",
+)
+
+
+class HipLibraryMissing(ImportError):
+    pass
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """Loads the HIP library (once).  Raises HipLibraryMissing if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise HipLibraryMissing(
+            "recometrics_amd: %s is missing -- build it with `python -m recometrics_amd.build` "
+            "(there is no CPU fallback)" % _LIB_PATH)
+    lib = C.CDLL(_LIB_PATH)
+    vp, i32, i64, u64, sz, ci = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_size_t, C.c_int
+    host = [vp, sz, vp, sz, i32, i32, i32, vp, vp, vp, vp, vp, i32, ci, ci] + [vp] * 10 + [ci, i32, i32, i32, u64]
+    dev = [vp, sz, vp, sz, i32, i32, i32, vp, vp, i64, vp, vp, vp, i64, i32, ci, ci] + [vp] * 10 + [ci, i32, i32, u64, vp]
+    rank_sig = [vp, sz, vp, sz, i32, i32, i32, vp, vp, vp, vp, i32, ci, ci, i32, i32, u64, vp, vp, vp, vp]
+    for suf in ("f32", "f64"):
+        getattr(lib, "rm_calc_metrics_" + suf).argtypes = host
+        getattr(lib, "rm_calc_metrics_dev_" + suf).argtypes = dev
+        getattr(lib, "rm_rank_" + suf).argtypes = rank_sig
+        getattr(lib, "rm_debug_scores_" + suf).argtypes = [vp, sz, vp, sz, i32, i32, i32, vp]
+        for fn in ("rm_calc_metrics_", "rm_calc_metrics_dev_", "rm_rank_", "rm_debug_scores_"):
+            getattr(lib, fn + suf).restype = ci
+    lib.rm_last_error.restype = C.c_char_p
+    lib.rm_get_timings.argtypes = [C.POINTER(C.c_double), ci]
+    lib.rm_set_device.argtypes = [ci]
+    _lib = lib
+    return lib
+
+
+def _raise(lib, rc):
+    msg = (lib.rm_last_error() or b"").decode(errors="replace")
+    if rc == 1:
+        raise ValueError(msg)
+    if rc == 3:
+        raise MemoryError(msg)
+    raise RuntimeError("recometrics_amd (status %d): %s" % (rc, msg))
+
+
+def _p(a):
+    return None if a is None or a.size == 0 else a.ctypes.data_as(C.c_void_p)
+
+
+def has_openmp():
+    return bool(load().rm_has_openmp())
+
+
+def device_count():
+    return int(load().rm_device_count())
+
+
+def set_device(i):
+    lib = load()
+    rc = lib.rm_set_device(int(i))
+    if rc:
+        _raise(lib, rc)
+
+
+def timings():
+    lib = load()
+    buf = (C.c_double * 8)()
+    n = lib.rm_get_timings(buf, 8)
+    keys = ("prep_ms", "sweep_ms", "finalize_ms", "device_ms", "sweep_launches", "item_splits", "sweep_blocks", "lds_bytes")
+    return {k: buf[i] for i, k in enumerate(keys[:n])}
+
+
+def _suffix(dtype):
+    return "f32" if dtype == np.float32 else "f64"
+
+
+def calc_metrics(A, lda, B, ldb, train_p, train_i, test_p, test_i, test_v, k_metrics, want, cumulative,
+                 break_ties_with_noise, consider_cold_start, min_items_pool, min_pos_test, nthreads, seed):
+    """Host-array entry.  `want`: dict metric-name -> bool in METRIC_ORDER.  Returns the 10-tuple of arrays the
+    reference's cpp_funs.calc_reco_metrics returns (wrapper.pyx:306-323): size-0 arrays for metrics not requested,
+    (m, k) arrays for cumulative top-K metrics."""
+    lib = load()
+    dtype = A.dtype.type
+    m, k = A.shape
+    n = B.shape[0]
+    size_arr = m * k_metrics if cumulative else m
+    outs = []
+    for name in METRIC_ORDER:
+        cnt = (m if name in ("roc", "pr") else size_arr) if want.get(name) else 0
+        outs.append(np.empty(cnt, dtype=dtype))
+    fn = getattr(lib, "rm_calc_metrics_" + _suffix(dtype))
+    rc = fn(_p(A), lda, _p(B), ldb, m, n, k, _p(train_p), _p(train_i), _p(test_p), _p(test_i), _p(test_v),
+            k_metrics, int(bool(cumulative)), int(bool(break_ties_with_noise)), *[_p(o) for o in outs],
+            int(bool(consider_cold_start)), min_items_pool, min_pos_test, nthreads, seed)
+    if rc:
+        _raise(lib, rc)
+    if cumulative:
+        outs = [(o.reshape((m, k_metrics)) if o.size else o.reshape((0, 0))) if i < 8 else o for i, o in enumerate(outs)]
+    return tuple(outs)
+
+
+def calc_metrics_device(dtype, A, lda, B, ldb, m, n, k, train_p, train_i, nnz_train, test_p, test_i, test_v, nnz_test,
+                        k_metrics, outs, cumulative=False, break_ties_with_noise=False, consider_cold_start=True,
+                        min_items_pool=2, min_pos_test=1, seed=1, stream=0):
+    """Device-pointer entry: every array argument is an integer device address (0 == NULL); `outs` is a sequence
+    of 10 addresses in METRIC_ORDER.  Asynchronous on `stream` apart from one small plan read-back."""
+    lib = load()
+    fn = getattr(lib, "rm_calc_metrics_dev_" + _suffix(dtype))
+
+    def vp(x):
+        return C.c_void_p(int(x)) if x else None
+    rc = fn(vp(A), lda, vp(B), ldb, m, n, k, vp(train_p), vp(train_i), nnz_train, vp(test_p), vp(test_i), vp(test_v), nnz_test,
+            k_metrics, int(bool(cumulative)), int(bool(break_ties_with_noise)), *[vp(o) for o in outs],
+            int(bool(consider_cold_start)), min_items_pool, min_pos_test, seed, vp(stream))
+    if rc:
+        _raise(lib, rc)
+
+
+def rank(A, B, train_p, train_i, test_p, test_i, k_metrics, break_ties_with_noise=False, consider_cold_start=True,
+         min_items_pool=2, min_pos_test=1, seed=1):
+    lib = load()
+    dtype = A.dtype.type
+    m, k = A.shape
+    n = B.shape[0]
+    idx = np.empty((m, k_metrics), dtype=np.int32)
+    sc = np.empty((m, k_metrics), dtype=dtype)
+    pr = np.zeros(max(int(test_i.shape[0]), 1), dtype=np.int64)
+    st = np.empty(m, dtype=np.int32)
+    fn = getattr(lib, "rm_rank_" + _suffix(dtype))
+    rc = fn(_p(A), A.shape[1], _p(B), B.shape[1], m, n, k, _p(train_p), _p(train_i), _p(test_p), _p(test_i),
+            k_metrics, int(bool(break_ties_with_noise)), int(bool(consider_cold_start)), min_items_pool, min_pos_test, seed,
+            _p(idx), _p(sc), _p(pr), _p(st))
+    if rc:
+        _raise(lib, rc)
+    return {"topk_idx": idx, "topk_score": sc, "pos_rank": pr[:test_i.shape[0]], "status": st}
+
+
+def debug_scores(A, B):
+    lib = load()
+    dtype = A.dtype.type
+    A = np.ascontiguousarray(A)
+    B = np.ascontiguousarray(B)
+    out = np.empty((A.shape[0], B.shape[0]), dtype=dtype)
+    fn = getattr(lib, "rm_debug_scores_" + _suffix(dtype))
+    rc = fn(_p(A), A.shape[1], _p(B), B.shape[1], A.shape[0], B.shape[0], A.shape[1], _p(out))
+    if rc:
+        _raise(lib, rc)
+    return out

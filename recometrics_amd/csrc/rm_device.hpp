@@ -1,0 +1,62 @@
+// rm_device.hpp -- shared device-side definitions for the gfx950 (MI355X / CDNA4) hot path.
+//
+// Path: per-user ranking metrics of recometrics' calc_metrics<real_t>
+// (reference src/recometrics.hpp:359-965).  Terminology follows the reference's domain:
+// users, items, factors, train/test CSR rows, candidates, top-K, positives.
+//
+// Device data model (see DESIGN.md for the full picture)
+//   slot      one lane-owner in the sweep: (user, chunk c of <= 63 of its sorted positives).  A user with P
+//             positives owns max(1, ceil(P/63)) slots; slot 0 ("primary") also owns the user's top-K/validity state.
+//   group     32 consecutive slots = the users one wavefront carries on its lanes (users-on-lanes MFMA orientation).
+//   tile      64 consecutive items; a packed item tile is the exact LDS image the MFMA loop reads.
+//   partial   one wavefront's private result for a slot (its 32-item half of every tile of its item split).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rm {
+
+constexpr int WAVE = 64;
+constexpr int GROUP_USERS = 32;        // users on the lanes of one wavefront (fp32 MFMA 32x32x2: D column = lane & 31)
+constexpr int TILE_ITEMS = 64;         // items per packed tile (two 32-item MFMA sub-tiles)
+constexpr int SWEEP_THREADS = 512;     // 8 wavefronts: 4 groups x 2 sub-tiles
+constexpr int GROUPS_PER_BLOCK = 4;
+constexpr int POS_CHUNK = 63;          // positives per slot = rows of a complete binary search tree of depth 6
+constexpr int MAX_J = 6;
+constexpr int IDX_EMPTY = 0x7fffffff;
+
+// per-user flags written by k_classify
+enum : int { UF_NAN = 1, UF_ONLY_NDCG = 2, UF_KLEQN = 4, UF_ACTIVE = 8 };
+
+// which outputs the caller asked for (NULL pointer == not requested, reference recometrics.hpp:370-379)
+enum : int { RQ_P = 1, RQ_TP = 2, RQ_R = 4, RQ_AP = 8, RQ_TAP = 16, RQ_NDCG = 32, RQ_HIT = 64, RQ_RR = 128, RQ_ROC = 256, RQ_PR = 512 };
+
+template <class T> struct Entry { T s; int idx; };     // (score, item) -- top-K list element
+typedef Entry<float> ListEntry;
+
+template <class T> struct PartialStat {          // one wavefront's validity / AUC state for one slot
+    T vmax, vmin;
+    unsigned long long rocsum;                    // sum over candidates of #positives-in-chunk scored below it
+    int has_nan; int pad;
+};
+
+struct Plan {                                     // produced on device, read back once by the host
+    int n_active;      // users that need scoring
+    int n_slots;
+    int n_groups;
+    int jmax;          // deepest positive tree over all groups (0 when no AUC is requested)
+    long long total_rows;   // sum over groups of (2^j - 1)
+    int class_count[MAX_J + 1];
+    int class_offset[MAX_J + 2];
+    int class_cursor[MAX_J + 1];
+    int pad;
+};
+
+__device__ __forceinline__ float nan_sentinel_f() { return __int_as_float(0xffffffff); }
+__device__ __forceinline__ float pos_inf_f() { return __int_as_float(0x7f800000); }
+__device__ __forceinline__ float neg_inf_f() { return __int_as_float(0xff800000); }
+
+// row of accumulator register r in a 32x32 MFMA result for the lane half h (cdna_hip_programming.md section 3)
+__device__ __forceinline__ constexpr int mfma32_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+} // namespace rm

@@ -1,0 +1,268 @@
+// rm_finalize.hpp -- per-user metric finalisation from the sweep's partial results (one thread per user).
+//
+// Replaces reference src/recometrics.hpp:450-476 (NaN fill), :541-562 (validity checks), :589-788 (top-K walk and NaN
+// overrides), :795-865 (ROC / PR AUC) and :868-961 (NDCG normalisation).  All metric arithmetic is fp64 with the
+// reference's operation order, cast to real_t on store; log2(i+2) comes from a host table built with the same libm
+// the CPU path uses.  ROC-AUC is formed in fp64 where the reference uses x87 long double (<= 1 ulp(fp64) apart).
+#pragma once
+#include "rm_device.hpp"
+
+namespace rm {
+
+constexpr int MAX_PARTS = 128;
+
+template <class T, class S> struct FinalArgs {     // T = real_t of inputs/outputs, S = score type of the sweep
+    int m, n, K, n_part, req, cumulative, noise;
+    const int *train_p, *test_p, *test_i; const T *test_v;
+    const int *flags, *user_nslots, *uslot_base, *slot_index;
+    const int *gj; const long long *grow;
+    const Entry<S> *pl; const PartialStat<S> *pst; const unsigned *hist; const S *pos_score;
+    const double *log2tab;
+    T *p, *tp, *r, *ap, *tap, *ndcg, *hit, *rr, *roc, *pr;
+    Entry<S> *merged;            // [m][K]   final ordered top-K (also the rm_rank_* output)
+    long long *rank_sorted;      // [nnz_test] 1-based full-ranking position per SORTED positive (0 = masked), optional
+    int *status;                 // [m] optional: 0 ranked, 1 skipped
+};
+
+template <class T> __device__ __forceinline__ T qnan();
+template <> __device__ __forceinline__ float qnan<float>() { return __int_as_float(0x7fc00000); }
+template <> __device__ __forceinline__ double qnan<double>() { return __longlong_as_double(0x7ff8000000000000ll); }
+
+template <class T, class S>
+__device__ void fill_user_nan(const FinalArgs<T, S> &a, int u)
+{
+    T *top8[8] = {a.p, a.tp, a.r, a.ap, a.tap, a.ndcg, a.hit, a.rr};
+    for (int q = 0; q < 8; q++) {
+        T *arr = top8[q];
+        if (!arr) continue;
+        if (!a.cumulative) arr[u] = qnan<T>();
+        else for (int i = 0; i < a.K; i++) arr[(size_t)u * a.K + i] = qnan<T>();
+    }
+    if (a.roc) a.roc[u] = qnan<T>();
+    if (a.pr) a.pr[u] = qnan<T>();
+}
+
+template <class S> __device__ __forceinline__ bool ent_before(const Entry<S> &x, const Entry<S> &y)
+{
+    return x.s > y.s || (x.s == y.s && x.idx < y.idx);
+}
+
+template <class T, class S>
+__global__ void k_finalize(FinalArgs<T, S> a)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= a.m) return;
+    const int K = a.K, n = a.n;
+    const int f = a.flags[u];
+    const int te0 = a.test_p[u], npos = a.test_p[u + 1] - te0;
+    if (a.status) a.status[u] = 1;
+    Entry<S> *M = a.merged + (size_t)u * K;
+    for (int i = 0; i < K; i++) { M[i].s = (S)qnan<float>(); M[i].idx = -1; }
+    if (a.rank_sorted) for (int t = 0; t < npos; t++) a.rank_sorted[te0 + t] = 0;
+    if (f & UF_NAN) { fill_user_nan(a, u); return; }
+
+    const int ntr = a.train_p[u + 1] - a.train_p[u];
+    const int C = n - ntr;
+    const bool only_ndcg = f & UF_ONLY_NDCG, kleqn = f & UF_KLEQN;
+    const int base = a.uslot_base[u];
+    const int s0 = a.slot_index[base];
+    const int NP = a.n_part;
+
+    // ---- merge the partial top-K lists (each descending) and the validity stats ----
+    int head[MAX_PARTS];
+    S vmax = -(S)INFINITY, vmin = (S)INFINITY; bool any_nan = false;
+    for (int q = 0; q < NP; q++) {
+        head[q] = 0;
+        const PartialStat<S> ps = a.pst[(size_t)s0 * NP + q];
+        vmax = ps.vmax > vmax ? ps.vmax : vmax;
+        vmin = ps.vmin < vmin ? ps.vmin : vmin;
+        any_nan |= ps.has_nan != 0;
+    }
+    const Entry<S> *PL = a.pl + (size_t)s0 * NP * K;
+    for (int i = 0; i < K; i++) {
+        int best = -1; Entry<S> be; be.s = 0; be.idx = 0;
+        for (int q = 0; q < NP; q++) {
+            if (head[q] >= K) continue;
+            const Entry<S> e = PL[(size_t)q * K + head[q]];
+            if (best < 0 || ent_before(e, be)) { best = q; be = e; }
+        }
+        head[best]++;
+        if (be.idx == IDX_EMPTY) { be.idx = -1; be.s = (S)qnan<float>(); }
+        M[i] = be;
+    }
+    const int W = K < C ? K : C;
+
+    // ---- validity (:517-526 with noise, :541-562 without; NaN anywhere => invalid, see DESIGN.md deviation D3) ----
+    const bool ref_full = ((a.req & RQ_ROC) && !only_ndcg) || K >= C;
+    bool invalid = any_nan;
+    if (a.noise) invalid |= (vmax == vmin) || isinf(vmax) || isinf(vmin);
+    else {
+        const S hi = M[0].s, lo = ref_full ? vmin : M[W - 1].s;
+        invalid |= isinf(hi) || isinf(lo) || hi == lo || M[W - 1].idx < 0;
+    }
+    if (invalid) {
+        for (int i = 0; i < K; i++) { M[i].s = (S)qnan<float>(); M[i].idx = -1; }
+        fill_user_nan(a, u); return;
+    }
+    if (a.status) a.status[u] = 0;
+
+    const int *ti = a.test_i + te0;
+    const T *tv = a.test_v ? a.test_v + te0 : nullptr;
+    const size_t st = (size_t)u * K;
+    T *cp = a.p ? a.p + st : nullptr, *ctp = a.tp ? a.tp + st : nullptr, *cr = a.r ? a.r + st : nullptr;
+    T *cap = a.ap ? a.ap + st : nullptr, *ctap = a.tap ? a.tap + st : nullptr, *cndcg = a.ndcg ? a.ndcg + st : nullptr;
+    T *chit = a.hit ? a.hit + st : nullptr, *crr = a.rr ? a.rr + st : nullptr;
+    const bool cum = a.cumulative;
+
+    // ---- top-K walk (:589-748) ----
+    const bool top = a.req & (RQ_P | RQ_TP | RQ_R | RQ_AP | RQ_TAP | RQ_NDCG | RQ_HIT | RQ_RR);
+    bool walked = false;
+    int hits = 0, first = 0x7fffffff;
+    double avg_p = 0, dcg = 0;
+    if (top && (!kleqn || (a.req & (RQ_AP | RQ_TAP | RQ_RR | RQ_NDCG)))) {
+        walked = true;
+        for (int ix = 0; ix < W; ix++) {
+            const int item = M[ix].idx;
+            int lo = 0, hi = npos;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (ti[mid] < item) lo = mid + 1; else hi = mid; }
+            if (lo < npos && ti[lo] == item) {
+                hits++;
+                avg_p += hits / (double)(ix + 1);
+                dcg += tv ? ((double)tv[lo] / a.log2tab[ix]) : 0.;
+                first = first < ix ? first : ix;
+            }
+            if (cum) {
+                const int mn = (ix + 1) < npos ? (ix + 1) : npos;
+                if (cp) cp[ix] = (T)(hits / (double)(ix + 1));
+                if (ctp) ctp[ix] = (T)(hits / (double)mn);
+                if (cr) cr[ix] = (T)(hits / (double)npos);
+                if (cap) cap[ix] = (T)(avg_p / (double)npos);
+                if (ctap) ctap[ix] = (T)(avg_p / (double)mn);
+                if (cndcg) cndcg[ix] = (T)dcg;
+                if (chit) chit[ix] = (T)(hits > 0);
+                if (crr) crr[ix] = (T)(hits ? ((double)1 / (double)(first + 1)) : 0.);
+            }
+        }
+        if (!cum) {
+            const int mn = K < npos ? K : npos;
+            if (a.p) a.p[u] = (T)((double)hits / (double)K);
+            if (a.tp) a.tp[u] = (T)((double)hits / (double)mn);
+            if (a.r) a.r[u] = (T)((double)hits / (double)npos);
+            if (a.ap) a.ap[u] = (T)(avg_p / (double)npos);
+            if (a.tap) a.tap[u] = (T)(avg_p / (double)mn);
+            if (a.hit) a.hit[u] = (T)(hits > 0);
+            if (a.rr) a.rr[u] = (T)(hits ? (1. / (double)(first + 1)) : 0.);
+        } else if (K > C) {
+            for (int i = C; i < K; i++) {
+                if (cp) cp[i] = qnan<T>(); if (ctp) ctp[i] = qnan<T>(); if (cr) cr[i] = qnan<T>(); if (chit) chit[i] = qnan<T>();
+                if (cap) cap[i] = cap[C - 1]; if (ctap) ctap[i] = ctap[C - 1]; if (crr) crr[i] = crr[C - 1]; if (cndcg) cndcg[i] = cndcg[C - 1];
+            }
+        }
+    }
+
+    // ---- NaN overrides (:750-788) ----
+    if (kleqn) {
+        if (!cum) {
+            if (a.p) a.p[u] = qnan<T>(); if (a.tp) a.tp[u] = qnan<T>(); if (a.r) a.r[u] = qnan<T>(); if (a.hit) a.hit[u] = qnan<T>();
+        } else if (!walked) {
+            for (int i = 0; i < K; i++) { if (cp) cp[i] = qnan<T>(); if (ctp) ctp[i] = qnan<T>(); if (cr) cr[i] = qnan<T>(); if (chit) chit[i] = qnan<T>(); }
+        }
+    } else if (only_ndcg) {
+        if (!cum) {
+            if (a.p) a.p[u] = qnan<T>(); if (a.tp) a.tp[u] = qnan<T>(); if (a.r) a.r[u] = qnan<T>(); if (a.ap) a.ap[u] = qnan<T>();
+            if (a.tap) a.tap[u] = qnan<T>(); if (a.hit) a.hit[u] = qnan<T>(); if (a.rr) a.rr[u] = qnan<T>();
+        } else {
+            for (int i = 0; i < K; i++) {
+                if (cp) cp[i] = qnan<T>(); if (ctp) ctp[i] = qnan<T>(); if (cr) cr[i] = qnan<T>(); if (cap) cap[i] = qnan<T>();
+                if (ctap) ctap[i] = qnan<T>(); if (chit) chit[i] = qnan<T>(); if (crr) crr[i] = qnan<T>();
+            }
+        }
+    }
+
+    // ---- ROC-AUC / PR-AUC from the rank histograms (:795-865) ----
+    if (only_ndcg) {
+        if (a.roc) a.roc[u] = qnan<T>();
+        if (a.pr) a.pr[u] = qnan<T>();
+    } else if (a.req & (RQ_ROC | RQ_PR)) {
+        const int nsl = a.user_nslots[u];
+        unsigned long long sum_ranks = 0; int h = 0; double ap_full = 0;
+        for (int c = nsl - 1; c >= 0; c--) {                       // chunks hold ascending scores: walk them downwards
+            const int slot = a.slot_index[base + c];
+            const int g = slot / GROUP_USERS, ul = slot % GROUP_USERS;
+            const int PLg = (1 << a.gj[g]) - 1;
+            const unsigned *H = a.hist + (a.grow[g] + g) * GROUP_USERS + ul;
+            const S *PS = a.pos_score + a.grow[g] * GROUP_USERS + ul;
+            const int pc = min(POS_CHUNK, npos - c * POS_CHUNK);
+            unsigned long long above = 0;                           // candidates scored above positive j of the chunk
+            for (int b = PLg; b > pc; b--) above += H[(size_t)b * GROUP_USERS];
+            for (int j = pc - 1; j >= 0; j--) {
+                above += H[(size_t)(j + 1) * GROUP_USERS];
+                if (isinf(PS[(size_t)j * GROUP_USERS]) && PS[(size_t)j * GROUP_USERS] > 0) continue;   // masked by the train row
+                const unsigned long long rank = above + 1;
+                sum_ranks += rank; h++;
+                ap_full += (double)h / (double)rank;
+                if (a.rank_sorted) a.rank_sorted[te0 + c * POS_CHUNK + j] = (long long)rank;
+            }
+        }
+        const unsigned long long P = (unsigned long long)npos, Nneg = (unsigned long long)C - P;
+        if (a.roc) a.roc[u] = (T)(1. - (double)(sum_ranks - (P * (P + 1)) / 2) / (double)(P * Nneg));
+        if (a.pr) a.pr[u] = (T)(ap_full / (double)npos);
+    }
+
+    // ---- NDCG normalisation (:868-961) ----
+    if (a.ndcg) {
+        const int L = K < npos ? K : npos;
+        // ideal DCG walks the test values in descending order; selection without scratch: next = largest value that
+        // comes after (value, index) of the previous pick in (value desc, index asc) order
+        auto pick_next = [&](bool have_prev, T pv, int pi, T &ov, int &oi) {
+            bool found = false; T bv = 0; int bi = -1;
+            for (int t = 0; t < npos; t++) {
+                const T x = tv[t];
+                if (have_prev && !(x < pv || (x == pv && t > pi))) continue;
+                if (!found || x > bv) { found = true; bv = x; bi = t; }
+            }
+            ov = bv; oi = bi; return found;
+        };
+        bool has_nan_val = false;
+        for (int t = 0; t < npos; t++) has_nan_val |= tv[t] != tv[t];
+        T vmaxv = 0, vlast = 0; int pi = -1; T pv = 0;
+        {   // first and L-th values
+            T x; int xi; bool hp = false; pv = 0; pi = -1;
+            for (int i = 0; i < L; i++) { pick_next(hp, pv, pi, x, xi); hp = true; pv = x; pi = xi; if (i == 0) vmaxv = x; }
+            vlast = pv;
+        }
+        if (has_nan_val || isinf(vmaxv) || isinf(vlast) || vmaxv <= 0) {
+            if (!cum) a.ndcg[u] = qnan<T>(); else for (int i = 0; i < K; i++) cndcg[i] = qnan<T>();
+            return;
+        }
+        double idcg = 0; bool hp = false; pv = 0; pi = -1; T x; int xi;
+        if (!cum) {
+            for (int ix = 0; ix < L; ix++) {
+                pick_next(hp, pv, pi, x, xi); hp = true; pv = x; pi = xi;
+                if (!(vlast >= 0) && x <= 0) break;
+                idcg += (double)x / a.log2tab[ix];
+            }
+            a.ndcg[u] = (T)(dcg / idcg);
+        } else {
+            if (vlast >= 0) {
+                for (int ix = 0; ix < L; ix++) {
+                    pick_next(hp, pv, pi, x, xi); hp = true; pv = x; pi = xi;
+                    idcg += (double)x / a.log2tab[ix];
+                    cndcg[ix] = (T)((double)cndcg[ix] / idcg);                      // quirk Q5: divides the rounded DCG
+                }
+            } else {
+                int ix = 0;
+                for (; ix < L; ix++) {
+                    pick_next(hp, pv, pi, x, xi); hp = true; pv = x; pi = xi;
+                    if (x < 0) break;
+                    idcg += (double)x / a.log2tab[ix];
+                    cndcg[ix] = (T)((double)cndcg[ix] / idcg);
+                }
+                for (; ix < L; ix++) cndcg[ix] = (T)((double)cndcg[ix] / idcg);
+            }
+            if (npos < K) { const int e = K < C ? K : C; for (int i = npos; i < e; i++) cndcg[i] = cndcg[npos - 1]; }   // quirk Q6
+        }
+    }
+}
+
+} // namespace rm

@@ -1,0 +1,530 @@
+// rm_lib.hip -- host orchestration + the C-ABI of include/recometrics_hip.h  (gfx950 only).
+//
+// Host counterpart of reference src/recometrics.hpp:359-436 (prologue: clamps, scratch) and of the instantiation
+// shims src/recometrics_instantiated.cpp:30-143.  The reference's OpenMP loop over users (:428-437) becomes:
+//   plan (classify users, slots, groups)  ->  pack operands  ->  positives  ->  k_sweep  ->  k_finalize
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/recometrics_hip.h"
+#include "rm_device.hpp"
+#include "rm_prep.hpp"
+#include "rm_sweep.hpp"
+#include "rm_finalize.hpp"
+
+namespace {
+
+using namespace rm;
+
+thread_local std::string g_err;
+thread_local double g_timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+thread_local hipEvent_t g_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+thread_local bool g_ev_valid = false;
+thread_local hipStream_t g_ev_stream = nullptr;
+std::mutex g_mu;
+
+struct RmError { int code; std::string msg; };
+
+#define HIP_CHECK(expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            throw RmError{e_ == hipErrorOutOfMemory ? RM_ERR_NOMEM : RM_ERR_HIP,                          \
+                          std::string(#expr) + ": " + hipGetErrorString(e_)};                             \
+    } while (0)
+
+// ---- cached device workspace (per device), so that repeated calls do not pay hipMalloc ----
+struct Workspace {
+    std::map<std::string, std::pair<void *, size_t>> bufs;
+    void *get(const std::string &name, size_t bytes)
+    {
+        bytes = std::max<size_t>(bytes, 256);
+        auto &b = bufs[name];
+        if (b.second < bytes) {
+            if (b.first) { (void)hipFree(b.first); b.first = nullptr; b.second = 0; }
+            const size_t cap = bytes + bytes / 8;
+            hipError_t e = hipMalloc(&b.first, cap);
+            if (e != hipSuccess) { b.first = nullptr; throw RmError{RM_ERR_NOMEM, "hipMalloc(" + name + ", " + std::to_string(cap) + " B): " + hipGetErrorString(e)}; }
+            b.second = cap;
+        }
+        return b.first;
+    }
+    void release()
+    {
+        for (auto &kv : bufs) if (kv.second.first) (void)hipFree(kv.second.first);
+        bufs.clear();
+    }
+};
+std::map<int, Workspace> g_ws;
+
+Workspace &workspace()
+{
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    return g_ws[dev];
+}
+
+template <class T> struct Call {          // one calc_metrics call; every pointer is a DEVICE pointer
+    const T *A; size_t lda; const T *B; size_t ldb;
+    int m, n, k;
+    const int *train_p, *train_i; long long nnz_train;
+    const int *test_p, *test_i; const T *test_v; long long nnz_test;
+    int K; bool cumulative, noise;
+    T *out[10];                            // p, tp, r, ap, tap, ndcg, hit, rr, roc, pr
+    bool cold; int min_items_pool, min_pos_test;
+    // optional ranking outputs (device)
+    int *topk_idx; T *topk_score; long long *pos_rank; int *status;
+};
+
+inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
+
+template <class T> __global__ void k_iota(T *p, int count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) p[i] = (T)i;
+}
+
+template <class S>
+__global__ void k_export_rank(int m, int K, const Entry<S> *merged, int *topk_idx, S *topk_score)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)m * K) return;
+    topk_idx[i] = merged[i].idx;
+    topk_score[i] = merged[i].s;
+}
+
+__global__ void k_export_pos_rank(long long nnz, int m, const int *test_p, const int *pos_order,
+                                  const long long *rank_sorted, long long *pos_rank)
+{
+    // one thread per user row (rows are short)
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= m) return;
+    for (int e = test_p[u]; e < test_p[u + 1]; e++) pos_rank[e] = rank_sorted[test_p[u] + pos_order[e]];
+}
+
+int supported_ng(int k)
+{
+    const int ng = (k + 7) / 8;
+    const int opts[4] = {2, 4, 8, 16};
+    for (int o : opts) if (ng <= o) return o;
+    return -1;
+}
+
+template <bool AUC, bool DUMP>
+void launch_sweep(int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa)
+{
+#define RM_LAUNCH(NGV)                                                                                               \
+    case NGV: {                                                                                                      \
+        auto kern = k_sweep<NGV, AUC, DUMP>;                                                                         \
+        HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+        hipLaunchKernelGGL(kern, grid, dim3(SWEEP_THREADS), lds, stream, sa);                                        \
+    } break;
+    switch (NG) {
+        RM_LAUNCH(2) RM_LAUNCH(4) RM_LAUNCH(8) RM_LAUNCH(16)
+        default: throw RmError{RM_ERR_UNSUPPORTED, "unsupported factor count"};
+    }
+#undef RM_LAUNCH
+    HIP_CHECK(hipGetLastError());
+}
+
+constexpr size_t LDS_LIMIT = 160 * 1024;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 device pipeline
+// ---------------------------------------------------------------------------------------------------------------------
+void run_f32(const Call<float> &c, hipStream_t stream)
+{
+    typedef float T;
+    Workspace &ws = workspace();
+    const int m = c.m, n = c.n, k = c.k, K = c.K;
+    // reference recometrics.hpp:390-393
+    const int min_items_pool = std::max(std::max(c.min_items_pool, K), 2);
+    const int min_pos_test = std::min(c.min_pos_test, 1);
+    int req = 0;
+    for (int i = 0; i < 10; i++) if (c.out[i]) req |= (1 << i);
+    const bool want_auc = req & (RQ_ROC | RQ_PR);
+
+    const int NG = supported_ng(k);
+    if (NG < 0) throw RmError{RM_ERR_UNSUPPORTED, "fp32 path supports up to 128 factors (got " + std::to_string(k) + ")"};
+
+    if (!g_ev_valid) { for (auto &e : g_ev) HIP_CHECK(hipEventCreate(&e)); g_ev_valid = true; }
+    g_ev_stream = stream;
+    HIP_CHECK(hipEventRecord(g_ev[0], stream));
+
+    // ---- plan ----
+    int *flags = (int *)ws.get("flags", sizeof(int) * (size_t)m);
+    int *user_nslots = (int *)ws.get("user_nslots", sizeof(int) * (size_t)m);
+    int *uslot_base = (int *)ws.get("uslot_base", sizeof(int) * (size_t)m);
+    Plan *plan = (Plan *)ws.get("plan", sizeof(Plan));
+    HIP_CHECK(hipMemsetAsync(plan, 0, sizeof(Plan), stream));
+    ClassifyArgs ca{m, n, K, c.train_p, c.test_p, req, c.cold ? 1 : 0, min_items_pool, min_pos_test, want_auc ? 1 : 0,
+                    flags, user_nslots, plan};
+    hipLaunchKernelGGL(k_classify, dim3(cdiv(m, 256)), dim3(256), 0, stream, ca);
+    hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, user_nslots, uslot_base, m, &plan->n_slots);
+    hipLaunchKernelGGL(k_plan_classes, dim3(1), dim3(1), 0, stream, plan);
+    const long long slot_bound = (long long)m + c.nnz_test / POS_CHUNK + 1;
+    const long long group_bound = slot_bound / GROUP_USERS + 2;
+    int *slot_user = (int *)ws.get("slot_user", sizeof(int) * (size_t)slot_bound);
+    int *slot_chunk = (int *)ws.get("slot_chunk", sizeof(int) * (size_t)slot_bound);
+    int *slot_index = (int *)ws.get("slot_index", sizeof(int) * (size_t)slot_bound);
+    unsigned char *slot_j = (unsigned char *)ws.get("slot_j", (size_t)slot_bound);
+    int *gj = (int *)ws.get("gj", sizeof(int) * (size_t)group_bound);
+    long long *grow = (long long *)ws.get("grow", sizeof(long long) * (size_t)group_bound);
+    AssignArgs aa{m, c.test_p, flags, user_nslots, uslot_base, want_auc ? 1 : 0, plan, slot_user, slot_chunk, slot_index, slot_j};
+    hipLaunchKernelGGL(k_assign_slots, dim3(cdiv(m, 256)), dim3(256), 0, stream, aa);
+    hipLaunchKernelGGL(k_group_rows, dim3(1), dim3(1), 0, stream, plan, slot_j, gj, grow);
+    Plan hp;
+    HIP_CHECK(hipMemcpyAsync(&hp, plan, sizeof(Plan), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+
+    const int n_slots = hp.n_slots, n_groups = hp.n_groups;
+    const int jmax = want_auc ? hp.jmax : 0;
+    const int tiles_total = (n + TILE_ITEMS - 1) / TILE_ITEMS;
+    const int n_ublocks = (n_groups + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK;
+
+    // ---- sweep geometry ----
+    int n_splits = 1;
+    if (n_ublocks > 0) {
+        const int want_blocks = 1024;                               // ~4 blocks per CU for tail balance
+        n_splits = std::max(1, want_blocks / n_ublocks);
+        n_splits = std::min(n_splits, std::max(1, tiles_total / 32));
+        n_splits = std::min(n_splits, MAX_PARTS / 2);
+    }
+    const int n_part = 2 * n_splits;
+    const size_t lds_b = 2ull * NG * 2 * TILE_ITEMS * 16;
+    const size_t lds_auc = want_auc ? (size_t)GROUPS_PER_BLOCK * (2 * ((1 << jmax) - 1) + 1) * GROUP_USERS * 4 : 0;
+    const size_t lds_lists = 8ull * K * GROUP_USERS * sizeof(ListEntry);
+    const bool list_in_lds = lds_b + lds_auc + lds_lists <= LDS_LIMIT;
+    const size_t lds_total = lds_b + lds_auc + (list_in_lds ? lds_lists : 0);
+
+    Entry<float> *merged = (Entry<float> *)ws.get("merged", sizeof(Entry<float>) * (size_t)m * K);
+    float *pos_score = nullptr; unsigned *hist = nullptr; int *pos_order = nullptr;
+    Entry<float> *pl = nullptr; PartialStat<float> *pst = nullptr;
+
+    if (n_slots > 0) {
+        // ---- pack operands into the MFMA images ----
+        const long long bp_f4 = (long long)tiles_total * NG * 2 * TILE_ITEMS;
+        const long long ap_f4 = (long long)n_groups * NG * 2 * GROUP_USERS;
+        float4 *Bp = (float4 *)ws.get("Bp", sizeof(float4) * (size_t)bp_f4);
+        float4 *Ap = (float4 *)ws.get("Ap", sizeof(float4) * (size_t)ap_f4);
+        hipLaunchKernelGGL(k_pack_items<T>, dim3(cdiv(bp_f4, 256)), dim3(256), 0, stream, c.B, c.ldb, n, k, NG, Bp, bp_f4);
+        hipLaunchKernelGGL(k_pack_users<T>, dim3(cdiv(ap_f4, 256)), dim3(256), 0, stream, c.A, c.lda, k, NG, slot_user, n_slots, Ap, ap_f4);
+
+        // ---- positives ----
+        if (want_auc) {
+            const long long rows = hp.total_rows;
+            pos_score = (float *)ws.get("pos_score", sizeof(float) * (size_t)(rows + 1) * GROUP_USERS);
+            hist = (unsigned *)ws.get("hist", sizeof(unsigned) * (size_t)(rows + n_groups + 1) * GROUP_USERS);
+            float *pos_tmp = (float *)ws.get("pos_tmp", sizeof(float) * (size_t)std::max<long long>(c.nnz_test, 1));
+            pos_order = (int *)ws.get("pos_order", sizeof(int) * (size_t)std::max<long long>(c.nnz_test, 1));
+            if (rows > 0)
+                hipLaunchKernelGGL(k_fill<float>, dim3(cdiv(rows * GROUP_USERS, 256)), dim3(256), 0, stream,
+                                   pos_score, INFINITY, rows * GROUP_USERS);
+            HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(unsigned) * (size_t)(rows + n_groups) * GROUP_USERS, stream));
+            PosArgs<T> pa{m, n, k, c.A, c.lda, c.B, c.ldb, c.train_p, c.train_i, c.test_p, c.test_i,
+                          flags, user_nslots, uslot_base, slot_index, grow, pos_tmp, pos_order, pos_score};
+            hipLaunchKernelGGL(k_pos_scores<T>, dim3(cdiv((long long)m * WAVE, 256)), dim3(256), 0, stream, pa);
+            hipLaunchKernelGGL(k_pos_place<T>, dim3(cdiv((long long)m * WAVE, 256)), dim3(256), 0, stream, pa);
+        }
+
+        pl = (Entry<float> *)ws.get("pl", sizeof(Entry<float>) * (size_t)n_slots * n_part * K);
+        pst = (PartialStat<float> *)ws.get("pst", sizeof(PartialStat<float>) * (size_t)n_slots * n_part);
+        ListEntry *glists = nullptr;
+        const unsigned n_blocks = (unsigned)n_ublocks * n_splits;
+        if (!list_in_lds) glists = (ListEntry *)ws.get("glists", sizeof(ListEntry) * (size_t)n_blocks * 8 * K * GROUP_USERS);
+
+        SweepArgs sa{};
+        sa.n = n; sa.K = K; sa.n_slots = n_slots; sa.n_groups = n_groups; sa.n_ublocks = n_ublocks;
+        sa.n_splits = n_splits; sa.tiles_total = tiles_total; sa.jmax = jmax; sa.list_in_lds = list_in_lds ? 1 : 0;
+        sa.Ap = Ap; sa.Bp = Bp; sa.slot_user = slot_user; sa.slot_chunk = slot_chunk;
+        sa.train_p = c.train_p; sa.train_i = c.train_i; sa.gj = gj; sa.grow = grow;
+        sa.pos_score = pos_score; sa.hist = hist; sa.glists = glists; sa.pl = pl; sa.pst = pst; sa.dump = nullptr;
+
+        HIP_CHECK(hipEventRecord(g_ev[1], stream));
+        if (want_auc) launch_sweep<true, false>(NG, dim3(n_blocks), lds_total, stream, sa);
+        else          launch_sweep<false, false>(NG, dim3(n_blocks), lds_total, stream, sa);
+        HIP_CHECK(hipEventRecord(g_ev[2], stream));
+        g_timings[4] = 1; g_timings[5] = n_splits; g_timings[6] = n_blocks; g_timings[7] = (double)lds_total;
+    } else {
+        HIP_CHECK(hipEventRecord(g_ev[1], stream));
+        HIP_CHECK(hipEventRecord(g_ev[2], stream));
+        g_timings[4] = 0; g_timings[5] = 0; g_timings[6] = 0; g_timings[7] = 0;
+    }
+
+    // ---- finalize ----
+    std::vector<double> lt((size_t)K);
+    for (int i = 0; i < K; i++) lt[i] = std::log2(i + 2);          // same call as reference :620,:902 (int -> double log2)
+    double *log2tab = (double *)ws.get("log2tab", sizeof(double) * (size_t)K);
+    HIP_CHECK(hipMemcpyAsync(log2tab, lt.data(), sizeof(double) * (size_t)K, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));                        // lt is a stack-owned staging buffer
+
+    long long *rank_sorted = nullptr;
+    if (c.pos_rank) rank_sorted = (long long *)ws.get("rank_sorted", sizeof(long long) * (size_t)std::max<long long>(c.nnz_test, 1));
+    FinalArgs<T, float> fa{};
+    fa.m = m; fa.n = n; fa.K = K; fa.n_part = n_part; fa.req = req; fa.cumulative = c.cumulative ? 1 : 0; fa.noise = c.noise ? 1 : 0;
+    fa.train_p = c.train_p; fa.test_p = c.test_p; fa.test_i = c.test_i; fa.test_v = c.test_v;
+    fa.flags = flags; fa.user_nslots = user_nslots; fa.uslot_base = uslot_base; fa.slot_index = slot_index;
+    fa.gj = gj; fa.grow = grow; fa.pl = pl; fa.pst = pst; fa.hist = hist; fa.pos_score = pos_score; fa.log2tab = log2tab;
+    fa.p = c.out[0]; fa.tp = c.out[1]; fa.r = c.out[2]; fa.ap = c.out[3]; fa.tap = c.out[4];
+    fa.ndcg = c.out[5]; fa.hit = c.out[6]; fa.rr = c.out[7]; fa.roc = c.out[8]; fa.pr = c.out[9];
+    fa.merged = merged; fa.rank_sorted = rank_sorted; fa.status = c.status;
+    hipLaunchKernelGGL((k_finalize<T, float>), dim3(cdiv(m, 128)), dim3(128), 0, stream, fa);
+    HIP_CHECK(hipGetLastError());
+    if (c.topk_idx)
+        hipLaunchKernelGGL(k_export_rank<float>, dim3(cdiv((long long)m * K, 256)), dim3(256), 0, stream, m, K, merged, c.topk_idx, c.topk_score);
+    if (c.pos_rank) {
+        if (want_auc && n_slots > 0)
+            hipLaunchKernelGGL(k_export_pos_rank, dim3(cdiv(m, 128)), dim3(128), 0, stream, c.nnz_test, m, c.test_p, pos_order, rank_sorted, c.pos_rank);
+        else
+            HIP_CHECK(hipMemsetAsync(c.pos_rank, 0, sizeof(long long) * (size_t)c.nnz_test, stream));
+    }
+    HIP_CHECK(hipEventRecord(g_ev[3], stream));
+    HIP_CHECK(hipGetLastError());
+}
+
+void run_f64(const Call<double> &, hipStream_t)
+{
+    throw RmError{RM_ERR_UNSUPPORTED, "fp64 device path not built yet"};
+}
+
+template <class T> void run(const Call<T> &c, hipStream_t s);
+template <> void run<float>(const Call<float> &c, hipStream_t s) { run_f32(c, s); }
+template <> void run<double>(const Call<double> &c, hipStream_t s) { run_f64(c, s); }
+
+template <class T>
+void validate(const T *A, const T *B, int m, int n, int k, const int *trp, const int *tep, const int *tei, int K, size_t lda, size_t ldb)
+{
+    if (!A || !B || !trp || !tep || !tei) throw RmError{RM_ERR_INVALID, "null input pointer"};
+    if (m <= 0 || n <= 0 || k <= 0) throw RmError{RM_ERR_INVALID, "m, n, k must be positive"};
+    if (K <= 0) throw RmError{RM_ERR_INVALID, "k_metrics must be positive"};
+    if (lda < (size_t)k || ldb < (size_t)k) throw RmError{RM_ERR_INVALID, "leading dimension smaller than k"};
+}
+
+template <class F> int guarded(F &&f)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_err.clear();
+    try { f(); return RM_OK; }
+    catch (const RmError &e) { g_err = e.msg; return e.code; }
+    catch (const std::bad_alloc &) { g_err = "host allocation failed"; return RM_ERR_NOMEM; }
+    catch (const std::exception &e) { g_err = e.what(); return RM_ERR_HIP; }
+}
+
+// host-pointer entry: stage inputs into HBM, run, copy the requested outputs back
+template <class T>
+void run_host(const T *A, size_t lda, const T *B, size_t ldb, int m, int n, int k,
+              const int *trp, const int *tri, const int *tep, const int *tei, const T *tev,
+              int K, bool cumulative, bool noise, T *const outs[10], bool cold, int mip, int mpt,
+              int *topk_idx, T *topk_score, long long *pos_rank, int *status)
+{
+    validate(A, B, m, n, k, trp, tep, tei, K, lda, ldb);
+    Workspace &ws = workspace();
+    hipStream_t stream = nullptr;
+    const long long nnz_tr = trp[m], nnz_te = tep[m];
+    if (nnz_tr > 0 && !tri) throw RmError{RM_ERR_INVALID, "null train indices"};
+    Call<T> c{};
+    // A and B are copied densely (rows of k), so the device leading dimension is k
+    T *dA = (T *)ws.get("in_A", sizeof(T) * (size_t)m * k);
+    T *dB = (T *)ws.get("in_B", sizeof(T) * (size_t)n * k);
+    HIP_CHECK(hipMemcpy2DAsync(dA, sizeof(T) * k, A, sizeof(T) * lda, sizeof(T) * k, m, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpy2DAsync(dB, sizeof(T) * k, B, sizeof(T) * ldb, sizeof(T) * k, n, hipMemcpyHostToDevice, stream));
+    int *dtrp = (int *)ws.get("in_trp", sizeof(int) * (size_t)(m + 1));
+    int *dtep = (int *)ws.get("in_tep", sizeof(int) * (size_t)(m + 1));
+    int *dtri = (int *)ws.get("in_tri", sizeof(int) * (size_t)std::max<long long>(nnz_tr, 1));
+    int *dtei = (int *)ws.get("in_tei", sizeof(int) * (size_t)std::max<long long>(nnz_te, 1));
+    T *dtev = nullptr;
+    HIP_CHECK(hipMemcpyAsync(dtrp, trp, sizeof(int) * (size_t)(m + 1), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(dtep, tep, sizeof(int) * (size_t)(m + 1), hipMemcpyHostToDevice, stream));
+    if (nnz_tr > 0) HIP_CHECK(hipMemcpyAsync(dtri, tri, sizeof(int) * (size_t)nnz_tr, hipMemcpyHostToDevice, stream));
+    if (nnz_te > 0) HIP_CHECK(hipMemcpyAsync(dtei, tei, sizeof(int) * (size_t)nnz_te, hipMemcpyHostToDevice, stream));
+    if (tev) {
+        dtev = (T *)ws.get("in_tev", sizeof(T) * (size_t)std::max<long long>(nnz_te, 1));
+        if (nnz_te > 0) HIP_CHECK(hipMemcpyAsync(dtev, tev, sizeof(T) * (size_t)nnz_te, hipMemcpyHostToDevice, stream));
+    }
+    if (outs[5] && !tev) throw RmError{RM_ERR_INVALID, "NDCG requested without test values"};
+    c.A = dA; c.lda = k; c.B = dB; c.ldb = k; c.m = m; c.n = n; c.k = k;
+    c.train_p = dtrp; c.train_i = dtri; c.nnz_train = nnz_tr; c.test_p = dtep; c.test_i = dtei; c.test_v = dtev; c.nnz_test = nnz_te;
+    c.K = K; c.cumulative = cumulative; c.noise = noise; c.cold = cold; c.min_items_pool = mip; c.min_pos_test = mpt;
+    const size_t per = cumulative ? (size_t)m * K : (size_t)m;
+    static const char *onames[10] = {"o_p", "o_tp", "o_r", "o_ap", "o_tap", "o_ndcg", "o_hit", "o_rr", "o_roc", "o_pr"};
+    for (int i = 0; i < 10; i++) {
+        const size_t cnt = i >= 8 ? (size_t)m : per;
+        c.out[i] = outs[i] ? (T *)ws.get(onames[i], sizeof(T) * cnt) : nullptr;
+    }
+    if (topk_idx) {
+        c.topk_idx = (int *)ws.get("o_topk_idx", sizeof(int) * (size_t)m * K);
+        c.topk_score = (T *)ws.get("o_topk_score", sizeof(T) * (size_t)m * K);
+        c.pos_rank = (long long *)ws.get("o_pos_rank", sizeof(long long) * (size_t)std::max<long long>(nnz_te, 1));
+        c.status = (int *)ws.get("o_status", sizeof(int) * (size_t)m);
+    }
+    run<T>(c, stream);
+    for (int i = 0; i < 10; i++) {
+        const size_t cnt = i >= 8 ? (size_t)m : per;
+        if (outs[i]) HIP_CHECK(hipMemcpyAsync(outs[i], c.out[i], sizeof(T) * cnt, hipMemcpyDeviceToHost, stream));
+    }
+    if (topk_idx) {
+        HIP_CHECK(hipMemcpyAsync(topk_idx, c.topk_idx, sizeof(int) * (size_t)m * K, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(topk_score, c.topk_score, sizeof(T) * (size_t)m * K, hipMemcpyDeviceToHost, stream));
+        if (nnz_te > 0) HIP_CHECK(hipMemcpyAsync(pos_rank, c.pos_rank, sizeof(long long) * (size_t)nnz_te, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(status, c.status, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+void debug_scores_f32(const float *A, size_t lda, const float *B, size_t ldb, int m, int n, int k, float *out)
+{
+    if (!A || !B || !out || m <= 0 || n <= 0 || k <= 0) throw RmError{RM_ERR_INVALID, "bad argument"};
+    const int NG = supported_ng(k);
+    if (NG < 0) throw RmError{RM_ERR_UNSUPPORTED, "fp32 path supports up to 128 factors"};
+    Workspace &ws = workspace();
+    hipStream_t stream = nullptr;
+    float *dA = (float *)ws.get("in_A", sizeof(float) * (size_t)m * k);
+    float *dB = (float *)ws.get("in_B", sizeof(float) * (size_t)n * k);
+    HIP_CHECK(hipMemcpy2DAsync(dA, sizeof(float) * k, A, sizeof(float) * lda, sizeof(float) * k, m, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpy2DAsync(dB, sizeof(float) * k, B, sizeof(float) * ldb, sizeof(float) * k, n, hipMemcpyHostToDevice, stream));
+    const int n_groups = (m + GROUP_USERS - 1) / GROUP_USERS, n_ublocks = (n_groups + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK;
+    const int tiles_total = (n + TILE_ITEMS - 1) / TILE_ITEMS;
+    int *slot_user = (int *)ws.get("slot_user", sizeof(int) * (size_t)m);
+    int *zeros = (int *)ws.get("dbg_zeros", sizeof(int) * (size_t)(m + 1 + n_groups));
+    long long *grow = (long long *)ws.get("grow", sizeof(long long) * (size_t)n_groups);
+    HIP_CHECK(hipMemsetAsync(zeros, 0, sizeof(int) * (size_t)(m + 1 + n_groups), stream));
+    HIP_CHECK(hipMemsetAsync(grow, 0, sizeof(long long) * (size_t)n_groups, stream));
+    hipLaunchKernelGGL(k_iota<int>, dim3(cdiv(m, 256)), dim3(256), 0, stream, slot_user, m);
+    const long long bp_f4 = (long long)tiles_total * NG * 2 * TILE_ITEMS, ap_f4 = (long long)n_groups * NG * 2 * GROUP_USERS;
+    float4 *Bp = (float4 *)ws.get("Bp", sizeof(float4) * (size_t)bp_f4);
+    float4 *Ap = (float4 *)ws.get("Ap", sizeof(float4) * (size_t)ap_f4);
+    hipLaunchKernelGGL(k_pack_items<float>, dim3(cdiv(bp_f4, 256)), dim3(256), 0, stream, dB, (size_t)k, n, k, NG, Bp, bp_f4);
+    hipLaunchKernelGGL(k_pack_users<float>, dim3(cdiv(ap_f4, 256)), dim3(256), 0, stream, dA, (size_t)k, k, NG, slot_user, m, Ap, ap_f4);
+    float *dump = (float *)ws.get("dbg_dump", sizeof(float) * (size_t)m * n);
+    const int K = 1;
+    ListEntry *glists = (ListEntry *)ws.get("glists", sizeof(ListEntry) * (size_t)n_ublocks * 8 * K * GROUP_USERS);
+    SweepArgs sa{};
+    sa.n = n; sa.K = K; sa.n_slots = m; sa.n_groups = n_groups; sa.n_ublocks = n_ublocks; sa.n_splits = 1;
+    sa.tiles_total = tiles_total; sa.jmax = 0; sa.list_in_lds = 0; sa.Ap = Ap; sa.Bp = Bp;
+    sa.slot_user = slot_user; sa.slot_chunk = zeros; sa.train_p = zeros; sa.train_i = zeros; sa.gj = zeros + m + 1; sa.grow = grow;
+    sa.glists = glists; sa.dump = dump;
+    launch_sweep<false, true>(NG, dim3(n_ublocks), 2ull * NG * 2 * TILE_ITEMS * 16, stream, sa);
+    HIP_CHECK(hipMemcpyAsync(out, dump, sizeof(float) * (size_t)m * n, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+} // namespace
+
+// =====================================================================================================================
+// C-ABI
+// =====================================================================================================================
+#define RM_HOST_ENTRY(SUFFIX, T)                                                                                        \
+extern "C" int rm_calc_metrics_##SUFFIX(                                                                                \
+    const T *A, size_t lda, const T *B, size_t ldb, int32_t m, int32_t n, int32_t k,                                    \
+    const int32_t *Xtrain_csr_p, const int32_t *Xtrain_csr_i,                                                           \
+    const int32_t *Xtest_csr_p, const int32_t *Xtest_csr_i, const T *Xtest_csr,                                         \
+    int32_t k_metrics, int cumulative, int break_ties_with_noise,                                                       \
+    T *p_at_k, T *tp_at_k, T *r_at_k, T *ap_at_k, T *tap_at_k, T *ndcg_at_k, T *hit_at_k, T *rr_at_k,                   \
+    T *roc_auc, T *pr_auc, int consider_cold_start, int32_t min_items_pool, int32_t min_pos_test,                       \
+    int32_t nthreads, uint64_t seed)                                                                                    \
+{                                                                                                                       \
+    (void)nthreads; (void)seed;                                                                                         \
+    return guarded([&] {                                                                                                \
+        T *outs[10] = {p_at_k, tp_at_k, r_at_k, ap_at_k, tap_at_k, ndcg_at_k, hit_at_k, rr_at_k, roc_auc, pr_auc};      \
+        run_host<T>(A, lda, B, ldb, m, n, k, Xtrain_csr_p, Xtrain_csr_i, Xtest_csr_p, Xtest_csr_i, Xtest_csr,           \
+                    k_metrics, cumulative != 0, break_ties_with_noise != 0, outs, consider_cold_start != 0,             \
+                    min_items_pool, min_pos_test, nullptr, nullptr, nullptr, nullptr);                                  \
+    });                                                                                                                 \
+}                                                                                                                       \
+extern "C" int rm_calc_metrics_dev_##SUFFIX(                                                                            \
+    const T *A, size_t lda, const T *B, size_t ldb, int32_t m, int32_t n, int32_t k,                                    \
+    const int32_t *Xtrain_csr_p, const int32_t *Xtrain_csr_i, int64_t nnz_train,                                        \
+    const int32_t *Xtest_csr_p, const int32_t *Xtest_csr_i, const T *Xtest_csr, int64_t nnz_test,                       \
+    int32_t k_metrics, int cumulative, int break_ties_with_noise,                                                       \
+    T *p_at_k, T *tp_at_k, T *r_at_k, T *ap_at_k, T *tap_at_k, T *ndcg_at_k, T *hit_at_k, T *rr_at_k,                   \
+    T *roc_auc, T *pr_auc, int consider_cold_start, int32_t min_items_pool, int32_t min_pos_test,                       \
+    uint64_t seed, void *stream)                                                                                        \
+{                                                                                                                       \
+    (void)seed;                                                                                                         \
+    return guarded([&] {                                                                                                \
+        validate(A, B, m, n, k, Xtrain_csr_p, Xtest_csr_p, Xtest_csr_i, k_metrics, lda, ldb);                           \
+        if (ndcg_at_k && !Xtest_csr) throw RmError{RM_ERR_INVALID, "NDCG requested without test values"};               \
+        Call<T> c{};                                                                                                    \
+        c.A = A; c.lda = lda; c.B = B; c.ldb = ldb; c.m = m; c.n = n; c.k = k;                                          \
+        c.train_p = Xtrain_csr_p; c.train_i = Xtrain_csr_i; c.nnz_train = nnz_train;                                    \
+        c.test_p = Xtest_csr_p; c.test_i = Xtest_csr_i; c.test_v = Xtest_csr; c.nnz_test = nnz_test;                    \
+        c.K = k_metrics; c.cumulative = cumulative != 0; c.noise = break_ties_with_noise != 0;                          \
+        T *outs[10] = {p_at_k, tp_at_k, r_at_k, ap_at_k, tap_at_k, ndcg_at_k, hit_at_k, rr_at_k, roc_auc, pr_auc};      \
+        for (int i = 0; i < 10; i++) c.out[i] = outs[i];                                                                \
+        c.cold = consider_cold_start != 0; c.min_items_pool = min_items_pool; c.min_pos_test = min_pos_test;            \
+        run<T>(c, (hipStream_t)stream);                                                                                 \
+    });                                                                                                                 \
+}                                                                                                                       \
+extern "C" int rm_rank_##SUFFIX(                                                                                        \
+    const T *A, size_t lda, const T *B, size_t ldb, int32_t m, int32_t n, int32_t k,                                    \
+    const int32_t *Xtrain_csr_p, const int32_t *Xtrain_csr_i, const int32_t *Xtest_csr_p, const int32_t *Xtest_csr_i,   \
+    int32_t k_metrics, int break_ties_with_noise, int consider_cold_start, int32_t min_items_pool,                      \
+    int32_t min_pos_test, uint64_t seed, int32_t *topk_idx, T *topk_score, int64_t *pos_rank, int32_t *status)          \
+{                                                                                                                       \
+    (void)seed;                                                                                                         \
+    return guarded([&] {                                                                                                \
+        if (!topk_idx || !topk_score || !pos_rank || !status) throw RmError{RM_ERR_INVALID, "null output pointer"};     \
+        std::vector<T> ap((size_t)std::max(m, 1)), roc((size_t)std::max(m, 1)), pr((size_t)std::max(m, 1));             \
+        T *outs[10] = {nullptr, nullptr, nullptr, ap.data(), nullptr, nullptr, nullptr, nullptr, roc.data(), pr.data()};\
+        run_host<T>(A, lda, B, ldb, m, n, k, Xtrain_csr_p, Xtrain_csr_i, Xtest_csr_p, Xtest_csr_i, (const T *)nullptr,  \
+                    k_metrics, false, break_ties_with_noise != 0, outs, consider_cold_start != 0,                       \
+                    min_items_pool, min_pos_test, topk_idx, topk_score, (long long *)pos_rank, status);                 \
+    });                                                                                                                 \
+}
+
+RM_HOST_ENTRY(f32, float)
+RM_HOST_ENTRY(f64, double)
+
+extern "C" int rm_debug_scores_f32(const float *A, size_t lda, const float *B, size_t ldb, int32_t m, int32_t n, int32_t k, float *out)
+{
+    return guarded([&] { debug_scores_f32(A, lda, B, ldb, m, n, k, out); });
+}
+
+extern "C" int rm_debug_scores_f64(const double *, size_t, const double *, size_t, int32_t, int32_t, int32_t, double *)
+{
+    return guarded([&] { throw RmError{RM_ERR_UNSUPPORTED, "fp64 device path not built yet"}; });
+}
+
+extern "C" int rm_has_openmp(void) { return 1; }
+
+extern "C" const char *rm_last_error(void) { return g_err.c_str(); }
+
+extern "C" int rm_device_count(void)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+extern "C" int rm_set_device(int device)
+{
+    return guarded([&] { HIP_CHECK(hipSetDevice(device)); });
+}
+
+extern "C" int rm_get_timings(double *out, int n)
+{
+    if (!out || n <= 0 || !g_ev_valid) return 0;
+    if (hipEventSynchronize(g_ev[3]) != hipSuccess) return 0;
+    float a = 0, b = 0, c = 0, d = 0;
+    (void)hipEventElapsedTime(&a, g_ev[0], g_ev[1]);
+    (void)hipEventElapsedTime(&b, g_ev[1], g_ev[2]);
+    (void)hipEventElapsedTime(&c, g_ev[2], g_ev[3]);
+    (void)hipEventElapsedTime(&d, g_ev[0], g_ev[3]);
+    g_timings[0] = a; g_timings[1] = b; g_timings[2] = c; g_timings[3] = d;
+    const int cnt = n < 8 ? n : 8;
+    for (int i = 0; i < cnt; i++) out[i] = g_timings[i];
+    return cnt;
+}
+
+extern "C" int rm_release_workspace(void)
+{
+    return guarded([&] { workspace().release(); });
+}

@@ -1,0 +1,268 @@
+// rm_prep.hpp -- plan building, operand packing and positive-score kernels (everything before the sweep).
+//
+// Replaces, on device, the per-user bookkeeping of reference src/recometrics.hpp:439-497 (eligibility filter,
+// candidate list) -- the candidate list itself is never materialised: train-item masking is a predicate in the
+// sweep's epilogue.
+#pragma once
+#include "rm_device.hpp"
+
+namespace rm {
+
+struct ClassifyArgs {
+    int m, n, K;
+    const int *train_p, *test_p;
+    int req;                 // RQ_* mask
+    int cold, min_items_pool, min_pos_test;     // already clamped as reference recometrics.hpp:390-393
+    int want_auc;            // ROC or PR requested
+    int *flags;              // [m]
+    int *user_nslots;        // [m]
+    Plan *plan;
+};
+
+__device__ __forceinline__ int chunk_depth(int pc)      // smallest j with 2^j - 1 >= pc   (pc in 1..63)
+{
+    return 32 - __clz(pc);
+}
+
+// reference recometrics.hpp:439-448, :479-486  (one thread per user)
+__global__ void k_classify(ClassifyArgs a)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= a.m) return;
+    const int ntr = a.train_p[u + 1] - a.train_p[u];
+    const int npos = a.test_p[u + 1] - a.test_p[u];
+    const int cand = a.n - ntr;
+    bool isnan_user = npos <= 0 || (ntr + npos >= a.n && !(a.req & RQ_NDCG)) || cand < a.min_items_pool ||
+                      (!a.cold && ntr == 0) || npos < a.min_pos_test;
+    const bool only_ndcg = (ntr + npos) >= a.n;
+    const bool kleqn = cand <= a.K;
+    if (!isnan_user && kleqn && !(a.req & (RQ_ROC | RQ_PR | RQ_AP | RQ_TAP | RQ_RR))) isnan_user = true;
+    int f = 0, nsl = 0;
+    if (isnan_user) f = UF_NAN;
+    else {
+        f = UF_ACTIVE | (only_ndcg ? UF_ONLY_NDCG : 0) | (kleqn ? UF_KLEQN : 0);
+        atomicAdd(&a.plan->n_active, 1);
+        if (a.want_auc && !only_ndcg) {
+            const int nfull = npos / POS_CHUNK, rem = npos % POS_CHUNK;
+            nsl = nfull + (rem ? 1 : 0);
+            if (nfull) atomicAdd(&a.plan->class_count[MAX_J], nfull);
+            if (rem) atomicAdd(&a.plan->class_count[chunk_depth(rem)], 1);
+        } else {
+            nsl = 1;
+            atomicAdd(&a.plan->class_count[0], 1);
+        }
+    }
+    a.flags[u] = f;
+    a.user_nslots[u] = nsl;
+}
+
+// exclusive scan of int array by ONE block of 1024 threads (m <= 2^31; a few hundred iterations at m = 1M)
+__global__ void k_scan_exclusive(const int *in, int *out, int count, int *total_out)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < count; base += 1024) {
+        const int i = base + tid;
+        const int v = i < count ? in[i] : 0;
+        int x = v;
+        #pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        const int carry = carry_s;
+        if (i < count) out[i] = carry + woff + x - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+    if (tid == 0 && total_out) *total_out = carry_s;
+}
+
+__global__ void k_plan_classes(Plan *p)      // one thread
+{
+    int off = 0, jmax = 0;
+    for (int j = 0; j <= MAX_J; j++) {
+        p->class_offset[j] = off;
+        off += p->class_count[j];
+        if (p->class_count[j]) jmax = j;
+        p->class_cursor[j] = 0;
+    }
+    p->class_offset[MAX_J + 1] = off;
+    p->n_groups = (p->n_slots + GROUP_USERS - 1) / GROUP_USERS;
+    p->jmax = jmax;
+}
+
+struct AssignArgs {
+    int m;
+    const int *test_p, *flags, *user_nslots, *uslot_base;
+    int want_auc;
+    Plan *plan;
+    int *slot_user, *slot_chunk, *slot_index;
+    unsigned char *slot_j;
+};
+
+// scatter every (user, chunk) into its depth class; order inside a class is arbitrary (results do not depend on it)
+__global__ void k_assign_slots(AssignArgs a)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= a.m) return;
+    const int nsl = a.user_nslots[u];
+    if (!nsl) return;
+    const int npos = a.test_p[u + 1] - a.test_p[u];
+    const bool auc_user = a.want_auc && !(a.flags[u] & UF_ONLY_NDCG);
+    for (int c = 0; c < nsl; c++) {
+        int j = 0;
+        if (auc_user) { const int pc = min(POS_CHUNK, npos - c * POS_CHUNK); j = chunk_depth(pc); }
+        const int pos = a.plan->class_offset[j] + atomicAdd(&a.plan->class_cursor[j], 1);
+        a.slot_user[pos] = u;
+        a.slot_chunk[pos] = c;
+        a.slot_j[pos] = (unsigned char)j;
+        a.slot_index[a.uslot_base[u] + c] = pos;
+    }
+}
+
+// per sweep block (4 groups): uniform tree depth jb = depth of its last slot; row base of each group.  One thread.
+__global__ void k_group_rows(Plan *p, const unsigned char *slot_j, int *gj, long long *grow)
+{
+    const int ng = p->n_groups, ns = p->n_slots;
+    long long rows = 0;
+    for (int b = 0; b * GROUPS_PER_BLOCK < ng; b++) {
+        const int glast = min(ng, (b + 1) * GROUPS_PER_BLOCK) - 1;
+        const int slast = min(ns, (glast + 1) * GROUP_USERS) - 1;
+        const int jb = slot_j[slast];
+        const int pl = (1 << jb) - 1;
+        for (int g = b * GROUPS_PER_BLOCK; g <= glast; g++) { gj[g] = jb; grow[g] = rows; rows += pl; }
+    }
+    p->total_rows = rows;
+}
+
+template <class T> __global__ void k_fill(T *p, T v, long long count)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) p[i] = v;
+}
+
+// ---- operand packing: the packed layouts ARE the LDS / register images the MFMA loop reads -----------------------
+// fp32, v_mfma_f32_32x32x2_f32: lane (r = lane & 31, h = lane >> 5) supplies element [r][k = 2*step + h].  A b128
+// read covers 4 steps, so a lane wants the 4 factors k = 8g + 2i + h (i = 0..3) contiguous:
+//   packed[tile][g][h][row][i] = X[tile*ROWS + row][8g + 2i + h]        (zero for k >= k or row >= rows)
+// The k order of the accumulate chain is unchanged: step 4g+i adds k = 8g+2i (h = 0) then k = 8g+2i+1 (h = 1).
+template <class T>
+__global__ void k_pack_items(const T *B, size_t ldb, int n, int k, int NG, float4 *Bp, long long total_f4)
+{
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // one float4 of the image per thread
+    if (o >= total_f4) return;
+    const int row = (int)(o % TILE_ITEMS);
+    const int h = (int)((o / TILE_ITEMS) & 1);
+    const long long tg = o / (2 * TILE_ITEMS);
+    const int g = (int)(tg % NG);
+    const long long tile = tg / NG;
+    const long long item = tile * TILE_ITEMS + row;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (item < n) {
+        const T *src = B + (size_t)item * ldb;
+        #pragma unroll
+        for (int i = 0; i < 4; i++) { const int kk = 8 * g + 2 * i + h; if (kk < k) v[i] = (float)src[kk]; }
+    }
+    Bp[o] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+template <class T>
+__global__ void k_pack_users(const T *A, size_t lda, int k, int NG, const int *slot_user, int n_slots,
+                             float4 *Ap, long long total_f4)
+{
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= total_f4) return;
+    const int ul = (int)(o % GROUP_USERS);
+    const int h = (int)((o / GROUP_USERS) & 1);
+    const long long gg = o / (2 * GROUP_USERS);
+    const int g = (int)(gg % NG);
+    const long long group = gg / NG;
+    const long long slot = group * GROUP_USERS + ul;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (slot < n_slots) {
+        const T *src = A + (size_t)slot_user[slot] * lda;
+        #pragma unroll
+        for (int i = 0; i < 4; i++) { const int kk = 8 * g + 2 * i + h; if (kk < k) v[i] = (float)src[kk]; }
+    }
+    Ap[o] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// ---- positives: scores of the user's test items (same k-ordered fma chain as the sweep's MFMA), sorted --------------
+template <class T> __device__ __forceinline__ T chain_dot(const T *x, const T *y, int k);
+template <> __device__ __forceinline__ float chain_dot<float>(const float *x, const float *y, int k)
+{
+    float s = 0.f;
+    for (int t = 0; t < k; t++) s = __builtin_fmaf(x[t], y[t], s);
+    return s;
+}
+template <> __device__ __forceinline__ double chain_dot<double>(const double *x, const double *y, int k)
+{
+    double s = 0.;
+    for (int t = 0; t < k; t++) s = __builtin_fma(x[t], y[t], s);
+    return s;
+}
+
+template <class T> struct PosArgs {
+    int m, n, k;
+    const T *A; size_t lda; const T *B; size_t ldb;
+    const int *train_p, *train_i, *test_p, *test_i;
+    const int *flags, *user_nslots, *uslot_base, *slot_index;
+    const long long *grow;
+    T *pos_tmp;          // [nnz_test] score of each test entry (+inf when the item is masked by the train row)
+    int *pos_order;      // [nnz_test] ascending rank of the entry inside its row, order (score asc, item desc)
+    T *pos_score;        // [total_rows][32]
+};
+
+__device__ __forceinline__ bool in_sorted_row(const int *row, int len, int item)
+{
+    int lo = 0, hi = len;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (row[mid] < item) lo = mid + 1; else hi = mid; }
+    return lo < len && row[lo] == item;
+}
+
+// one wavefront per user
+template <class T>
+__global__ void k_pos_scores(PosArgs<T> a)
+{
+    const int u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (u >= a.m || !(a.flags[u] & UF_ACTIVE) || (a.flags[u] & UF_ONLY_NDCG)) return;
+    const int te0 = a.test_p[u], te1 = a.test_p[u + 1];
+    const int tr0 = a.train_p[u], ntr = a.train_p[u + 1] - tr0;
+    const T *Au = a.A + (size_t)u * a.lda;
+    for (int e = te0 + lane; e < te1; e += WAVE) {
+        const int item = a.test_i[e];
+        T s;
+        if (ntr && in_sorted_row(a.train_i + tr0, ntr, item)) s = (T)__int_as_float(0x7f800000);
+        else s = chain_dot<T>(Au, a.B + (size_t)item * a.ldb, a.k);
+        a.pos_tmp[e] = s;
+    }
+}
+
+template <class T>
+__global__ void k_pos_place(PosArgs<T> a)
+{
+    const int u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (u >= a.m || !(a.flags[u] & UF_ACTIVE) || (a.flags[u] & UF_ONLY_NDCG)) return;
+    const int te0 = a.test_p[u], te1 = a.test_p[u + 1];
+    for (int e = te0 + lane; e < te1; e += WAVE) {
+        const T s = a.pos_tmp[e];
+        const int item = a.test_i[e];
+        int rank = 0;
+        for (int f = te0; f < te1; f++) {
+            const T sf = a.pos_tmp[f];
+            rank += (sf < s) || (sf == s && a.test_i[f] > item);
+        }
+        a.pos_order[e] = rank;
+        const int c = rank / POS_CHUNK, r = rank % POS_CHUNK;
+        const int slot = a.slot_index[a.uslot_base[u] + c];
+        a.pos_score[(a.grow[slot / GROUP_USERS] + r) * GROUP_USERS + (slot % GROUP_USERS)] = s;
+    }
+}
+
+} // namespace rm
