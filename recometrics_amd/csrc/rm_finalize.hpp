@@ -191,7 +191,7 @@ __global__ void k_finalize(FinalArgs<T, S> a)
             const int g = slot / GROUP_USERS, ul = slot % GROUP_USERS;
             const int PLg = (1 << a.gj[g]) - 1;
             const unsigned *H = a.hist + (a.grow[g] + g) * GROUP_USERS + ul;
-            const S *PS = a.pos_score + a.grow[g] * GROUP_USERS + ul;
+            const S *PS = a.pos_score + (a.grow[g] + g) * GROUP_USERS + ul;
             const int pc = min(POS_CHUNK, npos - c * POS_CHUNK);
             unsigned long long above = 0;                           // candidates scored above positive j of the chunk
             for (int b = PLg; b > pc; b--) above += H[(size_t)b * GROUP_USERS];

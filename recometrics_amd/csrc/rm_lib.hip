@@ -200,13 +200,13 @@ void run_f32(const Call<float> &c, hipStream_t stream)
     }
     const int n_part = 2 * n_splits;
     const size_t lds_b = 2ull * NG * 2 * TILE_ITEMS * 16;
-    const size_t lds_auc = want_auc ? (size_t)GROUPS_PER_BLOCK * (2 * ((1 << jmax) - 1) + 1) * GROUP_USERS * 4 : 0;
+    const size_t lds_auc = want_auc ? (size_t)GROUPS_PER_BLOCK * 2 * (1 << jmax) * GROUP_USERS * 4 : 0;
     const size_t lds_lists = 8ull * K * GROUP_USERS * sizeof(ListEntry);
     const bool list_in_lds = lds_b + lds_auc + lds_lists <= LDS_LIMIT;
     const size_t lds_total = lds_b + lds_auc + (list_in_lds ? lds_lists : 0);
 
     Entry<float> *merged = (Entry<float> *)ws.get("merged", sizeof(Entry<float>) * (size_t)m * K);
-    float *pos_score = nullptr; unsigned *hist = nullptr; int *pos_order = nullptr;
+    float *pos_score = nullptr; unsigned *hist = nullptr; int *pos_order = nullptr; int *sa_pos_item = nullptr;
     Entry<float> *pl = nullptr; PartialStat<float> *pst = nullptr;
 
     if (n_slots > 0) {
@@ -221,16 +221,17 @@ void run_f32(const Call<float> &c, hipStream_t stream)
         // ---- positives ----
         if (want_auc) {
             const long long rows = hp.total_rows;
-            pos_score = (float *)ws.get("pos_score", sizeof(float) * (size_t)(rows + 1) * GROUP_USERS);
+            pos_score = (float *)ws.get("pos_score", sizeof(float) * (size_t)(rows + n_groups + 1) * GROUP_USERS);
+            int *pos_item = (int *)ws.get("pos_item", sizeof(int) * (size_t)(rows + n_groups + 1) * GROUP_USERS);
             hist = (unsigned *)ws.get("hist", sizeof(unsigned) * (size_t)(rows + n_groups + 1) * GROUP_USERS);
             float *pos_tmp = (float *)ws.get("pos_tmp", sizeof(float) * (size_t)std::max<long long>(c.nnz_test, 1));
             pos_order = (int *)ws.get("pos_order", sizeof(int) * (size_t)std::max<long long>(c.nnz_test, 1));
-            if (rows > 0)
-                hipLaunchKernelGGL(k_fill<float>, dim3(cdiv(rows * GROUP_USERS, 256)), dim3(256), 0, stream,
-                                   pos_score, INFINITY, rows * GROUP_USERS);
+            hipLaunchKernelGGL(k_fill<float>, dim3(cdiv((rows + n_groups) * GROUP_USERS, 256)), dim3(256), 0, stream,
+                               pos_score, INFINITY, (rows + n_groups) * GROUP_USERS);
             HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(unsigned) * (size_t)(rows + n_groups) * GROUP_USERS, stream));
             PosArgs<T> pa{m, n, k, c.A, c.lda, c.B, c.ldb, c.train_p, c.train_i, c.test_p, c.test_i,
-                          flags, user_nslots, uslot_base, slot_index, grow, pos_tmp, pos_order, pos_score};
+                          flags, user_nslots, uslot_base, slot_index, grow, pos_tmp, pos_order, pos_score, pos_item};
+            sa_pos_item = pos_item;
             hipLaunchKernelGGL(k_pos_scores<T>, dim3(cdiv((long long)m * WAVE, 256)), dim3(256), 0, stream, pa);
             hipLaunchKernelGGL(k_pos_place<T>, dim3(cdiv((long long)m * WAVE, 256)), dim3(256), 0, stream, pa);
         }
@@ -246,7 +247,7 @@ void run_f32(const Call<float> &c, hipStream_t stream)
         sa.n_splits = n_splits; sa.tiles_total = tiles_total; sa.jmax = jmax; sa.list_in_lds = list_in_lds ? 1 : 0;
         sa.Ap = Ap; sa.Bp = Bp; sa.slot_user = slot_user; sa.slot_chunk = slot_chunk;
         sa.train_p = c.train_p; sa.train_i = c.train_i; sa.gj = gj; sa.grow = grow;
-        sa.pos_score = pos_score; sa.hist = hist; sa.glists = glists; sa.pl = pl; sa.pst = pst; sa.dump = nullptr;
+        sa.pos_score = pos_score; sa.pos_item = sa_pos_item; sa.hist = hist; sa.glists = glists; sa.pl = pl; sa.pst = pst; sa.dump = nullptr;
 
         HIP_CHECK(hipEventRecord(g_ev[1], stream));
         if (want_auc) launch_sweep<true, false>(NG, dim3(n_blocks), lds_total, stream, sa);

@@ -216,7 +216,8 @@ template <class T> struct PosArgs {
     const long long *grow;
     T *pos_tmp;          // [nnz_test] score of each test entry (+inf when the item is masked by the train row)
     int *pos_order;      // [nnz_test] ascending rank of the entry inside its row, order (score asc, item desc)
-    T *pos_score;        // [total_rows][32]
+    T *pos_score;        // [(total_rows + n_groups)][32]: group g owns rows (grow[g] + g) .. + 2^j - 1, last row = +inf pad
+    int *pos_item;       // same shape: item id of each sorted positive (tie resolution)
 };
 
 __device__ __forceinline__ bool in_sorted_row(const int *row, int len, int item)
@@ -261,7 +262,9 @@ __global__ void k_pos_place(PosArgs<T> a)
         a.pos_order[e] = rank;
         const int c = rank / POS_CHUNK, r = rank % POS_CHUNK;
         const int slot = a.slot_index[a.uslot_base[u] + c];
-        a.pos_score[(a.grow[slot / GROUP_USERS] + r) * GROUP_USERS + (slot % GROUP_USERS)] = s;
+        const long long at = (a.grow[slot / GROUP_USERS] + slot / GROUP_USERS + r) * GROUP_USERS + (slot % GROUP_USERS);
+        a.pos_score[at] = s;
+        a.pos_item[at] = item;
     }
 }
 

@@ -32,7 +32,8 @@ struct SweepArgs {
     const int *slot_user, *slot_chunk;
     const int *train_p, *train_i;
     const int *gj; const long long *grow;
-    const float *pos_score;               // [total_rows][32]
+    const float *pos_score;               // [(total_rows + n_groups)][32]  sorted positives, +inf padded (2^j rows per group)
+    const int *pos_item;                  // same shape, item ids (read only when a candidate ties a positive's score)
     unsigned *hist;                       // [(total_rows + n_groups)][32]
     ListEntry *glists;                    // global list scratch when !list_in_lds: [block][wave][K][32]
     ListEntry *pl;                        // partial lists [slot][n_part][K]
@@ -64,7 +65,8 @@ __device__ __forceinline__ void list_insert(ListEntry *L, int K, float s, int it
 // AUC rank counting for one tile: branchless lower_bound of every score in the lane's user's sorted positives
 // (complete tree of 2^J - 1 rows, +inf padded), then one LDS atomic into the rank histogram.
 template <int J>
-__device__ __forceinline__ void auc_pass(const float (&v)[16], const char *posb, char *histb, unsigned &rocacc)
+__device__ __forceinline__ void auc_pass(const float (&v)[16], const char *posb, char *histb, unsigned &rocacc,
+                                         const int *pos_item_g, int sb, int h)
 {
     #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -74,6 +76,18 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], const char *posb,
         for (int st = (J > 0 ? (1 << (J - 1)) : 0); st >= 1; st >>= 1) {
             const float pv = *(const float *)(posb + base + (st - 1) * 128);
             base = (pv < s) ? base + st * 128 : base;
+        }
+        // exact score tie with a positive (row `base` is the first positive not below s; the table has one +inf
+        // pad row, so the read is always in range): the total order is (score desc, item asc), i.e. the candidate
+        // also outranks the equal-scored positives with a LARGER item id.  Rare; positives' item ids stay in HBM.
+        const float nx = *(const float *)(posb + base);
+        if (__any(nx == s)) {
+            if (nx == s) {
+                const int item = sb + mfma32_row(r, h);
+                unsigned t = base;
+                while (t < (unsigned)(((1 << J) - 1) * 128) && *(const float *)(posb + t) == s && pos_item_g[t >> 2] > item) t += 128;
+                base = t;
+            }
         }
         rocacc += base;
         __hip_atomic_fetch_add((unsigned *)(histb + base), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -102,7 +116,7 @@ void k_sweep(SweepArgs a)
     ListEntry *lists_lds = (ListEntry *)p;
     if (a.list_in_lds) p += 8 * K * GROUP_USERS * (int)sizeof(ListEntry);
     const int PLmax = (1 << a.jmax) - 1;
-    float *posL = (float *)p;  p += GROUPS_PER_BLOCK * PLmax * GROUP_USERS * 4;
+    float *posL = (float *)p;  p += GROUPS_PER_BLOCK * (PLmax + 1) * GROUP_USERS * 4;
     unsigned *histL = (unsigned *)p;
 
     const int glast = min(a.n_groups, (blk_u + 1) * GROUPS_PER_BLOCK) - 1;
@@ -145,14 +159,15 @@ void k_sweep(SweepArgs a)
 
     // positives -> LDS, histogram zeroed
     if (AUC) {
-        for (int i = tid; i < GROUPS_PER_BLOCK * PLb * GROUP_USERS; i += SWEEP_THREADS) {
-            const int g4 = i / (PLb * GROUP_USERS), rem = i % (PLb * GROUP_USERS);
+        for (int i = tid; i < GROUPS_PER_BLOCK * (PLb + 1) * GROUP_USERS; i += SWEEP_THREADS) {
+            const int g4 = i / ((PLb + 1) * GROUP_USERS), rem = i % ((PLb + 1) * GROUP_USERS);
             const int gg = blk_u * GROUPS_PER_BLOCK + g4;
-            posL[g4 * PLmax * GROUP_USERS + rem] = gg < a.n_groups ? a.pos_score[a.grow[gg] * GROUP_USERS + rem] : pos_inf_f();
+            posL[g4 * (PLmax + 1) * GROUP_USERS + rem] = gg < a.n_groups ? a.pos_score[(a.grow[gg] + gg) * GROUP_USERS + rem] : pos_inf_f();
         }
         for (int i = tid; i < GROUPS_PER_BLOCK * (PLmax + 1) * GROUP_USERS; i += SWEEP_THREADS) histL[i] = 0;
     }
-    const char *posb = (const char *)(posL + gi * PLmax * GROUP_USERS + ul);
+    const char *posb = (const char *)(posL + gi * (PLmax + 1) * GROUP_USERS + ul);
+    const int *pos_item_g = (AUC && group_ok) ? a.pos_item + (a.grow[group] + group) * GROUP_USERS + ul : nullptr;
     char *histb = (char *)(histL + gi * (PLmax + 1) * GROUP_USERS + ul);
 
     // ---- staging: packed tile (BUF_F4 float4, contiguous) HBM -> registers -> LDS ----
@@ -231,8 +246,15 @@ void k_sweep(SweepArgs a)
                 const bool c = v[r] >= thr;
                 if (__any(c)) {
                     const int item = sb + mfma32_row(r, h);
-                    if (c && h == 0) list_insert(L, K, v[r], item);      // lanes u and u+32 share a user: one half at a time
+                    // lanes u and u+32 carry the same user (two item rows): one half of the wave at a time.  The wave
+                    // barriers keep the compiler from fusing the two predicated inserts into one (legal per thread,
+                    // wrong across lanes).
+                    if (c && h == 0) list_insert(L, K, v[r], item);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                     if (c && h == 1) list_insert(L, K, v[r], item);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                     if (primary) thr = L[(K - 1) * GROUP_USERS].s;
                 }
             }
@@ -241,12 +263,12 @@ void k_sweep(SweepArgs a)
         if (AUC) {
             unsigned rocacc = 0;
             switch (jb) {
-                case 1: auc_pass<1>(v, posb, histb, rocacc); break;
-                case 2: auc_pass<2>(v, posb, histb, rocacc); break;
-                case 3: auc_pass<3>(v, posb, histb, rocacc); break;
-                case 4: auc_pass<4>(v, posb, histb, rocacc); break;
-                case 5: auc_pass<5>(v, posb, histb, rocacc); break;
-                case 6: auc_pass<6>(v, posb, histb, rocacc); break;
+                case 1: auc_pass<1>(v, posb, histb, rocacc, pos_item_g, sb, h); break;
+                case 2: auc_pass<2>(v, posb, histb, rocacc, pos_item_g, sb, h); break;
+                case 3: auc_pass<3>(v, posb, histb, rocacc, pos_item_g, sb, h); break;
+                case 4: auc_pass<4>(v, posb, histb, rocacc, pos_item_g, sb, h); break;
+                case 5: auc_pass<5>(v, posb, histb, rocacc, pos_item_g, sb, h); break;
+                case 6: auc_pass<6>(v, posb, histb, rocacc, pos_item_g, sb, h); break;
                 default: break;
             }
             roc64 += rocacc >> 7;
