@@ -10,7 +10,8 @@ import os
 
 import numpy as np
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "librecometrics_hip.so")
+_LIB_PATH = os.environ.get("RECOMETRICS_HIP_LIB") or os.path.join(
+    os.path.dirname(os.path.abspath(__file__)), "csrc", "librecometrics_hip.so")
 _lib = None
 
 METRIC_ORDER = ("p", "tp", "r", "ap", "tap", "ndcg", "hit", "rr", "roc", "pr")

@@ -1,4 +1,7 @@
-"""Builds recometrics_amd/csrc/librecometrics_hip.so for gfx950 (in-tree; hipcc cross-compiles without a GPU)."""
+"""Builds recometrics_amd/csrc/librecometrics_hip.so for gfx950 (in-tree; hipcc cross-compiles without a GPU).
+
+The library is several translation units (host + prep/finalize kernels, fp32 sweep, fp64 sweeps) compiled in parallel."""
+import concurrent.futures
 import glob
 import os
 import shutil
@@ -6,7 +9,8 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "librecometrics_hip.so")
-SOURCES = ["rm_lib.hip"]
+SOURCES = ["rm_lib.hip", "rm_sweep32.hip", "rm_sweep64_small.hip", "rm_sweep64_large.hip"]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"]
 
 
 def _hipcc():
@@ -29,18 +33,31 @@ def needs_build():
     return any(os.path.getmtime(p) > t for p in _deps())
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return LIB
-    cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
+def _compile(src, extra):
+    obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+    res = subprocess.run([_hipcc()] + FLAGS + list(extra) + ["-c", os.path.join(CSRC, src), "-o", obj],
+                         capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    return LIB
+        raise RuntimeError("hipcc failed on %s:\n%s%s" % (src, res.stdout, res.stderr))
+    return obj, res.stderr
+
+
+def build(force=False, verbose=False, extra_flags=(), out=None):
+    out = out or LIB
+    if not force and out == LIB and not needs_build():
+        return LIB
+    with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        results = list(ex.map(lambda s: _compile(s, extra_flags), SOURCES))
+    if verbose:
+        for _, err in results:
+            print(err)
+    res = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-o", out] + [o for o, _ in results],
+                         capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force=True, verbose="-v" in sys.argv))

@@ -12,7 +12,7 @@ namespace rm {
 constexpr int MAX_PARTS = 128;
 
 template <class T, class S> struct FinalArgs {     // T = real_t of inputs/outputs, S = score type of the sweep
-    int m, n, K, n_part, req, cumulative, noise;
+    int m, n, K, n_part, req, cumulative, noise, gu;
     const int *train_p, *test_p, *test_i; const T *test_v;
     const int *flags, *user_nslots, *uslot_base, *slot_index;
     const int *gj; const long long *grow;
@@ -188,16 +188,17 @@ __global__ void k_finalize(FinalArgs<T, S> a)
         unsigned long long sum_ranks = 0; int h = 0; double ap_full = 0;
         for (int c = nsl - 1; c >= 0; c--) {                       // chunks hold ascending scores: walk them downwards
             const int slot = a.slot_index[base + c];
-            const int g = slot / GROUP_USERS, ul = slot % GROUP_USERS;
+            const int GUr = a.gu;
+            const int g = slot / GUr, ul = slot % GUr;
             const int PLg = (1 << a.gj[g]) - 1;
-            const unsigned *H = a.hist + (a.grow[g] + g) * GROUP_USERS + ul;
-            const S *PS = a.pos_score + (a.grow[g] + g) * GROUP_USERS + ul;
+            const unsigned *H = a.hist + (a.grow[g] + g) * GUr + ul;
+            const S *PS = a.pos_score + (a.grow[g] + g) * GUr + ul;
             const int pc = min(POS_CHUNK, npos - c * POS_CHUNK);
             unsigned long long above = 0;                           // candidates scored above positive j of the chunk
-            for (int b = PLg; b > pc; b--) above += H[(size_t)b * GROUP_USERS];
+            for (int b = PLg; b > pc; b--) above += H[(size_t)b * GUr];
             for (int j = pc - 1; j >= 0; j--) {
-                above += H[(size_t)(j + 1) * GROUP_USERS];
-                if (isinf(PS[(size_t)j * GROUP_USERS]) && PS[(size_t)j * GROUP_USERS] > 0) continue;   // masked by the train row
+                above += H[(size_t)(j + 1) * GUr];
+                if (isinf(PS[(size_t)j * GUr]) && PS[(size_t)j * GUr] > 0) continue;   // masked by the train row
                 const unsigned long long rank = above + 1;
                 sum_ranks += rank; h++;
                 ap_full += (double)h / (double)rank;

@@ -1,0 +1,55 @@
+// rm_launch.hpp -- argument blocks of the two sweep kernels and the launch entry points of their translation units
+// (the sweeps are compiled in separate .hip files so that the build parallelises).
+#pragma once
+#include "rm_device.hpp"
+#include "rm_list.hpp"
+
+namespace rm {
+
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+constexpr int GROUP_USERS64 = 16;      // users on the lanes of one wavefront in the fp64 sweep (MFMA 16x16x4: D column = lane & 15)
+
+struct SweepArgs {
+    int n, K;
+    int n_slots, n_groups, n_ublocks;     // n_ublocks = ceil(n_groups / 4)
+    int n_splits, tiles_total;            // item splits (grid = n_ublocks * n_splits)
+    int jmax;                             // LDS sizing (all blocks)
+    int list_in_lds;
+    const float4 *Ap, *Bp;
+    const int *slot_user, *slot_chunk;
+    const int *train_p, *train_i;
+    const int *gj; const long long *grow;
+    const float *pos_score;               // [(total_rows + n_groups)][32]  sorted positives, +inf padded (2^j rows per group)
+    const int *pos_item;                  // same shape, item ids (read only when a candidate ties a positive's score)
+    unsigned *hist;                       // [(total_rows + n_groups)][32]
+    u32x2 *glists;                        // list scratch in HBM when the lists do not fit LDS: [block][wave][K][32]
+    ListEntry *pl;                        // partial lists [slot][n_part][K]
+    PartialStat<float> *pst;              // [slot][n_part]
+    float *dump;                          // DUMP mode: dense [n_slots][n] scores
+};
+
+struct Sweep64Args {
+    int n, K;
+    int n_slots, n_groups, n_ublocks;
+    int n_splits, tiles_total;
+    int jmax;
+    const f64x2 *Ap, *Bp;
+    const int *slot_user, *slot_chunk;
+    const int *train_p, *train_i;
+    const int *gj; const long long *grow;
+    const double *pos_score;              // [(total_rows + n_groups)][16]
+    const int *pos_item;
+    unsigned *hist;                       // [(total_rows + n_groups)][16]
+    u32x4 *glists;                        // [block][wave][K][16]
+    Entry<double> *pl;                    // [slot][n_part][K]
+    PartialStat<double> *pst;             // [slot][n_part]
+    double *dump;
+};
+
+// return 0 = launched, -1 = unsupported factor-group count, otherwise a hipError_t
+int launch_sweep32(bool auc, bool dump, bool llds, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa);
+int launch_sweep64(bool auc, bool dump, bool llds, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa);
+int launch_sweep64_small(bool auc, bool dump, bool llds, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa);
+int launch_sweep64_large(bool auc, bool dump, bool llds, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa);
+
+} // namespace rm

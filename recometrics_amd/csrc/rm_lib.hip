@@ -17,7 +17,7 @@
 #include "../../include/recometrics_hip.h"
 #include "rm_device.hpp"
 #include "rm_prep.hpp"
-#include "rm_sweep.hpp"
+#include "rm_launch.hpp"
 #include "rm_finalize.hpp"
 
 namespace {
@@ -110,39 +110,64 @@ __global__ void k_export_pos_rank(long long nnz, int m, const int *test_p, const
     for (int e = test_p[u]; e < test_p[u + 1]; e++) pos_rank[e] = rank_sorted[test_p[u] + pos_order[e]];
 }
 
-int supported_ng(int k)
+// ---- per-precision traits: which sweep kernel, which operand image, how many users ride on a wavefront ----
+template <class T> struct Prec;
+template <> struct Prec<float> {
+    static constexpr int GU = GROUP_USERS;               // users per group
+    typedef float4 PackT;  typedef u32x2 ListT;  typedef SweepArgs Args;
+    static int supported_ng(int k) { const int ng = (k + 7) / 8; for (int o : {2, 4, 8, 16}) if (ng <= o) return o; return -1; }
+    static const char *limit() { return "the fp32 path supports up to 128 factors"; }
+    static size_t lds_b(int NG) { return 2ull * NG * 2 * TILE_ITEMS * 16; }
+    static long long items_units(int tiles, int NG) { return (long long)tiles * NG * 2 * TILE_ITEMS; }
+    static long long users_units(int groups, int NG) { return (long long)groups * NG * 2 * GU; }
+};
+template <> struct Prec<double> {
+    static constexpr int GU = GROUP_USERS64;
+    typedef double2 PackT;  typedef u32x4 ListT;  typedef Sweep64Args Args;
+    static int supported_ng(int k) { const int ng = (k + 7) / 8; for (int o : {2, 4, 8, 16, 32}) if (ng <= o) return o; return -1; }
+    static const char *limit() { return "the fp64 path supports up to 256 factors"; }
+    static size_t lds_b(int NG) { return 2ull * std::min(NG, 8) * 4 * TILE_ITEMS * 16; }
+    static long long items_units(int tiles, int NG) { return (long long)tiles * NG * 4 * TILE_ITEMS; }
+    static long long users_units(int groups, int NG) { return (long long)groups * NG * 4 * GU; }
+};
+
+inline void check_launch(int rc)
 {
-    const int ng = (k + 7) / 8;
-    const int opts[4] = {2, 4, 8, 16};
-    for (int o : opts) if (ng <= o) return o;
-    return -1;
+    if (rc == -1) throw RmError{RM_ERR_UNSUPPORTED, "unsupported factor count"};
+    if (rc != 0) throw RmError{RM_ERR_HIP, std::string("sweep launch: ") + hipGetErrorString((hipError_t)rc)};
+}
+inline void dispatch_sweep(bool auc, bool dump, bool llds, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa)
+{
+    check_launch(launch_sweep32(auc, dump, llds, NG, grid, lds, stream, sa));
+}
+inline void dispatch_sweep(bool auc, bool dump, bool llds, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa)
+{
+    check_launch(launch_sweep64(auc, dump, llds, NG, grid, lds, stream, sa));
 }
 
-template <bool AUC, bool DUMP>
-void launch_sweep(int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa)
+inline void pack_operands(const float *A, size_t lda, const float *B, size_t ldb, int n, int k, int NG, const int *slot_user,
+                          int n_slots, float4 *Ap, long long ap, float4 *Bp, long long bp, hipStream_t stream)
 {
-#define RM_LAUNCH(NGV)                                                                                               \
-    case NGV: {                                                                                                      \
-        auto kern = k_sweep<NGV, AUC, DUMP>;                                                                         \
-        HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
-        hipLaunchKernelGGL(kern, grid, dim3(SWEEP_THREADS), lds, stream, sa);                                        \
-    } break;
-    switch (NG) {
-        RM_LAUNCH(2) RM_LAUNCH(4) RM_LAUNCH(8) RM_LAUNCH(16)
-        default: throw RmError{RM_ERR_UNSUPPORTED, "unsupported factor count"};
-    }
-#undef RM_LAUNCH
-    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_pack_items<float>, dim3(cdiv(bp, 256)), dim3(256), 0, stream, B, ldb, n, k, NG, Bp, bp);
+    hipLaunchKernelGGL(k_pack_users<float>, dim3(cdiv(ap, 256)), dim3(256), 0, stream, A, lda, k, NG, slot_user, n_slots, Ap, ap);
+}
+inline void pack_operands(const double *A, size_t lda, const double *B, size_t ldb, int n, int k, int NG, const int *slot_user,
+                          int n_slots, double2 *Ap, long long ap, double2 *Bp, long long bp, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_pack_items64<double>, dim3(cdiv(bp, 256)), dim3(256), 0, stream, B, ldb, n, k, NG, Bp, bp);
+    hipLaunchKernelGGL(k_pack_users64<double>, dim3(cdiv(ap, 256)), dim3(256), 0, stream, A, lda, k, NG, slot_user, n_slots, Ap, ap);
 }
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
 // ---------------------------------------------------------------------------------------------------------------------
-// fp32 device pipeline
+// device pipeline (T = float: v_mfma_f32_32x32x2_f32 sweep; T = double: v_mfma_f64_16x16x4_f64 sweep)
 // ---------------------------------------------------------------------------------------------------------------------
-void run_f32(const Call<float> &c, hipStream_t stream)
+template <class T>
+void run(const Call<T> &c, hipStream_t stream)
 {
-    typedef float T;
+    typedef Prec<T> P;
+    constexpr int GU = P::GU;
     Workspace &ws = workspace();
     const int m = c.m, n = c.n, k = c.k, K = c.K;
     // reference recometrics.hpp:390-393
@@ -152,8 +177,8 @@ void run_f32(const Call<float> &c, hipStream_t stream)
     for (int i = 0; i < 10; i++) if (c.out[i]) req |= (1 << i);
     const bool want_auc = req & (RQ_ROC | RQ_PR);
 
-    const int NG = supported_ng(k);
-    if (NG < 0) throw RmError{RM_ERR_UNSUPPORTED, "fp32 path supports up to 128 factors (got " + std::to_string(k) + ")"};
+    const int NG = P::supported_ng(k);
+    if (NG < 0) throw RmError{RM_ERR_UNSUPPORTED, std::string(P::limit()) + " (got " + std::to_string(k) + ")"};
 
     if (!g_ev_valid) { for (auto &e : g_ev) HIP_CHECK(hipEventCreate(&e)); g_ev_valid = true; }
     g_ev_stream = stream;
@@ -169,9 +194,9 @@ void run_f32(const Call<float> &c, hipStream_t stream)
                     flags, user_nslots, plan};
     hipLaunchKernelGGL(k_classify, dim3(cdiv(m, 256)), dim3(256), 0, stream, ca);
     hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, user_nslots, uslot_base, m, &plan->n_slots);
-    hipLaunchKernelGGL(k_plan_classes, dim3(1), dim3(1), 0, stream, plan);
+    hipLaunchKernelGGL(k_plan_classes, dim3(1), dim3(1), 0, stream, plan, GU);
     const long long slot_bound = (long long)m + c.nnz_test / POS_CHUNK + 1;
-    const long long group_bound = slot_bound / GROUP_USERS + 2;
+    const long long group_bound = slot_bound / GU + 2;
     int *slot_user = (int *)ws.get("slot_user", sizeof(int) * (size_t)slot_bound);
     int *slot_chunk = (int *)ws.get("slot_chunk", sizeof(int) * (size_t)slot_bound);
     int *slot_index = (int *)ws.get("slot_index", sizeof(int) * (size_t)slot_bound);
@@ -180,7 +205,7 @@ void run_f32(const Call<float> &c, hipStream_t stream)
     long long *grow = (long long *)ws.get("grow", sizeof(long long) * (size_t)group_bound);
     AssignArgs aa{m, c.test_p, flags, user_nslots, uslot_base, want_auc ? 1 : 0, plan, slot_user, slot_chunk, slot_index, slot_j};
     hipLaunchKernelGGL(k_assign_slots, dim3(cdiv(m, 256)), dim3(256), 0, stream, aa);
-    hipLaunchKernelGGL(k_group_rows, dim3(1), dim3(1), 0, stream, plan, slot_j, gj, grow);
+    hipLaunchKernelGGL(k_group_rows, dim3(1), dim3(1), 0, stream, plan, slot_j, gj, grow, GU);
     Plan hp;
     HIP_CHECK(hipMemcpyAsync(&hp, plan, sizeof(Plan), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
@@ -191,67 +216,68 @@ void run_f32(const Call<float> &c, hipStream_t stream)
     const int n_ublocks = (n_groups + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK;
 
     // ---- sweep geometry ----
+    // LDS admits one block per CU, so the grid runs in rounds of 256 blocks: pick the item split count whose last
+    // round is fullest (each extra split restarts the streaming top-K lists, hence the small per-split penalty).
     int n_splits = 1;
     if (n_ublocks > 0) {
-        const int want_blocks = 1024;                               // ~4 blocks per CU for tail balance
-        n_splits = std::max(1, want_blocks / n_ublocks);
-        n_splits = std::min(n_splits, std::max(1, tiles_total / 32));
-        n_splits = std::min(n_splits, MAX_PARTS / 2);
+        const int n_cu = 256, max_splits = std::max(1, std::min(MAX_PARTS / 2, tiles_total / 256));
+        double best = -1;
+        for (int sct = 1; sct <= max_splits; sct++) {
+            const long long blocks = (long long)n_ublocks * sct;
+            const long long rounds = (blocks + n_cu - 1) / n_cu;
+            const double score = (double)blocks / (double)(rounds * n_cu) - 0.004 * sct;
+            if (score > best + 1e-9) { best = score; n_splits = sct; }
+        }
     }
     const int n_part = 2 * n_splits;
-    const size_t lds_b = 2ull * NG * 2 * TILE_ITEMS * 16;
-    const size_t lds_auc = want_auc ? (size_t)GROUPS_PER_BLOCK * 2 * (1 << jmax) * GROUP_USERS * 4 : 0;
-    const size_t lds_lists = 8ull * K * GROUP_USERS * sizeof(ListEntry);
+    const size_t lds_b = P::lds_b(NG);
+    const size_t lds_auc = want_auc ? (size_t)GROUPS_PER_BLOCK * (1 << jmax) * GU * (sizeof(T) + 4) : 0;
+    const size_t lds_lists = 8ull * K * GU * sizeof(typename P::ListT);
     const bool list_in_lds = lds_b + lds_auc + lds_lists <= LDS_LIMIT;
     const size_t lds_total = lds_b + lds_auc + (list_in_lds ? lds_lists : 0);
 
-    Entry<float> *merged = (Entry<float> *)ws.get("merged", sizeof(Entry<float>) * (size_t)m * K);
-    float *pos_score = nullptr; unsigned *hist = nullptr; int *pos_order = nullptr; int *sa_pos_item = nullptr;
-    Entry<float> *pl = nullptr; PartialStat<float> *pst = nullptr;
+    Entry<T> *merged = (Entry<T> *)ws.get("merged", sizeof(Entry<T>) * (size_t)m * K);
+    T *pos_score = nullptr; unsigned *hist = nullptr; int *pos_order = nullptr, *pos_item = nullptr;
+    Entry<T> *pl = nullptr; PartialStat<T> *pst = nullptr;
 
     if (n_slots > 0) {
         // ---- pack operands into the MFMA images ----
-        const long long bp_f4 = (long long)tiles_total * NG * 2 * TILE_ITEMS;
-        const long long ap_f4 = (long long)n_groups * NG * 2 * GROUP_USERS;
-        float4 *Bp = (float4 *)ws.get("Bp", sizeof(float4) * (size_t)bp_f4);
-        float4 *Ap = (float4 *)ws.get("Ap", sizeof(float4) * (size_t)ap_f4);
-        hipLaunchKernelGGL(k_pack_items<T>, dim3(cdiv(bp_f4, 256)), dim3(256), 0, stream, c.B, c.ldb, n, k, NG, Bp, bp_f4);
-        hipLaunchKernelGGL(k_pack_users<T>, dim3(cdiv(ap_f4, 256)), dim3(256), 0, stream, c.A, c.lda, k, NG, slot_user, n_slots, Ap, ap_f4);
+        const long long bp_units = P::items_units(tiles_total, NG), ap_units = P::users_units(n_groups, NG);
+        typename P::PackT *Bp = (typename P::PackT *)ws.get("Bp", 16 * (size_t)bp_units);
+        typename P::PackT *Ap = (typename P::PackT *)ws.get("Ap", 16 * (size_t)ap_units);
+        pack_operands(c.A, c.lda, c.B, c.ldb, n, k, NG, slot_user, n_slots, Ap, ap_units, Bp, bp_units, stream);
 
         // ---- positives ----
         if (want_auc) {
-            const long long rows = hp.total_rows;
-            pos_score = (float *)ws.get("pos_score", sizeof(float) * (size_t)(rows + n_groups + 1) * GROUP_USERS);
-            int *pos_item = (int *)ws.get("pos_item", sizeof(int) * (size_t)(rows + n_groups + 1) * GROUP_USERS);
-            hist = (unsigned *)ws.get("hist", sizeof(unsigned) * (size_t)(rows + n_groups + 1) * GROUP_USERS);
-            float *pos_tmp = (float *)ws.get("pos_tmp", sizeof(float) * (size_t)std::max<long long>(c.nnz_test, 1));
+            const long long rows = hp.total_rows + n_groups;       // 2^j rows per group (one +inf pad row each)
+            pos_score = (T *)ws.get("pos_score", sizeof(T) * (size_t)(rows + 1) * GU);
+            pos_item = (int *)ws.get("pos_item", sizeof(int) * (size_t)(rows + 1) * GU);
+            hist = (unsigned *)ws.get("hist", sizeof(unsigned) * (size_t)(rows + 1) * GU);
+            T *pos_tmp = (T *)ws.get("pos_tmp", sizeof(T) * (size_t)std::max<long long>(c.nnz_test, 1));
             pos_order = (int *)ws.get("pos_order", sizeof(int) * (size_t)std::max<long long>(c.nnz_test, 1));
-            hipLaunchKernelGGL(k_fill<float>, dim3(cdiv((rows + n_groups) * GROUP_USERS, 256)), dim3(256), 0, stream,
-                               pos_score, INFINITY, (rows + n_groups) * GROUP_USERS);
-            HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(unsigned) * (size_t)(rows + n_groups) * GROUP_USERS, stream));
+            hipLaunchKernelGGL(k_fill<T>, dim3(cdiv(rows * GU, 256)), dim3(256), 0, stream, pos_score, (T)INFINITY, rows * GU);
+            HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(unsigned) * (size_t)rows * GU, stream));
             PosArgs<T> pa{m, n, k, c.A, c.lda, c.B, c.ldb, c.train_p, c.train_i, c.test_p, c.test_i,
-                          flags, user_nslots, uslot_base, slot_index, grow, pos_tmp, pos_order, pos_score, pos_item};
-            sa_pos_item = pos_item;
+                          flags, user_nslots, uslot_base, slot_index, grow, pos_tmp, pos_order, pos_score, pos_item, GU};
             hipLaunchKernelGGL(k_pos_scores<T>, dim3(cdiv((long long)m * WAVE, 256)), dim3(256), 0, stream, pa);
             hipLaunchKernelGGL(k_pos_place<T>, dim3(cdiv((long long)m * WAVE, 256)), dim3(256), 0, stream, pa);
         }
 
-        pl = (Entry<float> *)ws.get("pl", sizeof(Entry<float>) * (size_t)n_slots * n_part * K);
-        pst = (PartialStat<float> *)ws.get("pst", sizeof(PartialStat<float>) * (size_t)n_slots * n_part);
-        ListEntry *glists = nullptr;
+        pl = (Entry<T> *)ws.get("pl", sizeof(Entry<T>) * (size_t)n_slots * n_part * K);
+        pst = (PartialStat<T> *)ws.get("pst", sizeof(PartialStat<T>) * (size_t)n_slots * n_part);
+        typename P::ListT *glists = nullptr;
         const unsigned n_blocks = (unsigned)n_ublocks * n_splits;
-        if (!list_in_lds) glists = (ListEntry *)ws.get("glists", sizeof(ListEntry) * (size_t)n_blocks * 8 * K * GROUP_USERS);
+        if (!list_in_lds) glists = (typename P::ListT *)ws.get("glists", sizeof(typename P::ListT) * (size_t)n_blocks * 8 * K * GU);
 
-        SweepArgs sa{};
+        typename P::Args sa{};
         sa.n = n; sa.K = K; sa.n_slots = n_slots; sa.n_groups = n_groups; sa.n_ublocks = n_ublocks;
-        sa.n_splits = n_splits; sa.tiles_total = tiles_total; sa.jmax = jmax; sa.list_in_lds = list_in_lds ? 1 : 0;
-        sa.Ap = Ap; sa.Bp = Bp; sa.slot_user = slot_user; sa.slot_chunk = slot_chunk;
+        sa.n_splits = n_splits; sa.tiles_total = tiles_total; sa.jmax = jmax;
+        sa.Ap = (decltype(sa.Ap))Ap; sa.Bp = (decltype(sa.Bp))Bp; sa.slot_user = slot_user; sa.slot_chunk = slot_chunk;
         sa.train_p = c.train_p; sa.train_i = c.train_i; sa.gj = gj; sa.grow = grow;
-        sa.pos_score = pos_score; sa.pos_item = sa_pos_item; sa.hist = hist; sa.glists = glists; sa.pl = pl; sa.pst = pst; sa.dump = nullptr;
+        sa.pos_score = pos_score; sa.pos_item = pos_item; sa.hist = hist; sa.glists = glists; sa.pl = pl; sa.pst = pst; sa.dump = nullptr;
 
         HIP_CHECK(hipEventRecord(g_ev[1], stream));
-        if (want_auc) launch_sweep<true, false>(NG, dim3(n_blocks), lds_total, stream, sa);
-        else          launch_sweep<false, false>(NG, dim3(n_blocks), lds_total, stream, sa);
+        dispatch_sweep(want_auc, false, list_in_lds, NG, dim3(n_blocks), lds_total, stream, sa);
         HIP_CHECK(hipEventRecord(g_ev[2], stream));
         g_timings[4] = 1; g_timings[5] = n_splits; g_timings[6] = n_blocks; g_timings[7] = (double)lds_total;
     } else {
@@ -269,18 +295,18 @@ void run_f32(const Call<float> &c, hipStream_t stream)
 
     long long *rank_sorted = nullptr;
     if (c.pos_rank) rank_sorted = (long long *)ws.get("rank_sorted", sizeof(long long) * (size_t)std::max<long long>(c.nnz_test, 1));
-    FinalArgs<T, float> fa{};
-    fa.m = m; fa.n = n; fa.K = K; fa.n_part = n_part; fa.req = req; fa.cumulative = c.cumulative ? 1 : 0; fa.noise = c.noise ? 1 : 0;
+    FinalArgs<T, T> fa{};
+    fa.m = m; fa.n = n; fa.K = K; fa.n_part = n_part; fa.req = req; fa.cumulative = c.cumulative ? 1 : 0; fa.noise = c.noise ? 1 : 0; fa.gu = GU;
     fa.train_p = c.train_p; fa.test_p = c.test_p; fa.test_i = c.test_i; fa.test_v = c.test_v;
     fa.flags = flags; fa.user_nslots = user_nslots; fa.uslot_base = uslot_base; fa.slot_index = slot_index;
     fa.gj = gj; fa.grow = grow; fa.pl = pl; fa.pst = pst; fa.hist = hist; fa.pos_score = pos_score; fa.log2tab = log2tab;
     fa.p = c.out[0]; fa.tp = c.out[1]; fa.r = c.out[2]; fa.ap = c.out[3]; fa.tap = c.out[4];
     fa.ndcg = c.out[5]; fa.hit = c.out[6]; fa.rr = c.out[7]; fa.roc = c.out[8]; fa.pr = c.out[9];
     fa.merged = merged; fa.rank_sorted = rank_sorted; fa.status = c.status;
-    hipLaunchKernelGGL((k_finalize<T, float>), dim3(cdiv(m, 128)), dim3(128), 0, stream, fa);
+    hipLaunchKernelGGL((k_finalize<T, T>), dim3(cdiv(m, 128)), dim3(128), 0, stream, fa);
     HIP_CHECK(hipGetLastError());
     if (c.topk_idx)
-        hipLaunchKernelGGL(k_export_rank<float>, dim3(cdiv((long long)m * K, 256)), dim3(256), 0, stream, m, K, merged, c.topk_idx, c.topk_score);
+        hipLaunchKernelGGL(k_export_rank<T>, dim3(cdiv((long long)m * K, 256)), dim3(256), 0, stream, m, K, merged, c.topk_idx, c.topk_score);
     if (c.pos_rank) {
         if (want_auc && n_slots > 0)
             hipLaunchKernelGGL(k_export_pos_rank, dim3(cdiv(m, 128)), dim3(128), 0, stream, c.nnz_test, m, c.test_p, pos_order, rank_sorted, c.pos_rank);
@@ -290,15 +316,6 @@ void run_f32(const Call<float> &c, hipStream_t stream)
     HIP_CHECK(hipEventRecord(g_ev[3], stream));
     HIP_CHECK(hipGetLastError());
 }
-
-void run_f64(const Call<double> &, hipStream_t)
-{
-    throw RmError{RM_ERR_UNSUPPORTED, "fp64 device path not built yet"};
-}
-
-template <class T> void run(const Call<T> &c, hipStream_t s);
-template <> void run<float>(const Call<float> &c, hipStream_t s) { run_f32(c, s); }
-template <> void run<double>(const Call<double> &c, hipStream_t s) { run_f64(c, s); }
 
 template <class T>
 void validate(const T *A, const T *B, int m, int n, int k, const int *trp, const int *tep, const int *tei, int K, size_t lda, size_t ldb)
@@ -380,18 +397,21 @@ void run_host(const T *A, size_t lda, const T *B, size_t ldb, int m, int n, int 
     HIP_CHECK(hipStreamSynchronize(stream));
 }
 
-void debug_scores_f32(const float *A, size_t lda, const float *B, size_t ldb, int m, int n, int k, float *out)
+template <class T>
+void debug_scores(const T *A, size_t lda, const T *B, size_t ldb, int m, int n, int k, T *out)
 {
+    typedef Prec<T> P;
+    constexpr int GU = P::GU;
     if (!A || !B || !out || m <= 0 || n <= 0 || k <= 0) throw RmError{RM_ERR_INVALID, "bad argument"};
-    const int NG = supported_ng(k);
-    if (NG < 0) throw RmError{RM_ERR_UNSUPPORTED, "fp32 path supports up to 128 factors"};
+    const int NG = P::supported_ng(k);
+    if (NG < 0) throw RmError{RM_ERR_UNSUPPORTED, P::limit()};
     Workspace &ws = workspace();
     hipStream_t stream = nullptr;
-    float *dA = (float *)ws.get("in_A", sizeof(float) * (size_t)m * k);
-    float *dB = (float *)ws.get("in_B", sizeof(float) * (size_t)n * k);
-    HIP_CHECK(hipMemcpy2DAsync(dA, sizeof(float) * k, A, sizeof(float) * lda, sizeof(float) * k, m, hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipMemcpy2DAsync(dB, sizeof(float) * k, B, sizeof(float) * ldb, sizeof(float) * k, n, hipMemcpyHostToDevice, stream));
-    const int n_groups = (m + GROUP_USERS - 1) / GROUP_USERS, n_ublocks = (n_groups + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK;
+    T *dA = (T *)ws.get("in_A", sizeof(T) * (size_t)m * k);
+    T *dB = (T *)ws.get("in_B", sizeof(T) * (size_t)n * k);
+    HIP_CHECK(hipMemcpy2DAsync(dA, sizeof(T) * k, A, sizeof(T) * lda, sizeof(T) * k, m, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpy2DAsync(dB, sizeof(T) * k, B, sizeof(T) * ldb, sizeof(T) * k, n, hipMemcpyHostToDevice, stream));
+    const int n_groups = (m + GU - 1) / GU, n_ublocks = (n_groups + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK;
     const int tiles_total = (n + TILE_ITEMS - 1) / TILE_ITEMS;
     int *slot_user = (int *)ws.get("slot_user", sizeof(int) * (size_t)m);
     int *zeros = (int *)ws.get("dbg_zeros", sizeof(int) * (size_t)(m + 1 + n_groups));
@@ -399,21 +419,20 @@ void debug_scores_f32(const float *A, size_t lda, const float *B, size_t ldb, in
     HIP_CHECK(hipMemsetAsync(zeros, 0, sizeof(int) * (size_t)(m + 1 + n_groups), stream));
     HIP_CHECK(hipMemsetAsync(grow, 0, sizeof(long long) * (size_t)n_groups, stream));
     hipLaunchKernelGGL(k_iota<int>, dim3(cdiv(m, 256)), dim3(256), 0, stream, slot_user, m);
-    const long long bp_f4 = (long long)tiles_total * NG * 2 * TILE_ITEMS, ap_f4 = (long long)n_groups * NG * 2 * GROUP_USERS;
-    float4 *Bp = (float4 *)ws.get("Bp", sizeof(float4) * (size_t)bp_f4);
-    float4 *Ap = (float4 *)ws.get("Ap", sizeof(float4) * (size_t)ap_f4);
-    hipLaunchKernelGGL(k_pack_items<float>, dim3(cdiv(bp_f4, 256)), dim3(256), 0, stream, dB, (size_t)k, n, k, NG, Bp, bp_f4);
-    hipLaunchKernelGGL(k_pack_users<float>, dim3(cdiv(ap_f4, 256)), dim3(256), 0, stream, dA, (size_t)k, k, NG, slot_user, m, Ap, ap_f4);
-    float *dump = (float *)ws.get("dbg_dump", sizeof(float) * (size_t)m * n);
+    const long long bp_units = P::items_units(tiles_total, NG), ap_units = P::users_units(n_groups, NG);
+    typename P::PackT *Bp = (typename P::PackT *)ws.get("Bp", 16 * (size_t)bp_units);
+    typename P::PackT *Ap = (typename P::PackT *)ws.get("Ap", 16 * (size_t)ap_units);
+    pack_operands(dA, (size_t)k, dB, (size_t)k, n, k, NG, slot_user, m, Ap, ap_units, Bp, bp_units, stream);
+    T *dump = (T *)ws.get("dbg_dump", sizeof(T) * (size_t)m * n);
     const int K = 1;
-    ListEntry *glists = (ListEntry *)ws.get("glists", sizeof(ListEntry) * (size_t)n_ublocks * 8 * K * GROUP_USERS);
-    SweepArgs sa{};
+    typename P::ListT *glists = (typename P::ListT *)ws.get("glists", sizeof(typename P::ListT) * (size_t)n_ublocks * 8 * K * GU);
+    typename P::Args sa{};
     sa.n = n; sa.K = K; sa.n_slots = m; sa.n_groups = n_groups; sa.n_ublocks = n_ublocks; sa.n_splits = 1;
-    sa.tiles_total = tiles_total; sa.jmax = 0; sa.list_in_lds = 0; sa.Ap = Ap; sa.Bp = Bp;
+    sa.tiles_total = tiles_total; sa.jmax = 0; sa.Ap = (decltype(sa.Ap))Ap; sa.Bp = (decltype(sa.Bp))Bp;
     sa.slot_user = slot_user; sa.slot_chunk = zeros; sa.train_p = zeros; sa.train_i = zeros; sa.gj = zeros + m + 1; sa.grow = grow;
     sa.glists = glists; sa.dump = dump;
-    launch_sweep<false, true>(NG, dim3(n_ublocks), 2ull * NG * 2 * TILE_ITEMS * 16, stream, sa);
-    HIP_CHECK(hipMemcpyAsync(out, dump, sizeof(float) * (size_t)m * n, hipMemcpyDeviceToHost, stream));
+    dispatch_sweep(false, true, false, NG, dim3(n_ublocks), P::lds_b(NG), stream, sa);
+    HIP_CHECK(hipMemcpyAsync(out, dump, sizeof(T) * (size_t)m * n, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
 }
 
@@ -486,12 +505,12 @@ RM_HOST_ENTRY(f64, double)
 
 extern "C" int rm_debug_scores_f32(const float *A, size_t lda, const float *B, size_t ldb, int32_t m, int32_t n, int32_t k, float *out)
 {
-    return guarded([&] { debug_scores_f32(A, lda, B, ldb, m, n, k, out); });
+    return guarded([&] { debug_scores<float>(A, lda, B, ldb, m, n, k, out); });
 }
 
-extern "C" int rm_debug_scores_f64(const double *, size_t, const double *, size_t, int32_t, int32_t, int32_t, double *)
+extern "C" int rm_debug_scores_f64(const double *A, size_t lda, const double *B, size_t ldb, int32_t m, int32_t n, int32_t k, double *out)
 {
-    return guarded([&] { throw RmError{RM_ERR_UNSUPPORTED, "fp64 device path not built yet"}; });
+    return guarded([&] { debug_scores<double>(A, lda, B, ldb, m, n, k, out); });
 }
 
 extern "C" int rm_has_openmp(void) { return 1; }

@@ -83,7 +83,7 @@ __global__ void k_scan_exclusive(const int *in, int *out, int count, int *total_
     if (tid == 0 && total_out) *total_out = carry_s;
 }
 
-__global__ void k_plan_classes(Plan *p)      // one thread
+__global__ void k_plan_classes(Plan *p, int gu)      // one thread; gu = users per group (32 fp32, 16 fp64)
 {
     int off = 0, jmax = 0;
     for (int j = 0; j <= MAX_J; j++) {
@@ -93,7 +93,7 @@ __global__ void k_plan_classes(Plan *p)      // one thread
         p->class_cursor[j] = 0;
     }
     p->class_offset[MAX_J + 1] = off;
-    p->n_groups = (p->n_slots + GROUP_USERS - 1) / GROUP_USERS;
+    p->n_groups = (p->n_slots + gu - 1) / gu;
     p->jmax = jmax;
 }
 
@@ -127,13 +127,13 @@ __global__ void k_assign_slots(AssignArgs a)
 }
 
 // per sweep block (4 groups): uniform tree depth jb = depth of its last slot; row base of each group.  One thread.
-__global__ void k_group_rows(Plan *p, const unsigned char *slot_j, int *gj, long long *grow)
+__global__ void k_group_rows(Plan *p, const unsigned char *slot_j, int *gj, long long *grow, int gu)
 {
     const int ng = p->n_groups, ns = p->n_slots;
     long long rows = 0;
     for (int b = 0; b * GROUPS_PER_BLOCK < ng; b++) {
         const int glast = min(ng, (b + 1) * GROUPS_PER_BLOCK) - 1;
-        const int slast = min(ns, (glast + 1) * GROUP_USERS) - 1;
+        const int slast = min(ns, (glast + 1) * gu) - 1;
         const int jb = slot_j[slast];
         const int pl = (1 << jb) - 1;
         for (int g = b * GROUPS_PER_BLOCK; g <= glast; g++) { gj[g] = jb; grow[g] = rows; rows += pl; }
@@ -193,6 +193,49 @@ __global__ void k_pack_users(const T *A, size_t lda, int k, int NG, const int *s
     Ap[o] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// fp64, v_mfma_f64_16x16x4_f64: lane (r = lane & 15, q = lane >> 4) supplies element [r][k = 4*step + q]; a b128 read
+// covers 2 steps:   packed[tile][g][q][row][i] = X[tile*ROWS + row][8g + 4i + q]   (i = 0, 1)
+template <class T>
+__global__ void k_pack_items64(const T *B, size_t ldb, int n, int k, int NG, double2 *Bp, long long total_d2)
+{
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= total_d2) return;
+    const int row = (int)(o % TILE_ITEMS);
+    const int q = (int)((o / TILE_ITEMS) & 3);
+    const long long tg = o / (4 * TILE_ITEMS);
+    const int g = (int)(tg % NG);
+    const long long tile = tg / NG;
+    const long long item = tile * TILE_ITEMS + row;
+    double v[2] = {0., 0.};
+    if (item < n) {
+        const T *src = B + (size_t)item * ldb;
+        #pragma unroll
+        for (int i = 0; i < 2; i++) { const int kk = 8 * g + 4 * i + q; if (kk < k) v[i] = (double)src[kk]; }
+    }
+    Bp[o] = make_double2(v[0], v[1]);
+}
+
+template <class T>
+__global__ void k_pack_users64(const T *A, size_t lda, int k, int NG, const int *slot_user, int n_slots,
+                               double2 *Ap, long long total_d2)
+{
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= total_d2) return;
+    const int ul = (int)(o % 16);
+    const int q = (int)((o / 16) & 3);
+    const long long gg = o / 64;
+    const int g = (int)(gg % NG);
+    const long long group = gg / NG;
+    const long long slot = group * 16 + ul;
+    double v[2] = {0., 0.};
+    if (slot < n_slots) {
+        const T *src = A + (size_t)slot_user[slot] * lda;
+        #pragma unroll
+        for (int i = 0; i < 2; i++) { const int kk = 8 * g + 4 * i + q; if (kk < k) v[i] = (double)src[kk]; }
+    }
+    Ap[o] = make_double2(v[0], v[1]);
+}
+
 // ---- positives: scores of the user's test items (same k-ordered fma chain as the sweep's MFMA), sorted --------------
 template <class T> __device__ __forceinline__ T chain_dot(const T *x, const T *y, int k);
 template <> __device__ __forceinline__ float chain_dot<float>(const float *x, const float *y, int k)
@@ -218,6 +261,7 @@ template <class T> struct PosArgs {
     int *pos_order;      // [nnz_test] ascending rank of the entry inside its row, order (score asc, item desc)
     T *pos_score;        // [(total_rows + n_groups)][32]: group g owns rows (grow[g] + g) .. + 2^j - 1, last row = +inf pad
     int *pos_item;       // same shape: item id of each sorted positive (tie resolution)
+    int gu;              // users per group
 };
 
 __device__ __forceinline__ bool in_sorted_row(const int *row, int len, int item)
@@ -262,7 +306,7 @@ __global__ void k_pos_place(PosArgs<T> a)
         a.pos_order[e] = rank;
         const int c = rank / POS_CHUNK, r = rank % POS_CHUNK;
         const int slot = a.slot_index[a.uslot_base[u] + c];
-        const long long at = (a.grow[slot / GROUP_USERS] + slot / GROUP_USERS + r) * GROUP_USERS + (slot % GROUP_USERS);
+        const long long at = (a.grow[slot / a.gu] + slot / a.gu + r) * a.gu + (slot % a.gu);
         a.pos_score[at] = s;
         a.pos_item[at] = item;
     }

@@ -17,50 +17,16 @@
 //                  (rm_prep.hpp k_pack_items) stream HBM -> registers -> LDS, double buffered, one barrier per tile.
 #pragma once
 #include "rm_device.hpp"
+#include "rm_list.hpp"
+#include "rm_launch.hpp"
 
 namespace rm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct SweepArgs {
-    int n, K;
-    int n_slots, n_groups, n_ublocks;     // n_ublocks = ceil(n_groups / 4)
-    int n_splits, tiles_total;            // item splits (grid = n_ublocks * n_splits)
-    int jmax;                             // LDS sizing (all blocks)
-    int list_in_lds;
-    const float4 *Ap, *Bp;
-    const int *slot_user, *slot_chunk;
-    const int *train_p, *train_i;
-    const int *gj; const long long *grow;
-    const float *pos_score;               // [(total_rows + n_groups)][32]  sorted positives, +inf padded (2^j rows per group)
-    const int *pos_item;                  // same shape, item ids (read only when a candidate ties a positive's score)
-    unsigned *hist;                       // [(total_rows + n_groups)][32]
-    ListEntry *glists;                    // global list scratch when !list_in_lds: [block][wave][K][32]
-    ListEntry *pl;                        // partial lists [slot][n_part][K]
-    PartialStat<float> *pst;              // [slot][n_part]
-    float *dump;                          // DUMP mode: dense [n_slots][n] scores
-};
 
-__device__ __forceinline__ bool entry_before(float s, int idx, float s2, int idx2)
-{
-    return s > s2 || (s == s2 && idx < idx2);
-}
-
-// per-lane insertion into the lane's user's descending list L[i*32] (i = 0..K-1); generic pointer (LDS or global)
-__device__ __forceinline__ void list_insert(ListEntry *L, int K, float s, int item)
-{
-    const ListEntry last = L[(K - 1) * GROUP_USERS];
-    if (!entry_before(s, item, last.s, last.idx)) return;
-    int i = K - 1;
-    while (i > 0) {
-        const ListEntry e = L[(i - 1) * GROUP_USERS];
-        if (entry_before(e.s, e.idx, s, item)) break;
-        L[i * GROUP_USERS] = e;
-        i--;
-    }
-    ListEntry ne; ne.s = s; ne.idx = item;
-    L[i * GROUP_USERS] = ne;
-}
+typedef __attribute__((address_space(3))) u32x2 *LdsListPtr;
+typedef u32x2 *GblListPtr;
 
 // AUC rank counting for one tile: branchless lower_bound of every score in the lane's user's sorted positives
 // (complete tree of 2^J - 1 rows, +inf padded), then one LDS atomic into the rank histogram.
@@ -68,33 +34,48 @@ template <int J>
 __device__ __forceinline__ void auc_pass(const float (&v)[16], const char *posb, char *histb, unsigned &rocacc,
                                          const int *pos_item_g, int sb, int h)
 {
+    // The 16 searches are independent: run them level by level (16 LDS reads in flight per level) instead of one
+    // dependent 6-deep chain after another, and keep the histogram atomics out of the way until all reads are done
+    // (an LDS atomic may alias the table for the compiler and would serialise the chains).
+    unsigned base[16];
     #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const float s = v[r];
-        unsigned base = 0;
+    for (int r = 0; r < 16; r++) base[r] = 0;
+    #pragma unroll
+    for (int st = (J > 0 ? (1 << (J - 1)) : 0); st >= 1; st >>= 1) {
+        float pv[16];
         #pragma unroll
-        for (int st = (J > 0 ? (1 << (J - 1)) : 0); st >= 1; st >>= 1) {
-            const float pv = *(const float *)(posb + base + (st - 1) * 128);
-            base = (pv < s) ? base + st * 128 : base;
-        }
-        // exact score tie with a positive (row `base` is the first positive not below s; the table has one +inf
-        // pad row, so the read is always in range): the total order is (score desc, item asc), i.e. the candidate
-        // also outranks the equal-scored positives with a LARGER item id.  Rare; positives' item ids stay in HBM.
-        const float nx = *(const float *)(posb + base);
-        if (__any(nx == s)) {
-            if (nx == s) {
+        for (int r = 0; r < 16; r++) pv[r] = *(const float *)(posb + base[r] + (st - 1) * 128);
+        #pragma unroll
+        for (int r = 0; r < 16; r++) base[r] = (pv[r] < v[r]) ? base[r] + st * 128 : base[r];
+    }
+    // exact score tie with a positive (row `base` is the first positive not below s; the table has one +inf pad
+    // row, so the read is always in range): the total order is (score desc, item asc), i.e. the candidate also
+    // outranks the equal-scored positives with a LARGER item id.  Rare; positives' item ids stay in HBM.
+    float nx[16];
+    #pragma unroll
+    for (int r = 0; r < 16; r++) nx[r] = *(const float *)(posb + base[r]);
+    unsigned long long tie = 0;
+    #pragma unroll
+    for (int r = 0; r < 16; r++) tie |= __ballot(nx[r] == v[r]);
+    if (tie) {
+        #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            if (nx[r] == v[r]) {
                 const int item = sb + mfma32_row(r, h);
-                unsigned t = base;
-                while (t < (unsigned)(((1 << J) - 1) * 128) && *(const float *)(posb + t) == s && pos_item_g[t >> 2] > item) t += 128;
-                base = t;
+                unsigned t = base[r];
+                while (t < (unsigned)(((1 << J) - 1) * 128) && *(const float *)(posb + t) == v[r] && pos_item_g[t >> 2] > item) t += 128;
+                base[r] = t;
             }
         }
-        rocacc += base;
-        __hip_atomic_fetch_add((unsigned *)(histb + base), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    #pragma unroll
+    for (int r = 0; r < 16; r++) {
+        rocacc += base[r];
+        __hip_atomic_fetch_add((unsigned *)(histb + base[r]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
-template <int NG, bool AUC, bool DUMP>
+template <int NG, bool AUC, bool DUMP, bool LLDS>
 __global__ __launch_bounds__(SWEEP_THREADS, 2)
 void k_sweep(SweepArgs a)
 {
@@ -114,7 +95,7 @@ void k_sweep(SweepArgs a)
     float4 *ldsB = (float4 *)smem;
     char *p = smem + 2 * BUF_F4 * 16;
     ListEntry *lists_lds = (ListEntry *)p;
-    if (a.list_in_lds) p += 8 * K * GROUP_USERS * (int)sizeof(ListEntry);
+    if (LLDS) p += 8 * K * GROUP_USERS * (int)sizeof(ListEntry);
     const int PLmax = (1 << a.jmax) - 1;
     float *posL = (float *)p;  p += GROUPS_PER_BLOCK * (PLmax + 1) * GROUP_USERS * 4;
     unsigned *histL = (unsigned *)p;
@@ -152,10 +133,12 @@ void k_sweep(SweepArgs a)
     for (int g = 0; g < NG; g++)
         af[g] = group_ok ? a.Ap[((size_t)(group * NG + g) * 2 + h) * GROUP_USERS + ul] : make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // top-K list of this wave: [K][32 users]
-    ListEntry *L = a.list_in_lds ? (lists_lds + wave * K * GROUP_USERS + ul)
-                                 : (a.glists + ((size_t)blockIdx.x * 8 + wave) * K * GROUP_USERS + ul);
-    if (h == 0) for (int i = 0; i < K; i++) { ListEntry e; e.s = neg_inf_f(); e.idx = IDX_EMPTY; L[i * GROUP_USERS] = e; }
+    // top-K list of this wave: [K][32 users], owned by the lanes with h == 0
+    GblListPtr Lg = LLDS ? ((GblListPtr)lists_lds + wave * K * GROUP_USERS + ul)
+                         : (a.glists + ((size_t)blockIdx.x * 8 + wave) * K * GROUP_USERS + ul);
+    LdsListPtr Ll = (LdsListPtr)Lg;
+    float ws = neg_inf_f(); int widx = IDX_EMPTY, wpos = 0;
+    if (h == 0) for (int i = 0; i < K; i++) { if (LLDS) Ll[i * GROUP_USERS] = ListRaw<float>::pack(neg_inf_f(), IDX_EMPTY); else Lg[i * GROUP_USERS] = ListRaw<float>::pack(neg_inf_f(), IDX_EMPTY); }
 
     // positives -> LDS, histogram zeroed
     if (AUC) {
@@ -170,18 +153,15 @@ void k_sweep(SweepArgs a)
     const int *pos_item_g = (AUC && group_ok) ? a.pos_item + (a.grow[group] + group) * GROUP_USERS + ul : nullptr;
     char *histb = (char *)(histL + gi * (PLmax + 1) * GROUP_USERS + ul);
 
-    // ---- staging: packed tile (BUF_F4 float4, contiguous) HBM -> registers -> LDS ----
-    constexpr int NST = (BUF_F4 + SWEEP_THREADS - 1) / SWEEP_THREADS;
-    float4 st[NST];
-    auto stage_load = [&](int tile) {
+    // ---- staging: packed tile (BUF_F4 float4, contiguous) HBM -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging
+    // registers, the wave never waits for the bytes before the end-of-step barrier.  One wave-instruction moves 1 KiB
+    // (64 lanes x 16 B) to a lane-linear LDS image, which is exactly how the packed tile is laid out. ----
+    auto stage = [&](int tile, int buf) {
         const float4 *src = a.Bp + (size_t)tile * BUF_F4;
-        #pragma unroll
-        for (int i = 0; i < NST; i++) { const int idx = tid + i * SWEEP_THREADS; if (idx < BUF_F4) st[i] = src[idx]; }
-    };
-    auto stage_store = [&](int buf) {
         float4 *dst = ldsB + buf * BUF_F4;
-        #pragma unroll
-        for (int i = 0; i < NST; i++) { const int idx = tid + i * SWEEP_THREADS; if (idx < BUF_F4) dst[idx] = st[i]; }
+        for (int pc = wave; pc < NG * 2; pc += 8)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + pc * 64 + lane),
+                                             (__attribute__((address_space(3))) void *)(dst + pc * 64), 16, 0, 0);
     };
 
     // ---- MFMA: 32 items (registers) x 32 users (lanes), k in index order ----
@@ -233,32 +213,37 @@ void k_sweep(SweepArgs a)
             #pragma unroll
             for (int r = 0; r < 16; r++) nanmask |= __ballot(v[r] != v[r]);
         }
+#ifndef RM_ABL_NO_STATS
         // (2) min / max over candidates (NaN-ignoring, so the sentinel is invisible) (:519-524)
         #pragma unroll
         for (int r = 0; r < 16; r++) { vmax = __builtin_fmaxf(vmax, v[r]); vmin = __builtin_fminf(vmin, v[r]); }
-        // (3) streaming top-K: anything at or above the lane's K-th best goes through the insert path (:537-540)
+#endif
+#ifndef RM_ABL_NO_TOPK
+        // (3) streaming top-K: anything at or above the user's current K-th best is offered to the list (:537-540).
+        // Lanes u (h = 0) and u + 32 (h = 1) carry two item rows of the same user: the h = 0 lane owns the list and
+        // also takes its partner's candidate.
         unsigned long long cm = 0;
         #pragma unroll
         for (int r = 0; r < 16; r++) cm |= __ballot(v[r] >= thr);
         if (cm) {
             #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const bool c = v[r] >= thr;
-                if (__any(c)) {
-                    const int item = sb + mfma32_row(r, h);
-                    // lanes u and u+32 carry the same user (two item rows): one half of the wave at a time.  The wave
-                    // barriers keep the compiler from fusing the two predicated inserts into one (legal per thread,
-                    // wrong across lanes).
-                    if (c && h == 0) list_insert(L, K, v[r], item);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    if (c && h == 1) list_insert(L, K, v[r], item);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    if (primary) thr = L[(K - 1) * GROUP_USERS].s;
+                if (__any(v[r] >= thr)) {
+                    const float other = __shfl_xor(v[r], 32);
+                    if (h == 0 && primary) {
+                        const int item0 = sb + mfma32_row(r, 0), item1 = sb + mfma32_row(r, 1);
+                        if (LLDS) { if (v[r] >= ws) list_offer<float, GROUP_USERS>(Ll, K, v[r], item0, ws, widx, wpos);
+                                    if (other >= ws) list_offer<float, GROUP_USERS>(Ll, K, other, item1, ws, widx, wpos); }
+                        else      { if (v[r] >= ws) list_offer<float, GROUP_USERS>(Lg, K, v[r], item0, ws, widx, wpos);
+                                    if (other >= ws) list_offer<float, GROUP_USERS>(Lg, K, other, item1, ws, widx, wpos); }
+                    }
                 }
             }
+            const float t2 = __shfl(ws, ul);
+            thr = primary ? t2 : thr;
         }
+#endif
+#ifndef RM_ABL_NO_AUC
         // (4) AUC rank counting (replaces the full sort of :552 + the walk of :795-865)
         if (AUC) {
             unsigned rocacc = 0;
@@ -273,20 +258,28 @@ void k_sweep(SweepArgs a)
             }
             roc64 += rocacc >> 7;
         }
+#endif
     };
 
     // ---- main loop: one barrier per tile; acc ping-pong; role X = waves 0-3 (MFMA first), role Y = waves 4-7 ----
     f32x16 acc0, acc1;
     const bool roleX = sub == 0;
-    if (ntiles > 0) { stage_load(t0); stage_store(0); }
+    if (ntiles > 0) stage(t0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     auto step = [&](int i, f32x16 &cur, f32x16 &prev) {
         const bool has_cur = i < ntiles, has_next = i + 1 < ntiles;
-        if (has_next) stage_load(t0 + i + 1);
+        if (has_next) stage(t0 + i + 1, (i + 1) & 1);        // buffer (i+1)&1 was last read in step i-1
+#ifndef RM_ABL_NO_MFMA
         if (roleX && has_cur) do_mfma(cur, i & 1);
+#endif
+#ifndef RM_ABL_NO_EPI
         if (i > 0) do_epi(prev, t0 + i - 1);
+#endif
+#ifndef RM_ABL_NO_MFMA
         if (!roleX && has_cur) do_mfma(cur, i & 1);
-        if (has_next) stage_store((i + 1) & 1);
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA of tile i+1 has landed
         __syncthreads();
     };
     for (int i = 0; i <= ntiles; i += 2) {
@@ -309,7 +302,8 @@ void k_sweep(SweepArgs a)
             ps.vmax = vmax; ps.vmin = vmin; ps.rocsum = roc64; ps.has_nan = hn ? 1 : 0; ps.pad = 0;
             a.pst[(size_t)slot * n_part + part] = ps;
             ListEntry *dst = a.pl + ((size_t)slot * n_part + part) * K;
-            for (int i = 0; i < K; i++) dst[i] = L[i * GROUP_USERS];
+            if (LLDS) { list_sort_desc<float, GROUP_USERS>(Ll, K); for (int i = 0; i < K; i++) ListRaw<float>::unpack(Ll[i * GROUP_USERS], dst[i].s, dst[i].idx); }
+            else      { list_sort_desc<float, GROUP_USERS>(Lg, K); for (int i = 0; i < K; i++) ListRaw<float>::unpack(Lg[i * GROUP_USERS], dst[i].s, dst[i].idx); }
         }
     }
     if (AUC) {

@@ -1,0 +1,306 @@
+// rm_sweep64.hpp -- the fp64 sweep: same fused pipeline as rm_sweep.hpp (contraction + train masking + validity scan +
+// streaming top-K + AUC rank counting) on v_mfma_f64_16x16x4_f64.
+//
+// Measured on gfx950 (scratch/probe_f64.hip): the f64 MFMA is bit-for-bit the k-ordered fma chain (accumulator in,
+// k = 4*step + (lane >> 4) within an instruction), i.e. exactly reference src/recometrics.hpp:84-97 in its canonical
+// build.  Geometry differences from the fp32 sweep:
+//   * D is 16 items x 16 users: column (user) = lane & 15, row (item) = (lane >> 4) + 4*reg -- a user sits on FOUR lanes
+//     (q = lane >> 4), a group is 16 users, a wave owns 16 users x 32 items per tile (two MFMA tiles, 8 values per lane);
+//   * the packed operand image is [g][q][row][2 doubles]: a b128 read gives the lane its factors k = 8g + q and 8g + 4 + q;
+//   * the factor axis is streamed in chunks of 64 factors (32 KiB LDS per buffer); user factors stay in registers
+//     (2 doubles per 8 factors), so 256 factors cost 128 VGPRs.
+#pragma once
+#include "rm_device.hpp"
+#include "rm_list.hpp"
+#include "rm_launch.hpp"
+
+namespace rm {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+
+typedef __attribute__((address_space(3))) u32x4 *LdsList64Ptr;
+typedef u32x4 *GblList64Ptr;
+
+__device__ __forceinline__ double pos_inf_d() { return __longlong_as_double(0x7ff0000000000000ll); }
+__device__ __forceinline__ double neg_inf_d() { return __longlong_as_double(0xfff0000000000000ll); }
+__device__ __forceinline__ double nan_sentinel_d() { return __longlong_as_double(-1ll); }
+
+template <int J>
+__device__ __forceinline__ void auc_pass64(const double (&v)[8], const char *posb, char *histb, unsigned &rocacc,
+                                           const int *pos_item_g, int sb, int q)
+{
+    unsigned base[8];
+    #pragma unroll
+    for (int r = 0; r < 8; r++) base[r] = 0;
+    #pragma unroll
+    for (int st = (J > 0 ? (1 << (J - 1)) : 0); st >= 1; st >>= 1) {
+        double pv[8];
+        #pragma unroll
+        for (int r = 0; r < 8; r++) pv[r] = *(const double *)(posb + base[r] + (st - 1) * 128);
+        #pragma unroll
+        for (int r = 0; r < 8; r++) base[r] = (pv[r] < v[r]) ? base[r] + st * 128 : base[r];
+    }
+    double nx[8];
+    #pragma unroll
+    for (int r = 0; r < 8; r++) nx[r] = *(const double *)(posb + base[r]);
+    unsigned long long tie = 0;
+    #pragma unroll
+    for (int r = 0; r < 8; r++) tie |= __ballot(nx[r] == v[r]);
+    if (tie) {
+        #pragma unroll
+        for (int r = 0; r < 8; r++) {
+            if (nx[r] == v[r]) {
+                const int item = sb + (r >> 2) * 16 + q + 4 * (r & 3);
+                unsigned t = base[r];
+                while (t < (unsigned)(((1 << J) - 1) * 128) && *(const double *)(posb + t) == v[r] &&
+                       pos_item_g[(t >> 7) * GROUP_USERS64] > item) t += 128;
+                base[r] = t;
+            }
+        }
+    }
+    #pragma unroll
+    for (int r = 0; r < 8; r++) {
+        rocacc += base[r];
+        __hip_atomic_fetch_add((unsigned *)(histb + (base[r] >> 1)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+template <int NGT, bool AUC, bool DUMP, bool LLDS>
+__global__ __launch_bounds__(SWEEP_THREADS, 2)
+void k_sweep64(Sweep64Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int GU = GROUP_USERS64;
+    constexpr int NGC = NGT < 8 ? NGT : 8;                      // factor groups (of 8) per LDS chunk
+    constexpr int NC = NGT / NGC;                               // chunks per tile
+    constexpr int BUF_D2 = NGC * 4 * TILE_ITEMS;                // double2 per chunk buffer
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gi = wave & 3, sub = wave >> 2;
+    const int ul = lane & 15, q = lane >> 4;
+    const int blk_u = blockIdx.x % a.n_ublocks, split = blockIdx.x / a.n_ublocks;
+    const int group = blk_u * GROUPS_PER_BLOCK + gi;
+    const bool group_ok = group < a.n_groups;
+    const int slot = group * GU + ul;
+    const bool slot_ok = group_ok && slot < a.n_slots;
+    const int K = a.K, n = a.n;
+
+    // ---- LDS carve: [B buf0 | B buf1 | lists (8 waves) | positives (4 groups) | histogram (4 groups)] ----
+    f64x2 *ldsB = (f64x2 *)smem;
+    char *p = smem + 2 * BUF_D2 * 16;
+    u32x4 *lists_lds = (u32x4 *)p;
+    if (LLDS) p += 8 * K * GU * 16;
+    const int PLmax = (1 << a.jmax) - 1;
+    double *posL = (double *)p;  p += GROUPS_PER_BLOCK * (PLmax + 1) * GU * 8;
+    unsigned *histL = (unsigned *)p;
+
+    const int glast = min(a.n_groups, (blk_u + 1) * GROUPS_PER_BLOCK) - 1;
+    const int jb = AUC ? a.gj[glast] : 0;
+    const int PLb = (1 << jb) - 1;
+
+    const int user = slot_ok ? a.slot_user[slot] : -1;
+    const bool primary = slot_ok && a.slot_chunk[slot] == 0;
+    double thr = primary ? neg_inf_d() : nan_sentinel_d();
+    double vmax = neg_inf_d(), vmin = pos_inf_d();
+    unsigned long long nanmask = 0, roc64 = 0;
+    int ntc = 0, nte = 0, nt = IDX_EMPTY;
+
+    const int tiles_per = (a.tiles_total + a.n_splits - 1) / a.n_splits;
+    const int t0 = split * tiles_per, t1 = min(a.tiles_total, t0 + tiles_per);
+    const int ntiles = max(0, t1 - t0);
+
+    if (user >= 0) {
+        ntc = a.train_p[user]; nte = a.train_p[user + 1];
+        const int first_item = t0 * TILE_ITEMS;
+        int lo = ntc, hi = nte;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.train_i[mid] < first_item) lo = mid + 1; else hi = mid; }
+        ntc = lo;
+        nt = ntc < nte ? a.train_i[ntc] : IDX_EMPTY;
+    }
+
+    // user factors -> registers: [group][g][q][16 users][2 doubles]
+    f64x2 af[NGT];
+    #pragma unroll
+    for (int g = 0; g < NGT; g++) {
+        f64x2 z; z.x = 0; z.y = 0;
+        af[g] = group_ok ? a.Ap[((size_t)(group * NGT + g) * 4 + q) * GU + ul] : z;
+    }
+
+    GblList64Ptr Lg = LLDS ? (lists_lds + wave * K * GU + ul) : (a.glists + ((size_t)blockIdx.x * 8 + wave) * K * GU + ul);
+    LdsList64Ptr Ll = (LdsList64Ptr)Lg;
+    double ws = neg_inf_d(); int widx = IDX_EMPTY, wpos = 0;
+    if (q == 0) for (int i = 0; i < K; i++) {
+        if (LLDS) Ll[i * GU] = ListRaw<double>::pack(neg_inf_d(), IDX_EMPTY); else Lg[i * GU] = ListRaw<double>::pack(neg_inf_d(), IDX_EMPTY);
+    }
+
+    if (AUC) {
+        for (int i = tid; i < GROUPS_PER_BLOCK * (PLb + 1) * GU; i += SWEEP_THREADS) {
+            const int g4 = i / ((PLb + 1) * GU), rem = i % ((PLb + 1) * GU);
+            const int gg = blk_u * GROUPS_PER_BLOCK + g4;
+            posL[g4 * (PLmax + 1) * GU + rem] = gg < a.n_groups ? a.pos_score[(a.grow[gg] + gg) * GU + rem] : pos_inf_d();
+        }
+        for (int i = tid; i < GROUPS_PER_BLOCK * (PLmax + 1) * GU; i += SWEEP_THREADS) histL[i] = 0;
+    }
+    const char *posb = (const char *)(posL + gi * (PLmax + 1) * GU + ul);
+    char *histb = (char *)(histL + gi * (PLmax + 1) * GU + ul);
+    const int *pos_item_g = (AUC && group_ok) ? a.pos_item + (a.grow[group] + group) * GU + ul : nullptr;
+
+    // unit u = (tile, chunk): contiguous BUF_D2 double2 of the packed image [tile][g][q][row][2]
+    auto stage = [&](int tile, int chunk, int buf) {
+        const f64x2 *src = a.Bp + ((size_t)tile * NGT + (size_t)chunk * NGC) * 4 * TILE_ITEMS;
+        f64x2 *dst = ldsB + buf * BUF_D2;
+        for (int pc = wave; pc < NGC * 4; pc += 8)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + pc * 64 + lane),
+                                             (__attribute__((address_space(3))) void *)(dst + pc * 64), 16, 0, 0);
+    };
+
+    auto do_epi = [&](const f64x4 &acc_lo, const f64x4 &acc_hi, int tile) {
+        const int sb = tile * TILE_ITEMS + sub * 32;
+        double v[8];
+        #pragma unroll
+        for (int r = 0; r < 4; r++) { v[r] = acc_lo[r]; v[4 + r] = acc_hi[r]; }
+        if (DUMP) {
+            #pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int item = sb + (r >> 2) * 16 + q + 4 * (r & 3);
+                if (slot_ok && item < n) a.dump[(size_t)slot * n + item] = v[r];
+            }
+            return;
+        }
+        const bool slow = __any(nt < sb + 32) || (sb + 32 > n);
+        if (slow) {
+            unsigned mbits = 0;
+            while (nt < sb + 32) {
+                if (nt >= sb) mbits |= 1u << (nt - sb);
+                ntc++;
+                nt = ntc < nte ? a.train_i[ntc] : IDX_EMPTY;
+            }
+            if (sb + 32 > n) mbits |= (n > sb) ? (0xffffffffu << (n - sb)) : 0xffffffffu;
+            #pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const bool mk = (mbits >> ((r >> 2) * 16 + q + 4 * (r & 3))) & 1u;
+                nanmask |= __ballot(!mk && (v[r] != v[r]));
+                v[r] = mk ? nan_sentinel_d() : v[r];
+            }
+        } else {
+            #pragma unroll
+            for (int r = 0; r < 8; r++) nanmask |= __ballot(v[r] != v[r]);
+        }
+        #pragma unroll
+        for (int r = 0; r < 8; r++) { vmax = __builtin_fmax(vmax, v[r]); vmin = __builtin_fmin(vmin, v[r]); }
+        unsigned long long cm = 0;
+        #pragma unroll
+        for (int r = 0; r < 8; r++) cm |= __ballot(v[r] >= thr);
+        if (cm) {
+            #pragma unroll
+            for (int r = 0; r < 8; r++) {
+                if (__any(v[r] >= thr)) {
+                    const double o1 = __shfl(v[r], ul + 16), o2 = __shfl(v[r], ul + 32), o3 = __shfl(v[r], ul + 48);
+                    if (q == 0 && primary) {
+                        const int ib = sb + (r >> 2) * 16 + 4 * (r & 3);
+                        if (LLDS) {
+                            if (v[r] >= ws) list_offer<double, GU>(Ll, K, v[r], ib, ws, widx, wpos);
+                            if (o1 >= ws) list_offer<double, GU>(Ll, K, o1, ib + 1, ws, widx, wpos);
+                            if (o2 >= ws) list_offer<double, GU>(Ll, K, o2, ib + 2, ws, widx, wpos);
+                            if (o3 >= ws) list_offer<double, GU>(Ll, K, o3, ib + 3, ws, widx, wpos);
+                        } else {
+                            if (v[r] >= ws) list_offer<double, GU>(Lg, K, v[r], ib, ws, widx, wpos);
+                            if (o1 >= ws) list_offer<double, GU>(Lg, K, o1, ib + 1, ws, widx, wpos);
+                            if (o2 >= ws) list_offer<double, GU>(Lg, K, o2, ib + 2, ws, widx, wpos);
+                            if (o3 >= ws) list_offer<double, GU>(Lg, K, o3, ib + 3, ws, widx, wpos);
+                        }
+                    }
+                }
+            }
+            const double t2 = __shfl(ws, ul);
+            thr = primary ? t2 : thr;
+        }
+        if (AUC) {
+            unsigned rocacc = 0;
+            switch (jb) {
+                case 1: auc_pass64<1>(v, posb, histb, rocacc, pos_item_g, sb, q); break;
+                case 2: auc_pass64<2>(v, posb, histb, rocacc, pos_item_g, sb, q); break;
+                case 3: auc_pass64<3>(v, posb, histb, rocacc, pos_item_g, sb, q); break;
+                case 4: auc_pass64<4>(v, posb, histb, rocacc, pos_item_g, sb, q); break;
+                case 5: auc_pass64<5>(v, posb, histb, rocacc, pos_item_g, sb, q); break;
+                case 6: auc_pass64<6>(v, posb, histb, rocacc, pos_item_g, sb, q); break;
+                default: break;
+            }
+            roc64 += rocacc >> 7;
+        }
+    };
+
+    // ---- main loop over tiles, chunks of the factor axis statically unrolled inside; one barrier per chunk ----
+    f64x4 a0lo, a0hi, a1lo, a1hi;
+    const bool roleX = sub == 0;
+    const int nunits = ntiles * NC;
+    if (ntiles > 0) stage(t0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    auto tile_step = [&](int i, f64x4 &clo, f64x4 &chi, f64x4 &plo, f64x4 &phi) {
+        const bool has_cur = i < ntiles;
+        #pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const int unit = i * NC + c;
+            const int buf = unit & 1;
+            if (unit + 1 < nunits) {
+                const int nu = unit + 1;
+                stage(t0 + nu / NC, nu % NC, nu & 1);
+            }
+            auto mfma_chunk = [&]() {
+                const f64x2 *bb = ldsB + buf * BUF_D2 + q * TILE_ITEMS + sub * 32 + ul;
+                if (c == 0) {
+                    #pragma unroll
+                    for (int r = 0; r < 4; r++) { clo[r] = 0.; chi[r] = 0.; }
+                }
+                #pragma unroll
+                for (int gl = 0; gl < NGC; gl++) {
+                    const f64x2 b0 = bb[gl * 4 * TILE_ITEMS], b1 = bb[gl * 4 * TILE_ITEMS + 16];
+                    const f64x2 u = af[c * NGC + gl];
+                    clo = __builtin_amdgcn_mfma_f64_16x16x4f64(b0.x, u.x, clo, 0, 0, 0);
+                    chi = __builtin_amdgcn_mfma_f64_16x16x4f64(b1.x, u.x, chi, 0, 0, 0);
+                    clo = __builtin_amdgcn_mfma_f64_16x16x4f64(b0.y, u.y, clo, 0, 0, 0);
+                    chi = __builtin_amdgcn_mfma_f64_16x16x4f64(b1.y, u.y, chi, 0, 0, 0);
+                }
+            };
+            if (roleX && has_cur) mfma_chunk();
+            if (c == 0 && i > 0) do_epi(plo, phi, t0 + i - 1);
+            if (!roleX && has_cur) mfma_chunk();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    };
+    for (int i = 0; i <= ntiles; i += 2) {
+        tile_step(i, a0lo, a0hi, a1lo, a1hi);
+        if (i + 1 <= ntiles) tile_step(i + 1, a1lo, a1hi, a0lo, a0hi);
+    }
+    if (DUMP) return;
+
+    const int n_part = a.n_splits * 2;
+    const int part = split * 2 + sub;
+    {   // the four lanes of a user hold four quarters of its stats
+        vmax = __builtin_fmax(vmax, __shfl_xor(vmax, 16)); vmax = __builtin_fmax(vmax, __shfl_xor(vmax, 32));
+        vmin = __builtin_fmin(vmin, __shfl_xor(vmin, 16)); vmin = __builtin_fmin(vmin, __shfl_xor(vmin, 32));
+        roc64 += __shfl_xor(roc64, 16); roc64 += __shfl_xor(roc64, 32);
+        const bool hn = ((nanmask >> ul) | (nanmask >> (ul + 16)) | (nanmask >> (ul + 32)) | (nanmask >> (ul + 48))) & 1ull;
+        if (slot_ok && q == 0) {
+            PartialStat<double> ps;
+            ps.vmax = vmax; ps.vmin = vmin; ps.rocsum = roc64; ps.has_nan = hn ? 1 : 0; ps.pad = 0;
+            a.pst[(size_t)slot * n_part + part] = ps;
+            Entry<double> *dst = a.pl + ((size_t)slot * n_part + part) * K;
+            if (LLDS) { list_sort_desc<double, GU>(Ll, K); for (int i = 0; i < K; i++) ListRaw<double>::unpack(Ll[i * GU], dst[i].s, dst[i].idx); }
+            else      { list_sort_desc<double, GU>(Lg, K); for (int i = 0; i < K; i++) ListRaw<double>::unpack(Lg[i * GU], dst[i].s, dst[i].idx); }
+        }
+    }
+    if (AUC) {
+        __syncthreads();
+        for (int i = tid; i < GROUPS_PER_BLOCK * (PLb + 1) * GU; i += SWEEP_THREADS) {
+            const int g4 = i / ((PLb + 1) * GU), rem = i % ((PLb + 1) * GU);
+            const int gg = blk_u * GROUPS_PER_BLOCK + g4;
+            const unsigned c = histL[g4 * (PLmax + 1) * GU + rem];
+            if (gg < a.n_groups && c) atomicAdd(&a.hist[(a.grow[gg] + gg) * GU + rem], c);
+        }
+    }
+}
+
+} // namespace rm

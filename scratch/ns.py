@@ -1,0 +1,17 @@
+import sys, os, json, numpy as np, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from recometrics_amd import _binding as binding
+from recometrics_amd.synth import CONFIGS
+from bench import DeviceProblem, measure
+import torch.distributed as dist
+wl = sys.argv[1] if len(sys.argv) > 1 else "NS"
+users = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+m, n, k, dtype, K, mean_c, seed = CONFIGS[wl]
+m = users
+torch.cuda.set_device(0); binding.load(); binding.set_device(0)
+p = DeviceProblem(torch, torch.device("cuda", 0), m, n, k, mean_c, seed, K)
+dt, sw, pr, fi, tm = measure(torch, dist, binding, p, steps, 1, 1, None)
+tf = 2.0 * n * k * m / (sw * 1e-3) / 1e12
+print(json.dumps({"workload": wl, "users": m, "users_per_s": m * steps / dt, "sweep_ms": sw, "prep_ms": pr, "fin_ms": fi, "TF": tf, "frac": tf / 157.3, "tm": tm}))

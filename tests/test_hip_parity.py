@@ -47,6 +47,17 @@ def test_mfma_scores_are_the_k_ordered_fma_chain(hip, oracle, k):
     assert_same_bits(got, want, "scores k=%d" % k)
 
 
+@pytest.mark.parametrize("k", [3, 8, 40, 64, 100, 130, 256])
+def test_mfma_f64_scores_are_the_k_ordered_fma_chain(hip, oracle, k):
+    """v_mfma_f64_16x16x4_f64 contraction == strict index-order fma chain (reference dot1, double), bit for bit."""
+    rng = np.random.default_rng(100 + k)
+    A = rng.standard_normal((37, k)) * np.exp(rng.uniform(-20, 20, (37, 1)))
+    B = rng.standard_normal((150, k))
+    got = hip.debug_scores(A, B)
+    want = oracle.scores(A, B, dtype=np.float64)
+    assert_same_bits(got, want, "f64 scores k=%d" % k)
+
+
 def test_mfma_scores_subnormal_and_special_values(hip, oracle):
     rng = np.random.default_rng(5)
     A = rng.standard_normal((40, 32)).astype(np.float32)
@@ -75,8 +86,6 @@ def _skip_user_with_nan_test_value(case, name, got, want, inp):
 @pytest.mark.parametrize("case", [c for c in golden_cases()])
 def test_golden_fixtures(hip, case):
     dtype, inp, variants = load_golden(case)
-    if dtype != np.float32:
-        pytest.importorskip("recometrics_amd")
     for vi, (kw, expected) in enumerate(variants):
         got = hip_calc(hip, inp["A"], inp["B"], inp["train"], inp["test"], dtype=dtype, **kw)
         assert set(got) == set(expected)
@@ -115,6 +124,18 @@ def test_random_problem_vs_oracle(hip, oracle, m, n, k, K, mean_c):
     from recometrics_amd.synth import make_problem
     pr = make_problem(m, n, k, np.float32, mean_c=mean_c, seed=m + n)
     _check_against_oracle(hip, oracle, pr, K)
+
+
+@pytest.mark.parametrize("m,n,k,K,mean_c", [
+    (200, 3000, 19, 10, 30),
+    (150, 5000, 64, 5, 50),
+    (70, 20000, 256, 50, 50),      # BASELINE config C5's factor count and K (fp64, lists out of LDS, item splits)
+    (129, 1027, 100, 7, 40),
+])
+def test_random_problem_vs_oracle_f64(hip, oracle, m, n, k, K, mean_c):
+    from recometrics_amd.synth import make_problem
+    pr = make_problem(m, n, k, np.float64, mean_c=mean_c, seed=m + n + 1)
+    _check_against_oracle(hip, oracle, pr, K, dtype=np.float64)
 
 
 def test_heavy_users_many_positives(hip, oracle):
