@@ -49,7 +49,8 @@ struct Plan {                                     // produced on device, read ba
     int class_count[MAX_J + 1];
     int class_offset[MAX_J + 2];
     int class_cursor[MAX_J + 1];
-    int pad;
+    int nonfinite;                      // some factor of A or B is NaN / Inf
+    unsigned long long amax_a, amax_b;  // bit patterns of max|A|, max|B| as doubles (non-negative doubles order like u64)
 };
 
 __device__ __forceinline__ float nan_sentinel_f() { return __int_as_float(0xffffffff); }

@@ -15,6 +15,7 @@ struct SweepArgs {
     int n_splits, tiles_total;            // item splits (grid = n_ublocks * n_splits)
     int jmax;                             // LDS sizing (all blocks)
     int list_in_lds;
+    int check_nan;                        // 0 when the host proved all scores finite (skips the NaN scan)
     const float4 *Ap, *Bp;
     const int *slot_user, *slot_chunk;
     const int *train_p, *train_i;
@@ -33,6 +34,7 @@ struct Sweep64Args {
     int n_slots, n_groups, n_ublocks;
     int n_splits, tiles_total;
     int jmax;
+    int check_nan;
     const f64x2 *Ap, *Bp;
     const int *slot_user, *slot_chunk;
     const int *train_p, *train_i;

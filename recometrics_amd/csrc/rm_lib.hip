@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 #include <map>
 #include <mutex>
 #include <string>
@@ -206,12 +207,19 @@ void run(const Call<T> &c, hipStream_t stream)
     AssignArgs aa{m, c.test_p, flags, user_nslots, uslot_base, want_auc ? 1 : 0, plan, slot_user, slot_chunk, slot_index, slot_j};
     hipLaunchKernelGGL(k_assign_slots, dim3(cdiv(m, 256)), dim3(256), 0, stream, aa);
     hipLaunchKernelGGL(k_group_rows, dim3(1), dim3(1), 0, stream, plan, slot_j, gj, grow, GU);
+    hipLaunchKernelGGL(k_absmax<T>, dim3(512), dim3(256), 0, stream, c.A, c.lda, (long long)m, k, &plan->amax_a, &plan->nonfinite);
+    hipLaunchKernelGGL(k_absmax<T>, dim3(1024), dim3(256), 0, stream, c.B, c.ldb, (long long)n, k, &plan->amax_b, &plan->nonfinite);
     Plan hp;
     HIP_CHECK(hipMemcpyAsync(&hp, plan, sizeof(Plan), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
 
     const int n_slots = hp.n_slots, n_groups = hp.n_groups;
     const int jmax = want_auc ? hp.jmax : 0;
+    // |any partial sum| <= k * max|A| * max|B|: if that is comfortably finite in T, no score is NaN / Inf
+    double amax_a, amax_b;
+    std::memcpy(&amax_a, &hp.amax_a, 8); std::memcpy(&amax_b, &hp.amax_b, 8);
+    const double tmax = std::is_same<T, float>::value ? 3.0e38 : 1.0e308;
+    const bool check_nan = hp.nonfinite || !((double)k * amax_a * 1.001 < tmax / std::max(amax_b, 1e-300));
     const int tiles_total = (n + TILE_ITEMS - 1) / TILE_ITEMS;
     const int n_ublocks = (n_groups + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK;
 
@@ -271,7 +279,7 @@ void run(const Call<T> &c, hipStream_t stream)
 
         typename P::Args sa{};
         sa.n = n; sa.K = K; sa.n_slots = n_slots; sa.n_groups = n_groups; sa.n_ublocks = n_ublocks;
-        sa.n_splits = n_splits; sa.tiles_total = tiles_total; sa.jmax = jmax;
+        sa.n_splits = n_splits; sa.tiles_total = tiles_total; sa.jmax = jmax; sa.check_nan = check_nan ? 1 : 0;
         sa.Ap = (decltype(sa.Ap))Ap; sa.Bp = (decltype(sa.Bp))Bp; sa.slot_user = slot_user; sa.slot_chunk = slot_chunk;
         sa.train_p = c.train_p; sa.train_i = c.train_i; sa.gj = gj; sa.grow = grow;
         sa.pos_score = pos_score; sa.pos_item = pos_item; sa.hist = hist; sa.glists = glists; sa.pl = pl; sa.pst = pst; sa.dump = nullptr;
@@ -428,7 +436,7 @@ void debug_scores(const T *A, size_t lda, const T *B, size_t ldb, int m, int n, 
     typename P::ListT *glists = (typename P::ListT *)ws.get("glists", sizeof(typename P::ListT) * (size_t)n_ublocks * 8 * K * GU);
     typename P::Args sa{};
     sa.n = n; sa.K = K; sa.n_slots = m; sa.n_groups = n_groups; sa.n_ublocks = n_ublocks; sa.n_splits = 1;
-    sa.tiles_total = tiles_total; sa.jmax = 0; sa.Ap = (decltype(sa.Ap))Ap; sa.Bp = (decltype(sa.Bp))Bp;
+    sa.tiles_total = tiles_total; sa.jmax = 0; sa.check_nan = 1; sa.Ap = (decltype(sa.Ap))Ap; sa.Bp = (decltype(sa.Bp))Bp;
     sa.slot_user = slot_user; sa.slot_chunk = zeros; sa.train_p = zeros; sa.train_i = zeros; sa.gj = zeros + m + 1; sa.grow = grow;
     sa.glists = glists; sa.dump = dump;
     dispatch_sweep(false, true, false, NG, dim3(n_ublocks), P::lds_b(NG), stream, sa);

@@ -141,6 +141,28 @@ __global__ void k_group_rows(Plan *p, const unsigned char *slot_j, int *gj, long
     p->total_rows = rows;
 }
 
+// max |x| over a row-major matrix (rows x k, leading dimension ld) + a non-finite flag: lets the host prove that no
+// score can overflow, in which case the sweep skips its NaN scan.
+template <class T>
+__global__ void k_absmax(const T *X, size_t ld, long long rows, int k, unsigned long long *amax_bits, int *nonfinite)
+{
+    double mx = 0.; bool bad = false;
+    const long long total = rows * k;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const double x = (double)X[(size_t)(i / k) * ld + (i % k)];
+        const double ax = x < 0 ? -x : x;
+        bad |= !(ax <= 1.7976931348623157e308);          // NaN or Inf
+        mx = ax > mx ? ax : mx;
+    }
+    #pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+    const bool anybad = __any(bad);
+    if ((threadIdx.x & 63) == 0) {
+        if (!anybad) atomicMax(amax_bits, (unsigned long long)__double_as_longlong(mx));
+        else atomicOr(nonfinite, 1);
+    }
+}
+
 template <class T> __global__ void k_fill(T *p, T v, long long count)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -193,7 +193,8 @@ void k_sweep(SweepArgs a)
             }
             return;
         }
-        // (1) train-item / out-of-range masking (reference :491-497) + NaN detection (:517-518)
+        // (1) train-item / out-of-range masking (reference :491-497) + NaN detection (:517-518).  The NaN scan is
+        // skipped when the host proved that no partial sum can overflow or be non-finite (k * max|A| * max|B| bound).
         const bool slow = __any(nt < sb + 32) || (sb + 32 > n);
         if (slow) {
             unsigned mbits = 0;
@@ -206,25 +207,31 @@ void k_sweep(SweepArgs a)
             #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const bool mk = (mbits >> mfma32_row(r, h)) & 1u;
-                nanmask |= __ballot(!mk && (v[r] != v[r]));
+                if (a.check_nan) nanmask |= __ballot(!mk && (v[r] != v[r]));
                 v[r] = mk ? nan_sentinel_f() : v[r];
             }
-        } else {
+        } else if (a.check_nan) {
             #pragma unroll
             for (int r = 0; r < 16; r++) nanmask |= __ballot(v[r] != v[r]);
         }
 #ifndef RM_ABL_NO_STATS
-        // (2) min / max over candidates (NaN-ignoring, so the sentinel is invisible) (:519-524)
-        #pragma unroll
-        for (int r = 0; r < 16; r++) { vmax = __builtin_fmaxf(vmax, v[r]); vmin = __builtin_fminf(vmin, v[r]); }
+        // (2) min / max over candidates (NaN-ignoring, so the sentinel is invisible) (:519-524): v_max3 / v_min3 trees
+        const float tmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), __builtin_fmaxf(v[2], v[3])),
+                                                           __builtin_fmaxf(__builtin_fmaxf(v[4], v[5]), __builtin_fmaxf(v[6], v[7]))),
+                                           __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(v[8], v[9]), __builtin_fmaxf(v[10], v[11])),
+                                                           __builtin_fmaxf(__builtin_fmaxf(v[12], v[13]), __builtin_fmaxf(v[14], v[15]))));
+        const float tmin = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fminf(v[0], v[1]), __builtin_fminf(v[2], v[3])),
+                                                           __builtin_fminf(__builtin_fminf(v[4], v[5]), __builtin_fminf(v[6], v[7]))),
+                                           __builtin_fminf(__builtin_fminf(__builtin_fminf(v[8], v[9]), __builtin_fminf(v[10], v[11])),
+                                                           __builtin_fminf(__builtin_fminf(v[12], v[13]), __builtin_fminf(v[14], v[15]))));
+        vmax = __builtin_fmaxf(vmax, tmax); vmin = __builtin_fminf(vmin, tmin);
 #endif
 #ifndef RM_ABL_NO_TOPK
         // (3) streaming top-K: anything at or above the user's current K-th best is offered to the list (:537-540).
+        // One compare per tile on the lane's tile maximum; the per-score work happens only in the rare hit path.
         // Lanes u (h = 0) and u + 32 (h = 1) carry two item rows of the same user: the h = 0 lane owns the list and
         // also takes its partner's candidate.
-        unsigned long long cm = 0;
-        #pragma unroll
-        for (int r = 0; r < 16; r++) cm |= __ballot(v[r] >= thr);
+        const unsigned long long cm = __ballot(tmax >= thr);
         if (cm) {
             #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -261,30 +268,23 @@ void k_sweep(SweepArgs a)
 #endif
     };
 
-    // ---- main loop: one barrier per tile; acc ping-pong; role X = waves 0-3 (MFMA first), role Y = waves 4-7 ----
-    f32x16 acc0, acc1;
-    const bool roleX = sub == 0;
+    // ---- main loop: one barrier per tile.  Measured on gfx950 (scratch/coexec2.hip): an f32-input MFMA chain and
+    // VALU/LDS work of the SIMD partner wave do NOT overlap (time = sum, the f32 MFMA runs on the vector ALUs), so the
+    // two waves of a SIMD run in phase: both chains back to back, then both epilogues sharing the VALU at full rate. ----
+    f32x16 acc;
     if (ntiles > 0) stage(t0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    auto step = [&](int i, f32x16 &cur, f32x16 &prev) {
-        const bool has_cur = i < ntiles, has_next = i + 1 < ntiles;
-        if (has_next) stage(t0 + i + 1, (i + 1) & 1);        // buffer (i+1)&1 was last read in step i-1
+    for (int i = 0; i < ntiles; i++) {
+        if (i + 1 < ntiles) stage(t0 + i + 1, (i + 1) & 1);       // buffer (i+1)&1 was last read in step i-1
 #ifndef RM_ABL_NO_MFMA
-        if (roleX && has_cur) do_mfma(cur, i & 1);
+        do_mfma(acc, i & 1);
 #endif
 #ifndef RM_ABL_NO_EPI
-        if (i > 0) do_epi(prev, t0 + i - 1);
+        do_epi(acc, t0 + i);
 #endif
-#ifndef RM_ABL_NO_MFMA
-        if (!roleX && has_cur) do_mfma(cur, i & 1);
-#endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA of tile i+1 has landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the DMA of tile i+1 has landed
         __syncthreads();
-    };
-    for (int i = 0; i <= ntiles; i += 2) {
-        step(i, acc0, acc1);
-        if (i + 1 <= ntiles) step(i + 1, acc1, acc0);
     }
     if (DUMP) return;
 

@@ -179,10 +179,10 @@ void k_sweep64(Sweep64Args a)
             #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const bool mk = (mbits >> ((r >> 2) * 16 + q + 4 * (r & 3))) & 1u;
-                nanmask |= __ballot(!mk && (v[r] != v[r]));
+                if (a.check_nan) nanmask |= __ballot(!mk && (v[r] != v[r]));
                 v[r] = mk ? nan_sentinel_d() : v[r];
             }
-        } else {
+        } else if (a.check_nan) {
             #pragma unroll
             for (int r = 0; r < 8; r++) nanmask |= __ballot(v[r] != v[r]);
         }
