@@ -57,6 +57,19 @@ __device__ __forceinline__ float nan_sentinel_f() { return __int_as_float(0xffff
 __device__ __forceinline__ float pos_inf_f() { return __int_as_float(0x7f800000); }
 __device__ __forceinline__ float neg_inf_f() { return __int_as_float(0xff800000); }
 
+// order-preserving integer keys: key(a) < key(b) <=> a < b for non-NaN floats; key(-inf) > 0, so 0 = "nothing yet"
+__device__ __forceinline__ unsigned ord_key(float x) { const unsigned b = __float_as_uint(x); return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u); }
+__device__ __forceinline__ float ord_unkey(unsigned k) { return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu)); }
+__device__ __forceinline__ unsigned long long ord_key(double x)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return b ^ ((b >> 63) ? 0xffffffffffffffffull : 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ord_unkey(unsigned long long k)
+{
+    return __longlong_as_double((long long)(k ^ ((k >> 63) ? 0x8000000000000000ull : 0xffffffffffffffffull)));
+}
+
 // row of accumulator register r in a 32x32 MFMA result for the lane half h (cdna_hip_programming.md section 3)
 __device__ __forceinline__ constexpr int mfma32_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

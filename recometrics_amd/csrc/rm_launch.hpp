@@ -23,6 +23,7 @@ struct SweepArgs {
     const float *pos_score;               // [(total_rows + n_groups)][32]  sorted positives, +inf padded (2^j rows per group)
     const int *pos_item;                  // same shape, item ids (read only when a candidate ties a positive's score)
     unsigned *hist;                       // [(total_rows + n_groups)][32]
+    unsigned *thr_shared;                 // [n_slots] order-preserving key of the best K-th-best any partial of the user has seen
     u32x2 *glists;                        // list scratch in HBM when the lists do not fit LDS: [block][wave][K][32]
     ListEntry *pl;                        // partial lists [slot][n_part][K]
     PartialStat<float> *pst;              // [slot][n_part]
@@ -42,6 +43,7 @@ struct Sweep64Args {
     const double *pos_score;              // [(total_rows + n_groups)][16]
     const int *pos_item;
     unsigned *hist;                       // [(total_rows + n_groups)][16]
+    unsigned long long *thr_shared;       // [n_slots] (64-bit keys)
     u32x4 *glists;                        // [block][wave][K][16]
     Entry<double> *pl;                    // [slot][n_part][K]
     PartialStat<double> *pst;             // [slot][n_part]

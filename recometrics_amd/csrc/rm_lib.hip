@@ -277,7 +277,11 @@ void run(const Call<T> &c, hipStream_t stream)
         const unsigned n_blocks = (unsigned)n_ublocks * n_splits;
         if (!list_in_lds) glists = (typename P::ListT *)ws.get("glists", sizeof(typename P::ListT) * (size_t)n_blocks * 8 * K * GU);
 
+        typedef typename std::remove_pointer<decltype(typename P::Args{}.thr_shared)>::type ThrT;
+        ThrT *thr_shared = (ThrT *)ws.get("thr_shared", sizeof(ThrT) * (size_t)n_slots);
+        HIP_CHECK(hipMemsetAsync(thr_shared, 0, sizeof(ThrT) * (size_t)n_slots, stream));
         typename P::Args sa{};
+        sa.thr_shared = thr_shared;
         sa.n = n; sa.K = K; sa.n_slots = n_slots; sa.n_groups = n_groups; sa.n_ublocks = n_ublocks;
         sa.n_splits = n_splits; sa.tiles_total = tiles_total; sa.jmax = jmax; sa.check_nan = check_nan ? 1 : 0;
         sa.Ap = (decltype(sa.Ap))Ap; sa.Bp = (decltype(sa.Bp))Bp; sa.slot_user = slot_user; sa.slot_chunk = slot_chunk;

@@ -110,7 +110,7 @@ void k_sweep(SweepArgs a)
     float thr = primary ? neg_inf_f() : nan_sentinel_f();        // NaN threshold: "v >= thr" never true
     float vmax = neg_inf_f(), vmin = pos_inf_f();
     unsigned long long nanmask = 0, roc64 = 0;
-    int ntc = 0, nte = 0, nt = IDX_EMPTY;
+    int ntc = 0, nte = 0, nt = IDX_EMPTY, nt2 = IDX_EMPTY;     // train cursor: next item and the one after (prefetched)
 
     // item range of this split
     const int tiles_per = (a.tiles_total + a.n_splits - 1) / a.n_splits;
@@ -125,6 +125,7 @@ void k_sweep(SweepArgs a)
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.train_i[mid] < first_item) lo = mid + 1; else hi = mid; }
         ntc = lo;
         nt = ntc < nte ? a.train_i[ntc] : IDX_EMPTY;
+        nt2 = ntc + 1 < nte ? a.train_i[ntc + 1] : IDX_EMPTY;
     }
 
     // user factors -> registers (packed: [group][g][h][32][4 floats])
@@ -180,7 +181,8 @@ void k_sweep(SweepArgs a)
     };
 
     // ---- epilogue of one 32-item x 32-user tile ----
-    auto do_epi = [&](const f32x16 &acc, int tile) {
+    unsigned thr_pub = 0;                                       // last key this lane published / observed
+    auto do_epi = [&](const f32x16 &acc, int tile, unsigned thr_seen) {
         const int sb = tile * TILE_ITEMS + sub * 32;            // first item of this wave's sub-tile
         float v[16];
         #pragma unroll
@@ -195,13 +197,18 @@ void k_sweep(SweepArgs a)
         }
         // (1) train-item / out-of-range masking (reference :491-497) + NaN detection (:517-518).  The NaN scan is
         // skipped when the host proved that no partial sum can overflow or be non-finite (k * max|A| * max|B| bound).
+#ifdef RM_ABL_NO_MASK
+        const bool slow = false;
+#else
         const bool slow = __any(nt < sb + 32) || (sb + 32 > n);
+#endif
         if (slow) {
             unsigned mbits = 0;
             while (nt < sb + 32) {
                 if (nt >= sb) mbits |= 1u << (nt - sb);
                 ntc++;
-                nt = ntc < nte ? a.train_i[ntc] : IDX_EMPTY;
+                nt = nt2;                                           // loaded when the previous item was consumed:
+                nt2 = ntc + 1 < nte ? a.train_i[ntc + 1] : IDX_EMPTY;   // the HBM latency never sits in front of the barrier
             }
             if (sb + 32 > n) mbits |= (n > sb) ? (0xffffffffu << (n - sb)) : 0xffffffffu;
             #pragma unroll
@@ -231,6 +238,9 @@ void k_sweep(SweepArgs a)
         // One compare per tile on the lane's tile maximum; the per-score work happens only in the rare hit path.
         // Lanes u (h = 0) and u + 32 (h = 1) carry two item rows of the same user: the h = 0 lane owns the list and
         // also takes its partner's candidate.
+        // every partial list of the user (other sub-tile wave, other item splits) publishes its K-th best; the largest
+        // of them is a valid lower bound of the final K-th best, so it filters for all of them
+        if (primary && thr_seen > thr_pub) { thr_pub = thr_seen; const float t = ord_unkey(thr_seen); thr = t > thr ? t : thr; }
         const unsigned long long cm = __ballot(tmax >= thr);
         if (cm) {
             #pragma unroll
@@ -247,7 +257,12 @@ void k_sweep(SweepArgs a)
                 }
             }
             const float t2 = __shfl(ws, ul);
-            thr = primary ? t2 : thr;
+            if (primary) {
+                thr = t2 > thr ? t2 : thr;
+                const unsigned kk = ord_key(t2);
+                if (h == 0 && kk > thr_pub) { atomicMax(a.thr_shared + slot, kk); }
+                thr_pub = kk > thr_pub ? kk : thr_pub;
+            }
         }
 #endif
 #ifndef RM_ABL_NO_AUC
@@ -277,11 +292,12 @@ void k_sweep(SweepArgs a)
     __syncthreads();
     for (int i = 0; i < ntiles; i++) {
         if (i + 1 < ntiles) stage(t0 + i + 1, (i + 1) & 1);       // buffer (i+1)&1 was last read in step i-1
+        const unsigned thr_seen = (primary && !DUMP) ? __hip_atomic_load(a.thr_shared + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #ifndef RM_ABL_NO_MFMA
         do_mfma(acc, i & 1);
 #endif
 #ifndef RM_ABL_NO_EPI
-        do_epi(acc, t0 + i);
+        do_epi(acc, t0 + i, thr_seen);
 #endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the DMA of tile i+1 has landed
         __syncthreads();

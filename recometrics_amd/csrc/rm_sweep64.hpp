@@ -103,7 +103,7 @@ void k_sweep64(Sweep64Args a)
     double thr = primary ? neg_inf_d() : nan_sentinel_d();
     double vmax = neg_inf_d(), vmin = pos_inf_d();
     unsigned long long nanmask = 0, roc64 = 0;
-    int ntc = 0, nte = 0, nt = IDX_EMPTY;
+    int ntc = 0, nte = 0, nt = IDX_EMPTY, nt2 = IDX_EMPTY;     // train cursor: next item and the one after (prefetched)
 
     const int tiles_per = (a.tiles_total + a.n_splits - 1) / a.n_splits;
     const int t0 = split * tiles_per, t1 = min(a.tiles_total, t0 + tiles_per);
@@ -116,6 +116,7 @@ void k_sweep64(Sweep64Args a)
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.train_i[mid] < first_item) lo = mid + 1; else hi = mid; }
         ntc = lo;
         nt = ntc < nte ? a.train_i[ntc] : IDX_EMPTY;
+        nt2 = ntc + 1 < nte ? a.train_i[ntc + 1] : IDX_EMPTY;
     }
 
     // user factors -> registers: [group][g][q][16 users][2 doubles]
@@ -173,7 +174,8 @@ void k_sweep64(Sweep64Args a)
             while (nt < sb + 32) {
                 if (nt >= sb) mbits |= 1u << (nt - sb);
                 ntc++;
-                nt = ntc < nte ? a.train_i[ntc] : IDX_EMPTY;
+                nt = nt2;                                           // loaded when the previous item was consumed:
+                nt2 = ntc + 1 < nte ? a.train_i[ntc + 1] : IDX_EMPTY;   // the HBM latency never sits in front of the barrier
             }
             if (sb + 32 > n) mbits |= (n > sb) ? (0xffffffffu << (n - sb)) : 0xffffffffu;
             #pragma unroll
