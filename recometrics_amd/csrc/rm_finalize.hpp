@@ -213,8 +213,13 @@ __global__ void k_finalize(FinalArgs<T, S> a)
     // ---- NDCG normalisation (:868-961) ----
     if (a.ndcg) {
         const int L = K < npos ? K : npos;
-        // ideal DCG walks the test values in descending order; selection without scratch: next = largest value that
-        // comes after (value, index) of the previous pick in (value desc, index asc) order
+        // the ideal DCG needs the L largest test values in descending order: ONE pass over the row keeping a small
+        // sorted buffer (values only -- equal values are interchangeable in the sums); rows longer than the buffer's
+        // K fall back to repeated selection
+        constexpr int TOPV = 64;
+        T topv[TOPV];
+        bool has_nan_val = false;
+        const bool buffered = L <= TOPV;
         auto pick_next = [&](bool have_prev, T pv, int pi, T &ov, int &oi) {
             bool found = false; T bv = 0; int bi = -1;
             for (int t = 0; t < npos; t++) {
@@ -224,22 +229,41 @@ __global__ void k_finalize(FinalArgs<T, S> a)
             }
             ov = bv; oi = bi; return found;
         };
-        bool has_nan_val = false;
-        for (int t = 0; t < npos; t++) has_nan_val |= tv[t] != tv[t];
-        T vmaxv = 0, vlast = 0; int pi = -1; T pv = 0;
-        {   // first and L-th values
-            T x; int xi; bool hp = false; pv = 0; pi = -1;
-            for (int i = 0; i < L; i++) { pick_next(hp, pv, pi, x, xi); hp = true; pv = x; pi = xi; if (i == 0) vmaxv = x; }
-            vlast = pv;
+        if (buffered) {
+            int cnt = 0;
+            for (int t = 0; t < npos; t++) {
+                const T x = tv[t];
+                has_nan_val |= x != x;
+                if (cnt < L || x > topv[L - 1]) {
+                    int j = cnt < L ? cnt : L - 1;
+                    while (j > 0 && topv[j - 1] < x) { topv[j] = topv[j - 1]; j--; }
+                    topv[j] = x;
+                    cnt = cnt < L ? cnt + 1 : cnt;
+                }
+            }
+        } else {
+            for (int t = 0; t < npos; t++) has_nan_val |= tv[t] != tv[t];
+        }
+        // value i of the descending order
+        T pv = 0; int pi = -1; bool hp = false;
+        auto next_value = [&](int i) -> T {
+            if (buffered) return topv[i];
+            T x; int xi; pick_next(hp, pv, pi, x, xi); hp = true; pv = x; pi = xi; return x;
+        };
+        T vmaxv = 0, vlast = 0;
+        if (buffered) { vmaxv = topv[0]; vlast = topv[L - 1]; }
+        else {
+            for (int i = 0; i < L; i++) { const T x = next_value(i); if (i == 0) vmaxv = x; vlast = x; }
+            hp = false; pv = 0; pi = -1;
         }
         if (has_nan_val || isinf(vmaxv) || isinf(vlast) || vmaxv <= 0) {
             if (!cum) a.ndcg[u] = qnan<T>(); else for (int i = 0; i < K; i++) cndcg[i] = qnan<T>();
             return;
         }
-        double idcg = 0; bool hp = false; pv = 0; pi = -1; T x; int xi;
+        double idcg = 0;
         if (!cum) {
             for (int ix = 0; ix < L; ix++) {
-                pick_next(hp, pv, pi, x, xi); hp = true; pv = x; pi = xi;
+                const T x = next_value(ix);
                 if (!(vlast >= 0) && x <= 0) break;
                 idcg += (double)x / a.log2tab[ix];
             }
@@ -247,14 +271,14 @@ __global__ void k_finalize(FinalArgs<T, S> a)
         } else {
             if (vlast >= 0) {
                 for (int ix = 0; ix < L; ix++) {
-                    pick_next(hp, pv, pi, x, xi); hp = true; pv = x; pi = xi;
+                    const T x = next_value(ix);
                     idcg += (double)x / a.log2tab[ix];
                     cndcg[ix] = (T)((double)cndcg[ix] / idcg);                      // quirk Q5: divides the rounded DCG
                 }
             } else {
                 int ix = 0;
                 for (; ix < L; ix++) {
-                    pick_next(hp, pv, pi, x, xi); hp = true; pv = x; pi = xi;
+                    const T x = next_value(ix);
                     if (x < 0) break;
                     idcg += (double)x / a.log2tab[ix];
                     cndcg[ix] = (T)((double)cndcg[ix] / idcg);

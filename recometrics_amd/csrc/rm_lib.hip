@@ -206,7 +206,14 @@ void run(const Call<T> &c, hipStream_t stream)
     long long *grow = (long long *)ws.get("grow", sizeof(long long) * (size_t)group_bound);
     AssignArgs aa{m, c.test_p, flags, user_nslots, uslot_base, want_auc ? 1 : 0, plan, slot_user, slot_chunk, slot_index, slot_j};
     hipLaunchKernelGGL(k_assign_slots, dim3(cdiv(m, 256)), dim3(256), 0, stream, aa);
-    hipLaunchKernelGGL(k_group_rows, dim3(1), dim3(1), 0, stream, plan, slot_j, gj, grow, GU);
+    const long long block_bound = group_bound / GROUPS_PER_BLOCK + 2;
+    int *blk_j = (int *)ws.get("blk_j", sizeof(int) * (size_t)block_bound);
+    int *blk_rows = (int *)ws.get("blk_rows", sizeof(int) * (size_t)block_bound);
+    int *blk_base = (int *)ws.get("blk_base", sizeof(int) * (size_t)(block_bound + 1));
+    HIP_CHECK(hipMemsetAsync(blk_rows, 0, sizeof(int) * (size_t)block_bound, stream));
+    hipLaunchKernelGGL(k_block_rows, dim3(cdiv(block_bound, 256)), dim3(256), 0, stream, plan, slot_j, blk_j, blk_rows, GU);
+    hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, blk_rows, blk_base, (int)block_bound, blk_base + block_bound);
+    hipLaunchKernelGGL(k_group_rows, dim3(cdiv(group_bound, 256)), dim3(256), 0, stream, plan, blk_j, blk_base, blk_base + block_bound, gj, grow);
     hipLaunchKernelGGL(k_absmax<T>, dim3(512), dim3(256), 0, stream, c.A, c.lda, (long long)m, k, &plan->amax_a, &plan->nonfinite);
     hipLaunchKernelGGL(k_absmax<T>, dim3(1024), dim3(256), 0, stream, c.B, c.ldb, (long long)n, k, &plan->amax_b, &plan->nonfinite);
     Plan hp;

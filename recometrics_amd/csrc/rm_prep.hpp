@@ -28,32 +28,39 @@ __device__ __forceinline__ int chunk_depth(int pc)      // smallest j with 2^j -
 __global__ void k_classify(ClassifyArgs a)
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= a.m) return;
-    const int ntr = a.train_p[u + 1] - a.train_p[u];
-    const int npos = a.test_p[u + 1] - a.test_p[u];
+    const bool live = u < a.m;
+    const int ntr = live ? a.train_p[u + 1] - a.train_p[u] : 0;
+    const int npos = live ? a.test_p[u + 1] - a.test_p[u] : 0;
     const int cand = a.n - ntr;
-    bool isnan_user = npos <= 0 || (ntr + npos >= a.n && !(a.req & RQ_NDCG)) || cand < a.min_items_pool ||
+    bool isnan_user = !live || npos <= 0 || (ntr + npos >= a.n && !(a.req & RQ_NDCG)) || cand < a.min_items_pool ||
                       (!a.cold && ntr == 0) || npos < a.min_pos_test;
     const bool only_ndcg = (ntr + npos) >= a.n;
     const bool kleqn = cand <= a.K;
     if (!isnan_user && kleqn && !(a.req & (RQ_ROC | RQ_PR | RQ_AP | RQ_TAP | RQ_RR))) isnan_user = true;
-    int f = 0, nsl = 0;
+    int f = 0, nsl = 0, myclass = -1, nfull = 0;
     if (isnan_user) f = UF_NAN;
     else {
         f = UF_ACTIVE | (only_ndcg ? UF_ONLY_NDCG : 0) | (kleqn ? UF_KLEQN : 0);
-        atomicAdd(&a.plan->n_active, 1);
         if (a.want_auc && !only_ndcg) {
-            const int nfull = npos / POS_CHUNK, rem = npos % POS_CHUNK;
+            nfull = npos / POS_CHUNK;
+            const int rem = npos % POS_CHUNK;
             nsl = nfull + (rem ? 1 : 0);
-            if (nfull) atomicAdd(&a.plan->class_count[MAX_J], nfull);
-            if (rem) atomicAdd(&a.plan->class_count[chunk_depth(rem)], 1);
+            myclass = rem ? chunk_depth(rem) : -1;
         } else {
             nsl = 1;
-            atomicAdd(&a.plan->class_count[0], 1);
+            myclass = 0;
         }
     }
-    a.flags[u] = f;
-    a.user_nslots[u] = nsl;
+    // one atomic per wave and class instead of one per user (7 hot addresses otherwise)
+    const int lane = threadIdx.x & 63;
+    const unsigned long long act = __ballot(!isnan_user);
+    if (act && lane == __ffsll((long long)act) - 1) atomicAdd(&a.plan->n_active, __popcll(act));
+    for (int j = 0; j <= MAX_J; j++) {
+        const unsigned long long mk = __ballot(myclass == j);
+        if (mk && lane == __ffsll((long long)mk) - 1) atomicAdd(&a.plan->class_count[j], __popcll(mk));
+    }
+    if (nfull) atomicAdd(&a.plan->class_count[MAX_J], nfull);
+    if (live) { a.flags[u] = f; a.user_nslots[u] = nsl; }
 }
 
 // exclusive scan of int array by ONE block of 1024 threads (m <= 2^31; a few hundred iterations at m = 1M)
@@ -110,35 +117,60 @@ struct AssignArgs {
 __global__ void k_assign_slots(AssignArgs a)
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= a.m) return;
-    const int nsl = a.user_nslots[u];
-    if (!nsl) return;
-    const int npos = a.test_p[u + 1] - a.test_p[u];
-    const bool auc_user = a.want_auc && !(a.flags[u] & UF_ONLY_NDCG);
-    for (int c = 0; c < nsl; c++) {
-        int j = 0;
-        if (auc_user) { const int pc = min(POS_CHUNK, npos - c * POS_CHUNK); j = chunk_depth(pc); }
-        const int pos = a.plan->class_offset[j] + atomicAdd(&a.plan->class_cursor[j], 1);
+    const int lane = threadIdx.x & 63;
+    const int nsl = u < a.m ? a.user_nslots[u] : 0;
+    const int npos = nsl ? a.test_p[u + 1] - a.test_p[u] : 0;
+    const bool auc_user = nsl && a.want_auc && !(a.flags[u] & UF_ONLY_NDCG);
+    // last (or only) chunk of every user: one cursor bump per wave and class
+    int jlast = -1;
+    if (nsl) jlast = auc_user ? chunk_depth(min(POS_CHUNK, npos - (nsl - 1) * POS_CHUNK)) : 0;
+    for (int j = 0; j <= MAX_J; j++) {
+        const unsigned long long mk = __ballot(jlast == j);
+        if (!mk) continue;
+        const int leader = __ffsll((long long)mk) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&a.plan->class_cursor[j], __popcll(mk));
+        base = __shfl(base, leader);
+        if (jlast == j) {
+            const int pos = a.plan->class_offset[j] + base + __popcll(mk & ((1ull << lane) - 1));
+            a.slot_user[pos] = u;
+            a.slot_chunk[pos] = nsl - 1;
+            a.slot_j[pos] = (unsigned char)j;
+            a.slot_index[a.uslot_base[u] + nsl - 1] = pos;
+        }
+    }
+    // the full 63-positive chunks of heavy users (rare)
+    for (int c = 0; c < nsl - 1; c++) {
+        const int pos = a.plan->class_offset[MAX_J] + atomicAdd(&a.plan->class_cursor[MAX_J], 1);
         a.slot_user[pos] = u;
         a.slot_chunk[pos] = c;
-        a.slot_j[pos] = (unsigned char)j;
+        a.slot_j[pos] = (unsigned char)MAX_J;
         a.slot_index[a.uslot_base[u] + c] = pos;
     }
 }
 
-// per sweep block (4 groups): uniform tree depth jb = depth of its last slot; row base of each group.  One thread.
-__global__ void k_group_rows(Plan *p, const unsigned char *slot_j, int *gj, long long *grow, int gu)
+// per sweep block (4 groups): uniform tree depth jb = depth of its last slot (slots are sorted by depth); the block's
+// positive tables take 2^jb - 1 rows per group.  k_block_rows -> k_scan_exclusive -> k_group_rows.
+__global__ void k_block_rows(const Plan *p, const unsigned char *slot_j, int *blk_j, int *blk_rows, int gu)
 {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
     const int ng = p->n_groups, ns = p->n_slots;
-    long long rows = 0;
-    for (int b = 0; b * GROUPS_PER_BLOCK < ng; b++) {
-        const int glast = min(ng, (b + 1) * GROUPS_PER_BLOCK) - 1;
-        const int slast = min(ns, (glast + 1) * gu) - 1;
-        const int jb = slot_j[slast];
-        const int pl = (1 << jb) - 1;
-        for (int g = b * GROUPS_PER_BLOCK; g <= glast; g++) { gj[g] = jb; grow[g] = rows; rows += pl; }
-    }
-    p->total_rows = rows;
+    if (b * GROUPS_PER_BLOCK >= ng) return;
+    const int glast = min(ng, (b + 1) * GROUPS_PER_BLOCK) - 1;
+    const int slast = min(ns, (glast + 1) * gu) - 1;
+    const int jb = slot_j[slast];
+    blk_j[b] = jb;
+    blk_rows[b] = (glast - b * GROUPS_PER_BLOCK + 1) * ((1 << jb) - 1);
+}
+
+__global__ void k_group_rows(Plan *p, const int *blk_j, const int *blk_base, const int *blk_total, int *gj, long long *grow)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0) p->total_rows = *blk_total;
+    if (g >= p->n_groups) return;
+    const int b = g / GROUPS_PER_BLOCK, jb = blk_j[b];
+    gj[g] = jb;
+    grow[g] = (long long)blk_base[b] + (long long)(g % GROUPS_PER_BLOCK) * ((1 << jb) - 1);
 }
 
 // max |x| over a row-major matrix (rows x k, leading dimension ld) + a non-finite flag: lets the host prove that no
@@ -311,26 +343,43 @@ __global__ void k_pos_scores(PosArgs<T> a)
     }
 }
 
+template <class T> __device__ __forceinline__ T lane_bcast(T v, int src);
+template <> __device__ __forceinline__ float lane_bcast<float>(float v, int src) { return __shfl(v, src); }
+template <> __device__ __forceinline__ double lane_bcast<double>(double v, int src) { return __shfl(v, src); }
+
+// one wavefront per user: rank of every test entry in (score asc, item desc) order by all-pairs counting.  Entries are
+// held in registers 64 at a time and broadcast lane by lane, so the inner loop touches no memory.
 template <class T>
 __global__ void k_pos_place(PosArgs<T> a)
 {
     const int u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (u >= a.m || !(a.flags[u] & UF_ACTIVE) || (a.flags[u] & UF_ONLY_NDCG)) return;
     const int te0 = a.test_p[u], te1 = a.test_p[u + 1];
-    for (int e = te0 + lane; e < te1; e += WAVE) {
-        const T s = a.pos_tmp[e];
-        const int item = a.test_i[e];
+    for (int e0 = te0; e0 < te1; e0 += WAVE) {                   // my block of 64 entries
+        const int e = e0 + lane;
+        const bool mine = e < te1;
+        const T s = mine ? a.pos_tmp[e] : (T)0;
+        const int item = mine ? a.test_i[e] : 0;
         int rank = 0;
-        for (int f = te0; f < te1; f++) {
-            const T sf = a.pos_tmp[f];
-            rank += (sf < s) || (sf == s && a.test_i[f] > item);
+        for (int f0 = te0; f0 < te1; f0 += WAVE) {               // against every block of 64 entries
+            const int f = f0 + lane;
+            const T sf = f < te1 ? a.pos_tmp[f] : (T)0;
+            const int itf = f < te1 ? a.test_i[f] : 0;
+            const int cnt = min(WAVE, te1 - f0);
+            for (int j = 0; j < cnt; j++) {
+                const T sj = lane_bcast<T>(sf, j);
+                const int ij = __shfl(itf, j);
+                rank += (sj < s) || (sj == s && ij > item);
+            }
         }
-        a.pos_order[e] = rank;
-        const int c = rank / POS_CHUNK, r = rank % POS_CHUNK;
-        const int slot = a.slot_index[a.uslot_base[u] + c];
-        const long long at = (a.grow[slot / a.gu] + slot / a.gu + r) * a.gu + (slot % a.gu);
-        a.pos_score[at] = s;
-        a.pos_item[at] = item;
+        if (mine) {
+            a.pos_order[e] = rank;
+            const int c = rank / POS_CHUNK, r = rank % POS_CHUNK;
+            const int slot = a.slot_index[a.uslot_base[u] + c];
+            const long long at = (a.grow[slot / a.gu] + slot / a.gu + r) * a.gu + (slot % a.gu);
+            a.pos_score[at] = s;
+            a.pos_item[at] = item;
+        }
     }
 }
 
