@@ -275,7 +275,7 @@ void run(const Call<T> &c, hipStream_t stream)
             PosArgs<T> pa{m, n, k, c.A, c.lda, c.B, c.ldb, c.train_p, c.train_i, c.test_p, c.test_i,
                           flags, user_nslots, uslot_base, slot_index, grow, pos_tmp, pos_order, pos_score, pos_item, GU};
             hipLaunchKernelGGL(k_pos_scores<T>, dim3(cdiv((long long)m * WAVE, 256)), dim3(256), 0, stream, pa);
-            hipLaunchKernelGGL(k_pos_place<T>, dim3(cdiv((long long)m * WAVE, 256)), dim3(256), 0, stream, pa);
+            hipLaunchKernelGGL(k_pos_place<T>, dim3(cdiv((long long)n_slots * WAVE, 256)), dim3(256), 0, stream, pa, slot_user, slot_chunk, n_slots);
         }
 
         pl = (Entry<T> *)ws.get("pl", sizeof(Entry<T>) * (size_t)n_slots * n_part * K);

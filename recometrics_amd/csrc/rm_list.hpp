@@ -51,12 +51,37 @@ __device__ __forceinline__ void list_find_worst(P L, int K, S &ws, int &widx, in
     }
 }
 
+// unsorted list, replace-the-minimum: 1 store + K loads per insert (used for lists in HBM, where a shifting chain of
+// dependent round trips would be slow)
 template <class S, int GU, class P>
 __device__ __forceinline__ void list_offer(P L, int K, S s, int item, S &ws, int &widx, int &wpos)
 {
     if (s > ws || (s == ws && item < widx)) {
         L[wpos * GU] = ListRaw<S>::pack(s, item);
         list_find_worst<S, GU>(L, K, ws, widx, wpos);
+    }
+}
+
+// descending sorted list, insertion from the bottom: a new entrant lands on average K/2 places up, so this is ~K/2
+// (load, compare, store) steps -- fewer instructions than the K-entry rescan above, which is what matters in LDS where
+// the issue slots are shared with the f32 MFMA.  (ws, widx) = the K-th entry.
+template <class S, int GU, class P>
+__device__ __forceinline__ void list_offer_sorted(P L, int K, S s, int item, S &ws, int &widx)
+{
+    if (s > ws || (s == ws && item < widx)) {
+        int i = K - 1;
+        S ps = ws; int pidx = widx;                    // entry that will end up K-th if the new one lands higher
+        while (i > 0) {
+            S qs; int qidx;
+            ListRaw<S>::unpack(L[(i - 1) * GU], qs, qidx);
+            if (qs > s || (qs == s && qidx < item)) break;
+            L[i * GU] = ListRaw<S>::pack(qs, qidx);
+            if (i == K - 1) { ps = qs; pidx = qidx; }
+            i--;
+        }
+        L[i * GU] = ListRaw<S>::pack(s, item);
+        if (i == K - 1) { ps = s; pidx = item; }
+        ws = ps; widx = pidx;
     }
 }
 

@@ -343,43 +343,52 @@ __global__ void k_pos_scores(PosArgs<T> a)
     }
 }
 
+// broadcast of lane `src` (wave-uniform index): v_readlane_b32, no LDS crossbar round trip
 template <class T> __device__ __forceinline__ T lane_bcast(T v, int src);
-template <> __device__ __forceinline__ float lane_bcast<float>(float v, int src) { return __shfl(v, src); }
-template <> __device__ __forceinline__ double lane_bcast<double>(double v, int src) { return __shfl(v, src); }
-
-// one wavefront per user: rank of every test entry in (score asc, item desc) order by all-pairs counting.  Entries are
-// held in registers 64 at a time and broadcast lane by lane, so the inner loop touches no memory.
-template <class T>
-__global__ void k_pos_place(PosArgs<T> a)
+template <> __device__ __forceinline__ int lane_bcast<int>(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+template <> __device__ __forceinline__ float lane_bcast<float>(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+template <> __device__ __forceinline__ double lane_bcast<double>(double v, int src)
 {
-    const int u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (u >= a.m || !(a.flags[u] & UF_ACTIVE) || (a.flags[u] & UF_ONLY_NDCG)) return;
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// One wavefront per SLOT (= up to 63 test entries of one user, by row position): rank of each of them among ALL the
+// user's entries in (score asc, item desc) order, by all-pairs counting.  The row is walked 64 entries at a time out
+// of registers (lane broadcasts), so the inner loop touches no memory, and a user with thousands of positives is
+// spread over as many waves as it has slots instead of serialising the kernel behind one wave.
+template <class T>
+__global__ void k_pos_place(PosArgs<T> a, const int *slot_user, const int *slot_chunk, int n_slots)
+{
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (w >= n_slots) return;
+    const int u = slot_user[w], c0 = slot_chunk[w];
+    if (a.flags[u] & UF_ONLY_NDCG) return;
     const int te0 = a.test_p[u], te1 = a.test_p[u + 1];
-    for (int e0 = te0; e0 < te1; e0 += WAVE) {                   // my block of 64 entries
-        const int e = e0 + lane;
-        const bool mine = e < te1;
-        const T s = mine ? a.pos_tmp[e] : (T)0;
-        const int item = mine ? a.test_i[e] : 0;
-        int rank = 0;
-        for (int f0 = te0; f0 < te1; f0 += WAVE) {               // against every block of 64 entries
-            const int f = f0 + lane;
-            const T sf = f < te1 ? a.pos_tmp[f] : (T)0;
-            const int itf = f < te1 ? a.test_i[f] : 0;
-            const int cnt = min(WAVE, te1 - f0);
-            for (int j = 0; j < cnt; j++) {
-                const T sj = lane_bcast<T>(sf, j);
-                const int ij = __shfl(itf, j);
-                rank += (sj < s) || (sj == s && ij > item);
-            }
+    const int e = te0 + c0 * POS_CHUNK + lane;
+    const bool mine = lane < POS_CHUNK && e < te1;
+    const T s = mine ? a.pos_tmp[e] : (T)0;
+    const int item = mine ? a.test_i[e] : 0;
+    int rank = 0;
+    for (int f0 = te0; f0 < te1; f0 += WAVE) {
+        const int f = f0 + lane;
+        const T sf = f < te1 ? a.pos_tmp[f] : (T)0;
+        const int itf = f < te1 ? a.test_i[f] : 0;
+        const int cnt = min(WAVE, te1 - f0);
+        for (int j = 0; j < cnt; j++) {
+            const T sj = lane_bcast<T>(sf, j);
+            const int ij = lane_bcast<int>(itf, j);
+            rank += (sj < s) || (sj == s && ij > item);
         }
-        if (mine) {
-            a.pos_order[e] = rank;
-            const int c = rank / POS_CHUNK, r = rank % POS_CHUNK;
-            const int slot = a.slot_index[a.uslot_base[u] + c];
-            const long long at = (a.grow[slot / a.gu] + slot / a.gu + r) * a.gu + (slot % a.gu);
-            a.pos_score[at] = s;
-            a.pos_item[at] = item;
-        }
+    }
+    if (mine) {
+        a.pos_order[e] = rank;
+        const int c = rank / POS_CHUNK, r = rank % POS_CHUNK;
+        const int slot = a.slot_index[a.uslot_base[u] + c];
+        const long long at = (a.grow[slot / a.gu] + slot / a.gu + r) * a.gu + (slot % a.gu);
+        a.pos_score[at] = s;
+        a.pos_item[at] = item;
     }
 }
 
