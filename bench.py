@@ -43,7 +43,7 @@ class DeviceProblem:
 
     def __init__(self, torch, dev, m, n, k, mean_c, seed, K, dtype=np.float32):
         from recometrics_amd.synth import make_factors, make_interactions
-        self.m, self.n, self.k, self.K = m, n, k, K
+        self.m, self.n, self.k, self.K, self.dtype = m, n, k, K, dtype
         A, B = make_factors(m, n, k, dtype, seed)
         trp, tri, tep, tei, tev = make_interactions(m, n, mean_c, dtype, seed)
         self.host = dict(A=A, B=B, train=(trp, tri), test=(tep, tei, tev))
@@ -51,12 +51,12 @@ class DeviceProblem:
         self.A, self.B = t(A), t(B)
         self.trp, self.tri, self.tep, self.tei, self.tev = t(trp), t(tri if tri.size else np.zeros(1, np.int32)), t(tep), t(tei), t(tev)
         self.nnz_tr, self.nnz_te = int(tri.shape[0]), int(tei.shape[0])
-        self.out = torch.empty((10, m), dtype=torch.float32, device=dev)     # the per-user metric block
+        self.out = torch.empty((10, m), dtype=torch.float32 if dtype == np.float32 else torch.float64, device=dev)   # per-user metric block
 
     def step(self, binding, stream):
         o = self.out
         binding.calc_metrics_device(
-            np.float32, self.A.data_ptr(), self.k, self.B.data_ptr(), self.k, self.m, self.n, self.k,
+            self.dtype, self.A.data_ptr(), self.k, self.B.data_ptr(), self.k, self.m, self.n, self.k,
             self.trp.data_ptr(), self.tri.data_ptr(), self.nnz_tr, self.tep.data_ptr(), self.tei.data_ptr(),
             self.tev.data_ptr(), self.nnz_te, self.K, [o[i].data_ptr() for i in range(10)],
             cumulative=False, break_ties_with_noise=False, stream=stream)

@@ -119,12 +119,18 @@ void k_sweep64(Sweep64Args a)
         nt2 = ntc + 1 < nte ? a.train_i[ntc + 1] : IDX_EMPTY;
     }
 
-    // user factors -> registers: [group][g][q][16 users][2 doubles]
-    f64x2 af[NGT];
-    #pragma unroll
-    for (int g = 0; g < NGT; g++) {
-        f64x2 z; z.x = 0; z.y = 0;
-        af[g] = group_ok ? a.Ap[((size_t)(group * NGT + g) * 4 + q) * GU + ul] : z;
+    // user factors -> registers: [group][g][q][16 users][2 doubles].  Up to 128 factors (64 VGPRs) they stay resident
+    // for the whole sweep; beyond that each 64-factor chunk is re-read from L2 when its turn comes.
+    constexpr bool AF_RESIDENT = NGT <= 16;
+    constexpr int NAF = AF_RESIDENT ? NGT : NGC;
+    f64x2 af[NAF];
+    const f64x2 *af_src = a.Ap + ((size_t)(group_ok ? group : 0) * NGT * 4 + q) * GU + ul;     // + g * 4 * GU
+    if (AF_RESIDENT) {
+        #pragma unroll
+        for (int g = 0; g < NGT; g++) {
+            f64x2 z; z.x = 0; z.y = 0;
+            af[g] = group_ok ? af_src[(size_t)g * 4 * GU] : z;
+        }
     }
 
     GblList64Ptr Lg = LLDS ? (lists_lds + wave * K * GU + ul) : (a.glists + ((size_t)blockIdx.x * 8 + wave) * K * GU + ul);
@@ -155,7 +161,8 @@ void k_sweep64(Sweep64Args a)
                                              (__attribute__((address_space(3))) void *)(dst + pc * 64), 16, 0, 0);
     };
 
-    auto do_epi = [&](const f64x4 &acc_lo, const f64x4 &acc_hi, int tile) {
+    unsigned long long thr_pub = 0;
+    auto do_epi = [&](const f64x4 &acc_lo, const f64x4 &acc_hi, int tile, unsigned long long thr_seen) {
         const int sb = tile * TILE_ITEMS + sub * 32;
         double v[8];
         #pragma unroll
@@ -190,6 +197,7 @@ void k_sweep64(Sweep64Args a)
         }
         #pragma unroll
         for (int r = 0; r < 8; r++) { vmax = __builtin_fmax(vmax, v[r]); vmin = __builtin_fmin(vmin, v[r]); }
+        if (primary && thr_seen > thr_pub) { thr_pub = thr_seen; const double t = ord_unkey(thr_seen); thr = t > thr ? t : thr; }
         unsigned long long cm = 0;
         #pragma unroll
         for (int r = 0; r < 8; r++) cm |= __ballot(v[r] >= thr);
@@ -215,7 +223,12 @@ void k_sweep64(Sweep64Args a)
                 }
             }
             const double t2 = __shfl(ws, ul);
-            thr = primary ? t2 : thr;
+            if (primary) {
+                thr = t2 > thr ? t2 : thr;
+                const unsigned long long kk = ord_key(t2);
+                if (q == 0 && kk > thr_pub) atomicMax(a.thr_shared + slot, kk);
+                thr_pub = kk > thr_pub ? kk : thr_pub;
+            }
         }
         if (AUC) {
             unsigned rocacc = 0;
@@ -232,15 +245,15 @@ void k_sweep64(Sweep64Args a)
         }
     };
 
-    // ---- main loop over tiles, chunks of the factor axis statically unrolled inside; one barrier per chunk ----
-    f64x4 a0lo, a0hi, a1lo, a1hi;
-    const bool roleX = sub == 0;
+    // ---- main loop over tiles, chunks of the factor axis statically unrolled inside; one barrier per chunk.  All waves
+    // run in phase (MFMA chunks, then the tile's epilogue), as in the fp32 sweep. ----
+    f64x4 clo, chi;
     const int nunits = ntiles * NC;
     if (ntiles > 0) stage(t0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    auto tile_step = [&](int i, f64x4 &clo, f64x4 &chi, f64x4 &plo, f64x4 &phi) {
-        const bool has_cur = i < ntiles;
+    for (int i = 0; i < ntiles; i++) {
+        const unsigned long long thr_seen = (primary && !DUMP) ? __hip_atomic_load(a.thr_shared + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         #pragma unroll
         for (int c = 0; c < NC; c++) {
             const int unit = i * NC + c;
@@ -249,32 +262,28 @@ void k_sweep64(Sweep64Args a)
                 const int nu = unit + 1;
                 stage(t0 + nu / NC, nu % NC, nu & 1);
             }
-            auto mfma_chunk = [&]() {
-                const f64x2 *bb = ldsB + buf * BUF_D2 + q * TILE_ITEMS + sub * 32 + ul;
-                if (c == 0) {
-                    #pragma unroll
-                    for (int r = 0; r < 4; r++) { clo[r] = 0.; chi[r] = 0.; }
-                }
+            const f64x2 *bb = ldsB + buf * BUF_D2 + q * TILE_ITEMS + sub * 32 + ul;
+            if (!AF_RESIDENT) {
                 #pragma unroll
-                for (int gl = 0; gl < NGC; gl++) {
-                    const f64x2 b0 = bb[gl * 4 * TILE_ITEMS], b1 = bb[gl * 4 * TILE_ITEMS + 16];
-                    const f64x2 u = af[c * NGC + gl];
-                    clo = __builtin_amdgcn_mfma_f64_16x16x4f64(b0.x, u.x, clo, 0, 0, 0);
-                    chi = __builtin_amdgcn_mfma_f64_16x16x4f64(b1.x, u.x, chi, 0, 0, 0);
-                    clo = __builtin_amdgcn_mfma_f64_16x16x4f64(b0.y, u.y, clo, 0, 0, 0);
-                    chi = __builtin_amdgcn_mfma_f64_16x16x4f64(b1.y, u.y, chi, 0, 0, 0);
-                }
-            };
-            if (roleX && has_cur) mfma_chunk();
-            if (c == 0 && i > 0) do_epi(plo, phi, t0 + i - 1);
-            if (!roleX && has_cur) mfma_chunk();
+                for (int gl = 0; gl < NGC; gl++) af[gl] = af_src[(size_t)(c * NGC + gl) * 4 * GU];
+            }
+            if (c == 0) {
+                #pragma unroll
+                for (int r = 0; r < 4; r++) { clo[r] = 0.; chi[r] = 0.; }
+            }
+            #pragma unroll
+            for (int gl = 0; gl < NGC; gl++) {
+                const f64x2 b0 = bb[gl * 4 * TILE_ITEMS], b1 = bb[gl * 4 * TILE_ITEMS + 16];
+                const f64x2 u = af[AF_RESIDENT ? c * NGC + gl : gl];
+                clo = __builtin_amdgcn_mfma_f64_16x16x4f64(b0.x, u.x, clo, 0, 0, 0);
+                chi = __builtin_amdgcn_mfma_f64_16x16x4f64(b1.x, u.x, chi, 0, 0, 0);
+                clo = __builtin_amdgcn_mfma_f64_16x16x4f64(b0.y, u.y, clo, 0, 0, 0);
+                chi = __builtin_amdgcn_mfma_f64_16x16x4f64(b1.y, u.y, chi, 0, 0, 0);
+            }
+            if (c == NC - 1) do_epi(clo, chi, t0 + i, thr_seen);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-    };
-    for (int i = 0; i <= ntiles; i += 2) {
-        tile_step(i, a0lo, a0hi, a1lo, a1hi);
-        if (i + 1 <= ntiles) tile_step(i + 1, a1lo, a1hi, a0lo, a0hi);
     }
     if (DUMP) return;
 

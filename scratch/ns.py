@@ -11,7 +11,8 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 m, n, k, dtype, K, mean_c, seed = CONFIGS[wl]
 m = users
 torch.cuda.set_device(0); binding.load(); binding.set_device(0)
-p = DeviceProblem(torch, torch.device("cuda", 0), m, n, k, mean_c, seed, K)
+p = DeviceProblem(torch, torch.device("cuda", 0), m, n, k, mean_c, seed, K, dtype)
 dt, sw, pr, fi, tm = measure(torch, dist, binding, p, steps, 1, 1, None)
 tf = 2.0 * n * k * m / (sw * 1e-3) / 1e12
-print(json.dumps({"workload": wl, "users": m, "users_per_s": m * steps / dt, "sweep_ms": sw, "prep_ms": pr, "fin_ms": fi, "TF": tf, "frac": tf / 157.3, "tm": tm}))
+peak = 157.3 if dtype == np.float32 else 78.6
+print(json.dumps({"workload": wl, "users": m, "users_per_s": m * steps / dt, "sweep_ms": sw, "prep_ms": pr, "fin_ms": fi, "TF": tf, "frac": tf / peak, "tm": tm}))
