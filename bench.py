@@ -22,6 +22,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, chip table: dense f32-input MFMA
+PEAK_FP64_MFMA_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
 
 
@@ -62,7 +63,18 @@ class DeviceProblem:
             cumulative=False, break_ties_with_noise=False, stream=stream)
 
 
-def cpu_baseline(host, K, n_users_total, budget_s):
+def load_traffic(workload, users):
+    """HBM bytes per sweep launch from the committed PMC run (scratch/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in
+    separate rocprofv3 passes, FETCH_SIZE doubled per the gfx950 correction); None when no matching profile exists."""
+    path = os.path.join(ROOT, "profiles", "r1_traffic_%s.json" % workload)
+    try:
+        d = json.load(open(path))
+        return d["hbm_bytes"] if int(d.get("users", -1)) == int(users) else None
+    except Exception:      # noqa: BLE001
+        return None
+
+
+def cpu_baseline(host, K, n_users_total, budget_s, dtype=np.float32):
     """The CPU path on this host's cores over a bounded sample of the same workload."""
     from oracle import oracle as orc
     ncores = os.cpu_count() or 1
@@ -78,7 +90,7 @@ def cpu_baseline(host, K, n_users_total, budget_s):
         sub_tr = (trp[:nu + 1], tri[:trp[nu]] if trp[nu] else np.zeros(1, np.int32))
         sub_te = (tep[:nu + 1], tei[:tep[nu]], tev[:tep[nu]])
         t0 = time.perf_counter()
-        impl.calc(A[:nu], B, sub_tr, sub_te, K, nthreads=ncores, noise=False)
+        impl.calc(A[:nu], B, sub_tr, sub_te, K, nthreads=ncores, noise=False, dtype=dtype)
         return time.perf_counter() - t0
 
     probe = min(n_users_total, max(ncores * 2, 64))
@@ -145,8 +157,11 @@ def main():
         m = m // 8                                           # C3 is quoted user-sharded over 8 GPUs
     if args.users:
         m = args.users
-    prob = DeviceProblem(torch, dev, m, n, k, mean_c, seed + 1000 * rank, K)
-    gather_buf = torch.empty((world * 10, m), dtype=torch.float32, device=dev) if world > 1 else None
+    prob = DeviceProblem(torch, dev, m, n, k, mean_c, seed + 1000 * rank, K, dtype)
+    gather_buf = torch.empty((world * 10, m), dtype=prob.out.dtype, device=dev) if world > 1 else None
+    peak = PEAK_FP32_MFMA_TFLOPS if dtype == np.float32 else PEAK_FP64_MFMA_TFLOPS
+    esize = 4.0 if dtype == np.float32 else 8.0
+    dname = "f32" if dtype == np.float32 else "f64"
 
     dt, sweep_ms, prep_ms, fin_ms, tm = measure(torch, dist, binding, prob, args.steps, args.warmup, world, gather_buf)
     users_per_s = world * m * args.steps / dt
@@ -155,16 +170,16 @@ def main():
     line = {
         "metric": "users/sec evaluated (all metrics, K=%d)" % K, "value": users_per_s, "unit": "users/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %d users/GPU x %d items, %d factors fp32, K=%d, all 10 metrics, noise off"
-                               % (args.workload, m, n, k, K),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dname, "data": "synthetic",
+        "config": {"workload": "%s: %d users/GPU x %d items, %d factors %s, K=%d, all 10 metrics, noise off"
+                               % (args.workload, m, n, k, dname, K),
                    "users_per_gpu": m, "n_items": n, "n_factors": k, "k_metrics": K,
                    "sharding": "users sharded, item factors replicated, 1 all-gather of the metric block per step"},
-        "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved_tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+        "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s",
+                     "frac": achieved_tf / peak, "traffic": load_traffic(args.workload, m),
                      "kernel": "k_sweep", "avg_launch_ms": sweep_ms, "flops_per_launch": flops_per_launch,
-                     "hbm_equiv_GBs": n * k * 4.0 * m / (sweep_ms * 1e-3) / 1e9,
-                     "hbm_equiv_frac": n * k * 4.0 * m / (sweep_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+                     "hbm_equiv_GBs": n * k * esize * m / (sweep_ms * 1e-3) / 1e9,
+                     "hbm_equiv_frac": n * k * esize * m / (sweep_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
         "stage_ms": {"prep": prep_ms, "sweep": sweep_ms, "finalize": fin_ms, "item_splits": tm.get("item_splits"),
                      "sweep_blocks": tm.get("sweep_blocks"), "lds_bytes": tm.get("lds_bytes")},
     }
@@ -190,7 +205,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu:
         try:
-            line["cpu_baseline"] = cpu_baseline(prob.host, K, m, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(prob.host, K, m, args.cpu_seconds, dtype)
         except Exception as e:      # noqa: BLE001
             line["cpu_baseline"] = {"value": None, "unit": "users/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
     elif rank == 0:
