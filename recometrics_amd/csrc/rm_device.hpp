@@ -70,6 +70,17 @@ __device__ __forceinline__ double ord_unkey(unsigned long long k)
     return __longlong_as_double((long long)(k ^ ((k >> 63) ? 0x8000000000000000ull : 0xffffffffffffffffull)));
 }
 
+// broadcast of lane `src` (wave-uniform index): v_readlane_b32, no LDS crossbar round trip
+template <class T> __device__ __forceinline__ T lane_bcast(T v, int src);
+template <> __device__ __forceinline__ int lane_bcast<int>(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+template <> __device__ __forceinline__ float lane_bcast<float>(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+template <> __device__ __forceinline__ double lane_bcast<double>(double v, int src)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // row of accumulator register r in a 32x32 MFMA result for the lane half h (cdna_hip_programming.md section 3)
 __device__ __forceinline__ constexpr int mfma32_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

@@ -16,6 +16,7 @@ struct SweepArgs {
     int jmax;                             // LDS sizing (all blocks)
     int list_in_lds;
     int check_nan;                        // 0 when the host proved all scores finite (skips the NaN scan)
+    int buffered_lists;                   // HBM lists: 1 = append buffer + compaction (large K), 0 = replace-the-minimum
     const float4 *Ap, *Bp;
     const int *slot_user, *slot_chunk;
     const int *train_p, *train_i;
@@ -36,6 +37,7 @@ struct Sweep64Args {
     int n_splits, tiles_total;
     int jmax;
     int check_nan;
+    int buffered_lists;
     const f64x2 *Ap, *Bp;
     const int *slot_user, *slot_chunk;
     const int *train_p, *train_i;

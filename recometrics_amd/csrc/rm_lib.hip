@@ -282,7 +282,10 @@ void run(const Call<T> &c, hipStream_t stream)
         pst = (PartialStat<T> *)ws.get("pst", sizeof(PartialStat<T>) * (size_t)n_slots * n_part);
         typename P::ListT *glists = nullptr;
         const unsigned n_blocks = (unsigned)n_ublocks * n_splits;
-        if (!list_in_lds) glists = (typename P::ListT *)ws.get("glists", sizeof(typename P::ListT) * (size_t)n_blocks * 8 * K * GU);
+        if (!list_in_lds) {
+            if (K > 256) throw RmError{RM_ERR_UNSUPPORTED, "k_metrics > 256 is not supported when the top-K lists do not fit LDS"};
+            glists = (typename P::ListT *)ws.get("glists", sizeof(typename P::ListT) * (size_t)n_blocks * 8 * GU * (2 * K + 32));
+        }
 
         typedef typename std::remove_pointer<decltype(typename P::Args{}.thr_shared)>::type ThrT;
         ThrT *thr_shared = (ThrT *)ws.get("thr_shared", sizeof(ThrT) * (size_t)n_slots);
@@ -290,7 +293,7 @@ void run(const Call<T> &c, hipStream_t stream)
         typename P::Args sa{};
         sa.thr_shared = thr_shared;
         sa.n = n; sa.K = K; sa.n_slots = n_slots; sa.n_groups = n_groups; sa.n_ublocks = n_ublocks;
-        sa.n_splits = n_splits; sa.tiles_total = tiles_total; sa.jmax = jmax; sa.check_nan = check_nan ? 1 : 0;
+        sa.n_splits = n_splits; sa.tiles_total = tiles_total; sa.jmax = jmax; sa.check_nan = check_nan ? 1 : 0; sa.buffered_lists = K > 32 ? 1 : 0;
         sa.Ap = (decltype(sa.Ap))Ap; sa.Bp = (decltype(sa.Bp))Bp; sa.slot_user = slot_user; sa.slot_chunk = slot_chunk;
         sa.train_p = c.train_p; sa.train_i = c.train_i; sa.gj = gj; sa.grow = grow;
         sa.pos_score = pos_score; sa.pos_item = pos_item; sa.hist = hist; sa.glists = glists; sa.pl = pl; sa.pst = pst; sa.dump = nullptr;
@@ -444,7 +447,7 @@ void debug_scores(const T *A, size_t lda, const T *B, size_t ldb, int m, int n, 
     pack_operands(dA, (size_t)k, dB, (size_t)k, n, k, NG, slot_user, m, Ap, ap_units, Bp, bp_units, stream);
     T *dump = (T *)ws.get("dbg_dump", sizeof(T) * (size_t)m * n);
     const int K = 1;
-    typename P::ListT *glists = (typename P::ListT *)ws.get("glists", sizeof(typename P::ListT) * (size_t)n_ublocks * 8 * K * GU);
+    typename P::ListT *glists = (typename P::ListT *)ws.get("glists", sizeof(typename P::ListT) * (size_t)n_ublocks * 8 * GU * (2 * K + 32));
     typename P::Args sa{};
     sa.n = n; sa.K = K; sa.n_slots = m; sa.n_groups = n_groups; sa.n_ublocks = n_ublocks; sa.n_splits = 1;
     sa.tiles_total = tiles_total; sa.jmax = 0; sa.check_nan = 1; sa.Ap = (decltype(sa.Ap))Ap; sa.Bp = (decltype(sa.Bp))Bp;

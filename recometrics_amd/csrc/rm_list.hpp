@@ -18,6 +18,12 @@ template <> struct ListRaw<float> {
     typedef u32x2 raw;                                        // (score bits, item id)
     __device__ static __forceinline__ raw pack(float s, int idx) { raw q; q.x = __float_as_uint(s); q.y = (unsigned)idx; return q; }
     __device__ static __forceinline__ void unpack(raw q, float &s, int &idx) { s = __uint_as_float(q.x); idx = (int)q.y; }
+    // L1-bypassing load (sc1): entries other lanes of this wave stored must be read back through L2
+    __device__ static __forceinline__ raw load_l2(const raw *p)
+    {
+        const unsigned long long b = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        raw q; q.x = (unsigned)b; q.y = (unsigned)(b >> 32); return q;
+    }
 };
 template <> struct ListRaw<double> {
     typedef u32x4 raw;                                        // (score lo, score hi, item id, pad)
@@ -29,6 +35,13 @@ template <> struct ListRaw<double> {
     __device__ static __forceinline__ void unpack(raw q, double &s, int &idx)
     {
         s = __longlong_as_double((long long)(((unsigned long long)q.y << 32) | q.x)); idx = (int)q.z;
+    }
+    __device__ static __forceinline__ raw load_l2(const raw *p)
+    {
+        const unsigned long long *pp = (const unsigned long long *)p;
+        const unsigned long long b0 = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long b1 = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        raw q; q.x = (unsigned)b0; q.y = (unsigned)(b0 >> 32); q.z = (unsigned)b1; q.w = (unsigned)(b1 >> 32); return q;
     }
 };
 
@@ -101,6 +114,51 @@ __device__ __forceinline__ void list_sort_desc(P L, int K)
         }
         L[j * GU] = ListRaw<S>::pack(es, eidx);
     }
+}
+
+// ---- large K: append buffer + wave-cooperative compaction (lists that do not fit LDS live in HBM) -----------------------
+// A user's buffer holds up to CAP = 2K + 32 raw entries, user-major (contiguous) in HBM.  The owner lane appends every
+// candidate that passes its threshold (one store); when more than 2K have accumulated, the whole wave selects the K best:
+// every lane holds cnt/64 entries, the buffer is replayed 64 entries at a time through lane broadcasts, each entry gets
+// its rank in the (score desc, item asc) order by counting, and entries ranked < K are written back at [rank] -- so the
+// survivors are also sorted.  The threshold only rises at a compaction, so the stream position doubles between
+// compactions: ~log2(n/K) of them per user and ~K of appends per compaction.
+template <class S>
+__device__ __forceinline__ void wave_compact(typename ListRaw<S>::raw *Gu, int cnt, int K, int lane, S &kth_s, int &kth_idx)
+{
+    constexpr int MAXE = 9;                                   // (2*256 + 32) / 64 rounded up
+    S es[MAXE]; int ei[MAXE]; int rk[MAXE];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the owner lane's appends have reached L2
+    const int E = (cnt + WAVE - 1) / WAVE;
+    #pragma unroll
+    for (int t = 0; t < MAXE; t++) {
+        const int i = lane + t * WAVE;
+        es[t] = 0; ei[t] = IDX_EMPTY; rk[t] = 0;
+        if (t < E && i < cnt) ListRaw<S>::unpack(ListRaw<S>::load_l2(Gu + i), es[t], ei[t]);
+    }
+    for (int b = 0; b < E; b++) {
+        const int nb = min(WAVE, cnt - b * WAVE);
+        S bs = 0; int bi = 0;
+        #pragma unroll
+        for (int t = 0; t < MAXE; t++) if (t == b) { bs = es[t]; bi = ei[t]; }
+        for (int j = 0; j < nb; j++) {
+            const S sj = lane_bcast<S>(bs, j);
+            const int ij = lane_bcast<int>(bi, j);
+            #pragma unroll
+            for (int t = 0; t < MAXE; t++) { if (t >= E) break; rk[t] += (sj > es[t]) || (sj == es[t] && ij < ei[t]); }
+        }
+    }
+    kth_s = -(S)INFINITY; kth_idx = IDX_EMPTY;
+    #pragma unroll
+    for (int t = 0; t < MAXE; t++) {
+        if (t >= E) break;
+        const int i = lane + t * WAVE;
+        const bool live = i < cnt;
+        if (live && rk[t] < K) Gu[rk[t]] = ListRaw<S>::pack(es[t], ei[t]);
+        const unsigned long long hit = __ballot(live && rk[t] == K - 1);
+        if (hit) { const int src = __ffsll((long long)hit) - 1; kth_s = lane_bcast<S>(es[t], src); kth_idx = lane_bcast<int>(ei[t], src); }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // survivors written before anyone appends behind them
 }
 
 } // namespace rm

@@ -343,17 +343,6 @@ __global__ void k_pos_scores(PosArgs<T> a)
     }
 }
 
-// broadcast of lane `src` (wave-uniform index): v_readlane_b32, no LDS crossbar round trip
-template <class T> __device__ __forceinline__ T lane_bcast(T v, int src);
-template <> __device__ __forceinline__ int lane_bcast<int>(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
-template <> __device__ __forceinline__ float lane_bcast<float>(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
-template <> __device__ __forceinline__ double lane_bcast<double>(double v, int src)
-{
-    const long long b = __double_as_longlong(v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), src);
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
 // One wavefront per SLOT (= up to 63 test entries of one user, by row position): rank of each of them among ALL the
 // user's entries in (score asc, item desc) order, by all-pairs counting.  The row is walked 64 entries at a time out
 // of registers (lane broadcasts), so the inner loop touches no memory, and a user with thousands of positives is

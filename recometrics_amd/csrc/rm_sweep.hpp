@@ -134,12 +134,30 @@ void k_sweep(SweepArgs a)
     for (int g = 0; g < NG; g++)
         af[g] = group_ok ? a.Ap[((size_t)(group * NG + g) * 2 + h) * GROUP_USERS + ul] : make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // top-K list of this wave: [K][32 users], owned by the lanes with h == 0
-    GblListPtr Lg = LLDS ? ((GblListPtr)lists_lds + wave * K * GROUP_USERS + ul)
-                         : (a.glists + ((size_t)blockIdx.x * 8 + wave) * K * GROUP_USERS + ul);
-    LdsListPtr Ll = (LdsListPtr)Lg;
-    float ws = neg_inf_f(); int widx = IDX_EMPTY, wpos = 0;
-    if (h == 0) for (int i = 0; i < K; i++) { if (LLDS) Ll[i * GROUP_USERS] = ListRaw<float>::pack(neg_inf_f(), IDX_EMPTY); else Lg[i * GROUP_USERS] = ListRaw<float>::pack(neg_inf_f(), IDX_EMPTY); }
+    // top-K list of this wave, owned by the lanes with h == 0.  LDS: [K][32 users], unsorted, replace-the-minimum.
+    // HBM (lists that do not fit LDS): per user an append buffer of 2K + 32 entries + wave-cooperative compaction.
+    const int CAP = 2 * K + 32;
+    LdsListPtr Ll = (LdsListPtr)((GblListPtr)lists_lds + wave * K * GROUP_USERS + ul);
+    GblListPtr Gw = LLDS ? nullptr : a.glists + ((size_t)blockIdx.x * 8 + wave) * GROUP_USERS * CAP;    // wave's 32 buffers
+    GblListPtr Gu = LLDS ? nullptr : Gw + (size_t)ul * CAP;                                                // this user's
+    // small K in HBM: [K][32 users] replace-the-minimum like the LDS list (cheaper than compactions below K ~ 32)
+    const bool buffered = a.buffered_lists != 0;
+    GblListPtr Lr = LLDS ? nullptr : a.glists + ((size_t)blockIdx.x * 8 + wave) * GROUP_USERS * CAP + ul;
+    float ws = neg_inf_f(); int widx = IDX_EMPTY, wpos = 0, cnt = 0;
+    if (h == 0 && (LLDS || !buffered)) for (int i = 0; i < K; i++) {
+        if (LLDS) Ll[i * GROUP_USERS] = ListRaw<float>::pack(neg_inf_f(), IDX_EMPTY); else Lr[i * GROUP_USERS] = ListRaw<float>::pack(neg_inf_f(), IDX_EMPTY);
+    }
+    // compaction of every owner lane in `need` (wave-uniform mask): K best kept, sorted; (ws, widx) = the K-th
+    auto compact_users = [&](unsigned long long need) {
+        while (need) {
+            const int l = __ffsll((long long)need) - 1;
+            need &= need - 1;
+            const int c = lane_bcast<int>(cnt, l);
+            float ks; int ki;
+            wave_compact<float>(Gw + (size_t)l * CAP, c, K, lane, ks, ki);
+            if (lane == l) { cnt = c < K ? c : K; if (c >= K) { ws = ks; widx = ki; } }
+        }
+    };
 
     // positives -> LDS, histogram zeroed
     if (AUC) {
@@ -251,11 +269,14 @@ void k_sweep(SweepArgs a)
                         const int item0 = sb + mfma32_row(r, 0), item1 = sb + mfma32_row(r, 1);
                         if (LLDS) { if (v[r] >= ws) list_offer<float, GROUP_USERS>(Ll, K, v[r], item0, ws, widx, wpos);
                                     if (other >= ws) list_offer<float, GROUP_USERS>(Ll, K, other, item1, ws, widx, wpos); }
-                        else      { if (v[r] >= ws) list_offer<float, GROUP_USERS>(Lg, K, v[r], item0, ws, widx, wpos);
-                                    if (other >= ws) list_offer<float, GROUP_USERS>(Lg, K, other, item1, ws, widx, wpos); }
+                        else if (buffered) { if (v[r] > ws || (v[r] == ws && item0 < widx)) Gu[cnt++] = ListRaw<float>::pack(v[r], item0);
+                                             if (other > ws || (other == ws && item1 < widx)) Gu[cnt++] = ListRaw<float>::pack(other, item1); }
+                        else      { if (v[r] >= ws) list_offer<float, GROUP_USERS>(Lr, K, v[r], item0, ws, widx, wpos);
+                                    if (other >= ws) list_offer<float, GROUP_USERS>(Lr, K, other, item1, ws, widx, wpos); }
                     }
                 }
             }
+            if (!LLDS && buffered) compact_users(__ballot(h == 0 && primary && cnt > 2 * K));
             const float t2 = __shfl(ws, ul);
             if (primary) {
                 thr = t2 > thr ? t2 : thr;
@@ -319,7 +340,22 @@ void k_sweep(SweepArgs a)
             a.pst[(size_t)slot * n_part + part] = ps;
             ListEntry *dst = a.pl + ((size_t)slot * n_part + part) * K;
             if (LLDS) { list_sort_desc<float, GROUP_USERS>(Ll, K); for (int i = 0; i < K; i++) ListRaw<float>::unpack(Ll[i * GROUP_USERS], dst[i].s, dst[i].idx); }
-            else      { list_sort_desc<float, GROUP_USERS>(Lg, K); for (int i = 0; i < K; i++) ListRaw<float>::unpack(Lg[i * GROUP_USERS], dst[i].s, dst[i].idx); }
+        }
+    }
+    if (!LLDS && !buffered) {
+        if (slot_ok && h == 0) {
+            ListEntry *dst = a.pl + ((size_t)slot * n_part + part) * K;
+            list_sort_desc<float, GROUP_USERS>(Lr, K);
+            for (int i = 0; i < K; i++) ListRaw<float>::unpack(Lr[i * GROUP_USERS], dst[i].s, dst[i].idx);
+        }
+    } else if (!LLDS) {
+        compact_users(__ballot(slot_ok && h == 0 && primary && cnt > 0));
+        if (slot_ok && h == 0) {
+            ListEntry *dst = a.pl + ((size_t)slot * n_part + part) * K;
+            for (int i = 0; i < K; i++) {
+                if (i < cnt) ListRaw<float>::unpack(ListRaw<float>::load_l2(Gu + i), dst[i].s, dst[i].idx);
+                else { dst[i].s = neg_inf_f(); dst[i].idx = IDX_EMPTY; }
+            }
         }
     }
     if (AUC) {

@@ -133,12 +133,28 @@ void k_sweep64(Sweep64Args a)
         }
     }
 
-    GblList64Ptr Lg = LLDS ? (lists_lds + wave * K * GU + ul) : (a.glists + ((size_t)blockIdx.x * 8 + wave) * K * GU + ul);
-    LdsList64Ptr Ll = (LdsList64Ptr)Lg;
-    double ws = neg_inf_d(); int widx = IDX_EMPTY, wpos = 0;
-    if (q == 0) for (int i = 0; i < K; i++) {
-        if (LLDS) Ll[i * GU] = ListRaw<double>::pack(neg_inf_d(), IDX_EMPTY); else Lg[i * GU] = ListRaw<double>::pack(neg_inf_d(), IDX_EMPTY);
+    // top-K list owned by the q == 0 lane of the user: LDS [K][16 users] replace-the-minimum, or HBM append buffer +
+    // wave-cooperative compaction when the lists do not fit LDS (rm_list.hpp)
+    const int CAP = 2 * K + 32;
+    LdsList64Ptr Ll = (LdsList64Ptr)((GblList64Ptr)lists_lds + wave * K * GU + ul);
+    GblList64Ptr Gw = LLDS ? nullptr : a.glists + ((size_t)blockIdx.x * 8 + wave) * GU * CAP;
+    GblList64Ptr Gu = LLDS ? nullptr : Gw + (size_t)ul * CAP;
+    const bool buffered = a.buffered_lists != 0;
+    GblList64Ptr Lr = LLDS ? nullptr : a.glists + ((size_t)blockIdx.x * 8 + wave) * GU * CAP + ul;
+    double ws = neg_inf_d(); int widx = IDX_EMPTY, wpos = 0, cnt = 0;
+    if (q == 0 && (LLDS || !buffered)) for (int i = 0; i < K; i++) {
+        if (LLDS) Ll[i * GU] = ListRaw<double>::pack(neg_inf_d(), IDX_EMPTY); else Lr[i * GU] = ListRaw<double>::pack(neg_inf_d(), IDX_EMPTY);
     }
+    auto compact_users = [&](unsigned long long need) {
+        while (need) {
+            const int l = __ffsll((long long)need) - 1;
+            need &= need - 1;
+            const int c = lane_bcast<int>(cnt, l);
+            double ks; int ki;
+            wave_compact<double>(Gw + (size_t)l * CAP, c, K, lane, ks, ki);
+            if (lane == l) { cnt = c < K ? c : K; if (c >= K) { ws = ks; widx = ki; } }
+        }
+    };
 
     if (AUC) {
         for (int i = tid; i < GROUPS_PER_BLOCK * (PLb + 1) * GU; i += SWEEP_THREADS) {
@@ -213,15 +229,21 @@ void k_sweep64(Sweep64Args a)
                             if (o1 >= ws) list_offer<double, GU>(Ll, K, o1, ib + 1, ws, widx, wpos);
                             if (o2 >= ws) list_offer<double, GU>(Ll, K, o2, ib + 2, ws, widx, wpos);
                             if (o3 >= ws) list_offer<double, GU>(Ll, K, o3, ib + 3, ws, widx, wpos);
+                        } else if (buffered) {
+                            if (v[r] > ws || (v[r] == ws && ib < widx)) Gu[cnt++] = ListRaw<double>::pack(v[r], ib);
+                            if (o1 > ws || (o1 == ws && ib + 1 < widx)) Gu[cnt++] = ListRaw<double>::pack(o1, ib + 1);
+                            if (o2 > ws || (o2 == ws && ib + 2 < widx)) Gu[cnt++] = ListRaw<double>::pack(o2, ib + 2);
+                            if (o3 > ws || (o3 == ws && ib + 3 < widx)) Gu[cnt++] = ListRaw<double>::pack(o3, ib + 3);
                         } else {
-                            if (v[r] >= ws) list_offer<double, GU>(Lg, K, v[r], ib, ws, widx, wpos);
-                            if (o1 >= ws) list_offer<double, GU>(Lg, K, o1, ib + 1, ws, widx, wpos);
-                            if (o2 >= ws) list_offer<double, GU>(Lg, K, o2, ib + 2, ws, widx, wpos);
-                            if (o3 >= ws) list_offer<double, GU>(Lg, K, o3, ib + 3, ws, widx, wpos);
+                            if (v[r] >= ws) list_offer<double, GU>(Lr, K, v[r], ib, ws, widx, wpos);
+                            if (o1 >= ws) list_offer<double, GU>(Lr, K, o1, ib + 1, ws, widx, wpos);
+                            if (o2 >= ws) list_offer<double, GU>(Lr, K, o2, ib + 2, ws, widx, wpos);
+                            if (o3 >= ws) list_offer<double, GU>(Lr, K, o3, ib + 3, ws, widx, wpos);
                         }
                     }
                 }
             }
+            if (!LLDS && buffered) compact_users(__ballot(q == 0 && primary && cnt > 2 * K));
             const double t2 = __shfl(ws, ul);
             if (primary) {
                 thr = t2 > thr ? t2 : thr;
@@ -300,7 +322,22 @@ void k_sweep64(Sweep64Args a)
             a.pst[(size_t)slot * n_part + part] = ps;
             Entry<double> *dst = a.pl + ((size_t)slot * n_part + part) * K;
             if (LLDS) { list_sort_desc<double, GU>(Ll, K); for (int i = 0; i < K; i++) ListRaw<double>::unpack(Ll[i * GU], dst[i].s, dst[i].idx); }
-            else      { list_sort_desc<double, GU>(Lg, K); for (int i = 0; i < K; i++) ListRaw<double>::unpack(Lg[i * GU], dst[i].s, dst[i].idx); }
+        }
+    }
+    if (!LLDS && !buffered) {
+        if (slot_ok && q == 0) {
+            Entry<double> *dst = a.pl + ((size_t)slot * n_part + part) * K;
+            list_sort_desc<double, GU>(Lr, K);
+            for (int i = 0; i < K; i++) ListRaw<double>::unpack(Lr[i * GU], dst[i].s, dst[i].idx);
+        }
+    } else if (!LLDS) {
+        compact_users(__ballot(slot_ok && q == 0 && primary && cnt > 0));
+        if (slot_ok && q == 0) {
+            Entry<double> *dst = a.pl + ((size_t)slot * n_part + part) * K;
+            for (int i = 0; i < K; i++) {
+                if (i < cnt) ListRaw<double>::unpack(ListRaw<double>::load_l2(Gu + i), dst[i].s, dst[i].idx);
+                else { dst[i].s = neg_inf_d(); dst[i].idx = IDX_EMPTY; }
+            }
         }
     }
     if (AUC) {

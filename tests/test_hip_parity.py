@@ -119,6 +119,8 @@ def _check_against_oracle(hip, oracle, pr, k, dtype=np.float32, **kw):
     (257, 1111, 50, 5, 30),        # ragged: users % 32, items % 64, factors % 8 all non-zero
     (64, 40000, 128, 10, 100),     # few users, long item axis: item splits + merge of partial lists
     (500, 3000, 16, 40, 60),       # larger K (top-K lists out of LDS)
+    (200, 50000, 128, 100, 10),    # BASELINE config C4's factor count and K: HBM append buffers + wave compaction
+    (300, 9000, 100, 256, 30),     # largest supported K for HBM lists
 ])
 def test_random_problem_vs_oracle(hip, oracle, m, n, k, K, mean_c):
     from recometrics_amd.synth import make_problem
