@@ -116,9 +116,9 @@ template <class T> struct Prec;
 template <> struct Prec<float> {
     static constexpr int GU = GROUP_USERS;               // users per group
     typedef float4 PackT;  typedef u32x2 ListT;  typedef SweepArgs Args;
-    static int supported_ng(int k) { const int ng = (k + 7) / 8; for (int o : {2, 4, 8, 16}) if (ng <= o) return o; return -1; }
-    static const char *limit() { return "the fp32 path supports up to 128 factors"; }
-    static size_t lds_b(int NG) { return 2ull * NG * 2 * TILE_ITEMS * 16; }
+    static int supported_ng(int k) { const int ng = (k + 7) / 8; for (int o : {2, 4, 8, 16, 32, 64}) if (ng <= o) return o; return -1; }
+    static const char *limit() { return "the fp32 path supports up to 512 factors"; }
+    static size_t lds_b(int NG) { return 2ull * std::min(NG, 16) * 2 * TILE_ITEMS * 16; }
     static long long items_units(int tiles, int NG) { return (long long)tiles * NG * 2 * TILE_ITEMS; }
     static long long users_units(int groups, int NG) { return (long long)groups * NG * 2 * GU; }
 };

@@ -75,10 +75,16 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], const char *posb,
     }
 }
 
-template <int NG, bool AUC, bool DUMP, bool LLDS>
+template <int NGT, bool AUC, bool DUMP, bool LLDS>
 __global__ __launch_bounds__(SWEEP_THREADS, 2)
 void k_sweep(SweepArgs a)
 {
+    // factor axis: NGT groups of 8 factors; up to 128 factors (NGT <= 16) a tile is one LDS image and the user factors
+    // stay in registers for the whole sweep; beyond that the axis is streamed in chunks of 128 factors (one barrier
+    // per chunk) and each chunk of user factors is re-read from L2 when its turn comes.
+    constexpr int NG = NGT < 16 ? NGT : 16;                    // groups per LDS chunk
+    constexpr int NC = NGT / NG;                                // chunks per tile
+    constexpr bool AF_RESIDENT = NC == 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BUF_F4 = NG * 2 * TILE_ITEMS;                 // float4 per packed tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -130,9 +136,12 @@ void k_sweep(SweepArgs a)
 
     // user factors -> registers (packed: [group][g][h][32][4 floats])
     float4 af[NG];
-    #pragma unroll
-    for (int g = 0; g < NG; g++)
-        af[g] = group_ok ? a.Ap[((size_t)(group * NG + g) * 2 + h) * GROUP_USERS + ul] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 *af_src = a.Ap + ((size_t)(group_ok ? group : 0) * NGT * 2 + h) * GROUP_USERS + ul;      // + g * 2 * GROUP_USERS
+    if (AF_RESIDENT) {
+        #pragma unroll
+        for (int g = 0; g < NG; g++)
+            af[g] = group_ok ? af_src[(size_t)g * 2 * GROUP_USERS] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 
     // top-K list of this wave, owned by the lanes with h == 0.  LDS: [K][32 users], unsorted, replace-the-minimum.
     // HBM (lists that do not fit LDS): per user an append buffer of 2K + 32 entries + wave-cooperative compaction.
@@ -175,8 +184,8 @@ void k_sweep(SweepArgs a)
     // ---- staging: packed tile (BUF_F4 float4, contiguous) HBM -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging
     // registers, the wave never waits for the bytes before the end-of-step barrier.  One wave-instruction moves 1 KiB
     // (64 lanes x 16 B) to a lane-linear LDS image, which is exactly how the packed tile is laid out. ----
-    auto stage = [&](int tile, int buf) {
-        const float4 *src = a.Bp + (size_t)tile * BUF_F4;
+    auto stage = [&](int unit, int buf) {                     // unit = tile * NC + chunk: contiguous in the packed image
+        const float4 *src = a.Bp + (size_t)unit * BUF_F4;
         float4 *dst = ldsB + buf * BUF_F4;
         for (int pc = wave; pc < NG * 2; pc += 8)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + pc * 64 + lane),
@@ -184,10 +193,16 @@ void k_sweep(SweepArgs a)
     };
 
     // ---- MFMA: 32 items (registers) x 32 users (lanes), k in index order ----
-    auto do_mfma = [&](f32x16 &acc, int buf) {
+    auto do_mfma = [&](f32x16 &acc, int buf, int chunk) {
         const float4 *bb = ldsB + buf * BUF_F4 + h * TILE_ITEMS + sub * 32 + ul;
-        #pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        if (!AF_RESIDENT) {
+            #pragma unroll
+            for (int g = 0; g < NG; g++) af[g] = af_src[(size_t)(chunk * NG + g) * 2 * GROUP_USERS];
+        }
+        if (chunk == 0) {
+            #pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        }
         #pragma unroll
         for (int g = 0; g < NG; g++) {
             const float4 b = bb[g * 2 * TILE_ITEMS];
@@ -308,20 +323,24 @@ void k_sweep(SweepArgs a)
     // VALU/LDS work of the SIMD partner wave do NOT overlap (time = sum, the f32 MFMA runs on the vector ALUs), so the
     // two waves of a SIMD run in phase: both chains back to back, then both epilogues sharing the VALU at full rate. ----
     f32x16 acc;
-    if (ntiles > 0) stage(t0, 0);
+    const int nunits = ntiles * NC;
+    if (ntiles > 0) stage(t0 * NC, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int i = 0; i < ntiles; i++) {
-        if (i + 1 < ntiles) stage(t0 + i + 1, (i + 1) & 1);       // buffer (i+1)&1 was last read in step i-1
         const unsigned thr_seen = (primary && !DUMP) ? __hip_atomic_load(a.thr_shared + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        for (int c = 0; c < NC; c++) {
+            const int unit = i * NC + c;
+            if (unit + 1 < nunits) stage(t0 * NC + unit + 1, (unit + 1) & 1);   // that buffer was last read one step ago
 #ifndef RM_ABL_NO_MFMA
-        do_mfma(acc, i & 1);
+            do_mfma(acc, unit & 1, c);
 #endif
 #ifndef RM_ABL_NO_EPI
-        do_epi(acc, t0 + i, thr_seen);
+            if (c == NC - 1) do_epi(acc, t0 + i, thr_seen);
 #endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the DMA of tile i+1 has landed
-        __syncthreads();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the DMA of the next unit has landed
+            __syncthreads();
+        }
     }
     if (DUMP) return;
 

@@ -36,7 +36,7 @@ def hip_calc(hip, A, B, train, test, k, metrics=("p", "tp", "r", "ap", "tap", "n
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("k", [1, 8, 24, 50, 64, 100, 128])
+@pytest.mark.parametrize("k", [1, 8, 24, 50, 64, 100, 128, 129, 200, 256, 300, 512])
 def test_mfma_scores_are_the_k_ordered_fma_chain(hip, oracle, k):
     """The sweep's v_mfma_f32_32x32x2_f32 contraction == strict index-order fmaf chain (reference dot1), bit for bit."""
     rng = np.random.default_rng(k)
@@ -121,6 +121,8 @@ def _check_against_oracle(hip, oracle, pr, k, dtype=np.float32, **kw):
     (500, 3000, 16, 40, 60),       # larger K (top-K lists out of LDS)
     (200, 50000, 128, 100, 10),    # BASELINE config C4's factor count and K: HBM append buffers + wave compaction
     (300, 9000, 100, 256, 30),     # largest supported K for HBM lists
+    (150, 4000, 200, 10, 40),      # > 128 factors: the factor axis is streamed in chunks of 128
+    (90, 3000, 500, 5, 30),
 ])
 def test_random_problem_vs_oracle(hip, oracle, m, n, k, K, mean_c):
     from recometrics_amd.synth import make_problem
