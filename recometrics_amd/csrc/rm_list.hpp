@@ -116,6 +116,51 @@ __device__ __forceinline__ void list_sort_desc(P L, int K)
     }
 }
 
+// ---- fp32 LDS lists as packed 64-bit keys: (order-preserving score key << 32) | ~item.  "Better" in the total order
+// (score desc, item asc) is simply "larger key", so the worst-entry scan is one 64-bit compare + selects per entry. ----
+__device__ __forceinline__ unsigned long long pack_key(float s, int item)
+{
+    return ((unsigned long long)ord_key(s) << 32) | (unsigned)(~item);
+}
+__device__ __forceinline__ void unpack_key(unsigned long long k, float &s, int &item)
+{
+    if ((k >> 32) == 0) { s = __int_as_float(0xff800000); item = IDX_EMPTY; }      // never written
+    else { s = ord_unkey((unsigned)(k >> 32)); item = ~(int)(unsigned)k; }
+}
+template <int GU, class P>
+__device__ __forceinline__ void keylist_find_worst(P L, int K, unsigned long long &wkey, int &wpos)
+{
+    wkey = L[0]; wpos = 0;
+    for (int i = 1; i < K; i++) {
+        const unsigned long long k = L[i * GU];
+        const bool worse = k < wkey;
+        wkey = worse ? k : wkey; wpos = worse ? i : wpos;
+    }
+}
+template <int GU, class P>
+__device__ __forceinline__ void keylist_offer(P L, int K, unsigned long long ck, unsigned long long &wkey, int &wpos)
+{
+    if (ck > wkey) {
+        L[wpos * GU] = ck;
+        keylist_find_worst<GU>(L, K, wkey, wpos);
+    }
+}
+template <int GU, class P>
+__device__ __forceinline__ void keylist_sort_desc(P L, int K)
+{
+    for (int i = 1; i < K; i++) {
+        const unsigned long long e = L[i * GU];
+        int j = i;
+        while (j > 0) {
+            const unsigned long long q = L[(j - 1) * GU];
+            if (q > e) break;
+            L[j * GU] = q;
+            j--;
+        }
+        L[j * GU] = e;
+    }
+}
+
 // ---- large K: append buffer + wave-cooperative compaction (lists that do not fit LDS live in HBM) -----------------------
 // A user's buffer holds up to CAP = 2K + 32 raw entries, user-major (contiguous) in HBM.  The owner lane appends every
 // candidate that passes its threshold (one store); when more than 2K have accumulated, the whole wave selects the K best:

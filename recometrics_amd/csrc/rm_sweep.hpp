@@ -25,7 +25,7 @@ namespace rm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 
-typedef __attribute__((address_space(3))) u32x2 *LdsListPtr;
+typedef __attribute__((address_space(3))) unsigned long long *LdsListPtr;
 typedef u32x2 *GblListPtr;
 
 // AUC rank counting for one tile: branchless lower_bound of every score in the lane's user's sorted positives
@@ -146,7 +146,8 @@ void k_sweep(SweepArgs a)
     // top-K list of this wave, owned by the lanes with h == 0.  LDS: [K][32 users], unsorted, replace-the-minimum.
     // HBM (lists that do not fit LDS): per user an append buffer of 2K + 32 entries + wave-cooperative compaction.
     const int CAP = 2 * K + 32;
-    LdsListPtr Ll = (LdsListPtr)((GblListPtr)lists_lds + wave * K * GROUP_USERS + ul);
+    LdsListPtr Ll = (LdsListPtr)((unsigned long long *)lists_lds + wave * K * GROUP_USERS + ul);
+    unsigned long long wkey = 0;                                   // LDS list: key of its worst entry (0 = empty slot)
     GblListPtr Gw = LLDS ? nullptr : a.glists + ((size_t)blockIdx.x * 8 + wave) * GROUP_USERS * CAP;    // wave's 32 buffers
     GblListPtr Gu = LLDS ? nullptr : Gw + (size_t)ul * CAP;                                                // this user's
     // small K in HBM: [K][32 users] replace-the-minimum like the LDS list (cheaper than compactions below K ~ 32)
@@ -154,7 +155,7 @@ void k_sweep(SweepArgs a)
     GblListPtr Lr = LLDS ? nullptr : a.glists + ((size_t)blockIdx.x * 8 + wave) * GROUP_USERS * CAP + ul;
     float ws = neg_inf_f(); int widx = IDX_EMPTY, wpos = 0, cnt = 0;
     if (h == 0 && (LLDS || !buffered)) for (int i = 0; i < K; i++) {
-        if (LLDS) Ll[i * GROUP_USERS] = ListRaw<float>::pack(neg_inf_f(), IDX_EMPTY); else Lr[i * GROUP_USERS] = ListRaw<float>::pack(neg_inf_f(), IDX_EMPTY);
+        if (LLDS) Ll[i * GROUP_USERS] = 0ull; else Lr[i * GROUP_USERS] = ListRaw<float>::pack(neg_inf_f(), IDX_EMPTY);
     }
     // compaction of every owner lane in `need` (wave-uniform mask): K best kept, sorted; (ws, widx) = the K-th
     auto compact_users = [&](unsigned long long need) {
@@ -278,12 +279,15 @@ void k_sweep(SweepArgs a)
         if (cm) {
             #pragma unroll
             for (int r = 0; r < 16; r++) {
-                if (__any(v[r] >= thr)) {
-                    const float other = __shfl_xor(v[r], 32);
+                const unsigned long long hitm = __ballot(v[r] >= thr);
+                if (hitm) {
+                    // the partner's score is only fetched when a lane of the upper half has a candidate
+                    const float other = (hitm >> 32) ? __shfl_xor(v[r], 32) : nan_sentinel_f();
                     if (h == 0 && primary) {
                         const int item0 = sb + mfma32_row(r, 0), item1 = sb + mfma32_row(r, 1);
-                        if (LLDS) { if (v[r] >= ws) list_offer<float, GROUP_USERS>(Ll, K, v[r], item0, ws, widx, wpos);
-                                    if (other >= ws) list_offer<float, GROUP_USERS>(Ll, K, other, item1, ws, widx, wpos); }
+                        if (LLDS) { if (v[r] >= ws) keylist_offer<GROUP_USERS>(Ll, K, pack_key(v[r], item0), wkey, wpos);
+                                    if (other >= ws) keylist_offer<GROUP_USERS>(Ll, K, pack_key(other, item1), wkey, wpos);
+                                    ws = (wkey >> 32) ? ord_unkey((unsigned)(wkey >> 32)) : neg_inf_f(); }
                         else if (buffered) { if (v[r] > ws || (v[r] == ws && item0 < widx)) Gu[cnt++] = ListRaw<float>::pack(v[r], item0);
                                              if (other > ws || (other == ws && item1 < widx)) Gu[cnt++] = ListRaw<float>::pack(other, item1); }
                         else      { if (v[r] >= ws) list_offer<float, GROUP_USERS>(Lr, K, v[r], item0, ws, widx, wpos);
@@ -358,7 +362,7 @@ void k_sweep(SweepArgs a)
             ps.vmax = vmax; ps.vmin = vmin; ps.rocsum = roc64; ps.has_nan = hn ? 1 : 0; ps.pad = 0;
             a.pst[(size_t)slot * n_part + part] = ps;
             ListEntry *dst = a.pl + ((size_t)slot * n_part + part) * K;
-            if (LLDS) { list_sort_desc<float, GROUP_USERS>(Ll, K); for (int i = 0; i < K; i++) ListRaw<float>::unpack(Ll[i * GROUP_USERS], dst[i].s, dst[i].idx); }
+            if (LLDS) { keylist_sort_desc<GROUP_USERS>(Ll, K); for (int i = 0; i < K; i++) unpack_key(Ll[i * GROUP_USERS], dst[i].s, dst[i].idx); }
         }
     }
     if (!LLDS && !buffered) {
