@@ -245,11 +245,13 @@ void k_sweep(SweepArgs a)
                 nt2 = ntc + 1 < nte ? a.train_i[ntc + 1] : IDX_EMPTY;   // the HBM latency never sits in front of the barrier
             }
             if (sb + 32 > n) mbits |= (n > sb) ? (0xffffffffu << (n - sb)) : 0xffffffffu;
+            // the sentinel is all ones: OR-ing the sign-extended mask bit into the score masks it (2 VALU per register)
+            const int mb = (int)(mbits >> (4 * h));
             #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const bool mk = (mbits >> mfma32_row(r, h)) & 1u;
+                const int mk = __builtin_amdgcn_sbfe(mb, (r & 3) + 8 * (r >> 2), 1);          // 0 or -1
                 if (a.check_nan) nanmask |= __ballot(!mk && (v[r] != v[r]));
-                v[r] = mk ? nan_sentinel_f() : v[r];
+                v[r] = __int_as_float(__float_as_int(v[r]) | mk);
             }
         } else if (a.check_nan) {
             #pragma unroll
