@@ -16,6 +16,9 @@ CONFIGS = {
     "C4": (100_000, 10_000_000, 128, np.float32, 100, 10, 104),
     "C5": (200_000, 500_000, 256, np.float64, 50, 50, 105),
     "NS": (32_768, 1_000_000, 128, np.float32, 10, 100, 100),
+    # probes (not BASELINE configs): fp64 with resident user factors / small K
+    "P64a": (8_192, 500_000, 128, np.float64, 10, 50, 106),
+    "P64b": (8_192, 500_000, 256, np.float64, 10, 50, 107),
 }
 
 

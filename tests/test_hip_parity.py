@@ -202,6 +202,14 @@ def test_python_api_drop_in(hip, oracle):
         calc_reco_metrics(Xtr, Xte, pr["A"], pr["B"], k=n + 1)
 
 
+def test_north_star_shape_vs_oracle(hip, oracle):
+    """n = 1M items x 128 factors (the north-star shape), 192 users: item splits + shared thresholds + exact ties at
+    scale (fp32 scores collide with positives' scores ~0.5 times per user here)."""
+    from recometrics_amd.synth import make_problem
+    pr = make_problem(192, 1_000_000, 128, np.float32, mean_c=100, seed=100)
+    _check_against_oracle(hip, oracle, pr, 10)
+
+
 def test_full_size_properties(hip):
     """BASELINE-scale shape (C2-like slice): size-independent properties instead of an oracle run"""
     from recometrics_amd.synth import make_problem
