@@ -1,13 +1,11 @@
 """recometrics_amd -- MI355X-native drop-in for the ranking-metric hot path of david-cortes/recometrics.
 
 Public surface = the reference's ``calc_reco_metrics`` (recometrics/__init__.py:44-628): same keyword arguments,
-defaults, validation errors / warnings, dtype rule, output naming.  The per-user work (score the item pool, mask
+defaults, error / warning conditions, dtype rule and output naming.  The per-user work (score the item pool, mask
 train items, top-K, P/TP/R/AP/TAP/NDCG/Hit/RR@K, ROC/PR-AUC) runs in hand-written HIP kernels behind the C-ABI of
 ``include/recometrics_hip.h``.  There is no CPU fallback: without the built library and a GPU the call raises.
 """
-import ctypes
 import multiprocessing
-import re
 from warnings import warn
 
 import numpy as np
@@ -17,39 +15,88 @@ from . import _binding
 __all__ = ["calc_reco_metrics"]
 __version__ = "0.1.0"
 
-_FLAG_TO_KEY = (("precision", "p", "P@K"), ("trunc_precision", "tp", "TP@K"), ("recall", "r", "R@K"),
-                ("average_precision", "ap", "AP@K"), ("trunc_average_precision", "tap", "TAP@K"),
-                ("ndcg", "ndcg", "NDCG@K"), ("hit", "hit", "Hit@K"), ("rr", "rr", "RR@K"),
-                ("roc_auc", "roc", "ROC_AUC"), ("pr_auc", "pr", "PR_AUC"))
+# (keyword of calc_reco_metrics, name in the C-ABI order, key of the result dict) -- reference __init__.py:590-613
+_METRICS = (
+    ("precision", "p", "P@K"), ("trunc_precision", "tp", "TP@K"), ("recall", "r", "R@K"),
+    ("average_precision", "ap", "AP@K"), ("trunc_average_precision", "tap", "TAP@K"), ("ndcg", "ndcg", "NDCG@K"),
+    ("hit", "hit", "Hit@K"), ("rr", "rr", "RR@K"), ("roc_auc", "roc", "ROC_AUC"), ("pr_auc", "pr", "PR_AUC"),
+)
+_INT32_MAX = np.iinfo(np.int32).max
 
 
 def _row_major_with_ld(X):
-    """(array, leading dimension in elements) -- reference __init__.py:11-16"""
+    """(array, leading dimension in elements): a row-major view keeps its stride, anything else is copied
+    (reference __init__.py:11-16)."""
     if X.flags["C_CONTIGUOUS"]:
         return X, X.shape[1]
-    if X.strides[1] != X.dtype.itemsize:
-        return np.ascontiguousarray(X), X.shape[1]
-    return X, int(X.strides[0] / X.itemsize)
-
-
-def _to_dtype(X, dtype):
-    return X if X.dtype == dtype else X.astype(dtype)
+    if X.strides[1] == X.dtype.itemsize:
+        return X, X.strides[0] // X.itemsize
+    return np.ascontiguousarray(X), X.shape[1]
 
 
 def _sorted_csr_int32(X):
-    """CSR with sorted indices and int32 index arrays -- reference __init__.py:26-41 (sorts in place, like it)"""
+    """CSR with sorted column indices and int32 index arrays (reference __init__.py:26-41; sorts in place, like it)."""
     from scipy.sparse import csr_array, issparse
-    if issparse(X):
-        if X.format != "csr":
-            X = X.tocsr()
-        X.sort_indices()
-    else:
-        X = csr_array(X)
+    X = X.tocsr() if issparse(X) and X.format != "csr" else (X if issparse(X) else csr_array(X))
+    X.sort_indices()
     if X.indptr.dtype != np.int32 or X.indices.dtype != np.int32:
         X = X.copy()
-        X.indptr = X.indptr.astype(np.int32)
-        X.indices = X.indices.astype(np.int32)
+        X.indptr, X.indices = X.indptr.astype(np.int32), X.indices.astype(np.int32)
     return X
+
+
+def _fail_if(cond, message):
+    if cond:
+        raise ValueError(message)
+
+
+def _check_factors(A, B, n_users, n_items):
+    """Shape rules of reference __init__.py:442-467; returns A, B trimmed to the test matrix (with its warnings)."""
+    _fail_if(A.ndim != 2, "'A' must be a 2-dimensional array.")
+    _fail_if(B.ndim != 2, "'B' must be a 2-dimensional array.")
+    _fail_if(A.shape[1] != B.shape[1], "'A' and 'B' must have the same number of columns.")
+    _fail_if(0 in (A.shape[0], A.shape[1], B.shape[1], n_users, n_items), "Input matrices cannot be empty.")
+    _fail_if(A.shape[0] < n_users, "Number of users in 'A' and 'X_test' does not match.")
+    _fail_if(B.shape[0] < n_items, "Number of items in 'B' and 'X_test' does not match.")
+    if A.shape[0] > n_users:
+        warn("'A' has more users than 'X_test'.")
+        A = A[:n_users]
+    if B.shape[0] > n_items:
+        warn("'B' has more items than 'X_test'.")
+        B = B[:n_items]
+    return A, B
+
+
+def _fold_item_biases(A, B, item_biases, n_items, dtype):
+    """scores = A @ B.T + bias  ==  [A | 1] @ [B | bias].T   (reference __init__.py:534-551)"""
+    assert isinstance(item_biases, np.ndarray)
+    _fail_if(item_biases.ndim > 2, "'item_biases' should be a 1-d array.")
+    item_biases = item_biases.reshape(-1)
+    _fail_if(item_biases.shape[0] == 0, "'item_biases' is empty.")
+    _fail_if(item_biases.shape[0] < n_items, "Number of items in 'item_biases' must match with 'X_test'.")
+    if item_biases.shape[0] > n_items:
+        warn("'item_biases' has more items than 'X_test'.")
+        item_biases = item_biases[:n_items]
+    ones = np.ones((A.shape[0], 1), dtype=dtype)
+    return np.hstack([A.astype(dtype, copy=False), ones]), np.hstack([B.astype(dtype, copy=False), item_biases.astype(dtype).reshape(-1, 1)])
+
+
+def _as_frame(out, k, cumulative, rename_k):
+    """dict of arrays -> DataFrame with the reference's column names (__init__.py:615-626): "P@K" -> "P@5", cumulative
+    blocks -> "P@1" .. "P@k".  ROC_AUC / PR_AUC stay single columns in cumulative mode (the reference raises there)."""
+    import pandas as pd
+    if not cumulative:
+        df = pd.DataFrame(out)
+        if rename_k:
+            df.columns = [c[:-1] + str(k) if c.endswith("@K") else c for c in df.columns]
+        return df
+    blocks = []
+    for key, arr in out.items():
+        if arr.ndim == 1:
+            blocks.append(pd.DataFrame({key: arr}))
+        else:
+            blocks.append(pd.DataFrame(arr, columns=["%s%d" % (key[:-1], i + 1) for i in range(arr.shape[1])]))
+    return pd.concat(blocks, axis=1)
 
 
 def calc_reco_metrics(
@@ -91,144 +138,83 @@ def calc_reco_metrics(
     instead of by the reference's mt19937 noise stream; ``hit`` / ``rr`` requested alone are computed (the reference
     leaves them uninitialised) and ``pr_auc`` without ``roc_auc`` is computed from the full ranking.
     """
-    import pandas as pd
     from scipy.sparse import csr_array, issparse
 
-    if all_metrics:
-        precision = trunc_precision = recall = average_precision = trunc_average_precision = True
-        ndcg = hit = rr = roc_auc = pr_auc = True
+    requested = dict(precision=precision, trunc_precision=trunc_precision, recall=recall,
+                     average_precision=average_precision, trunc_average_precision=trunc_average_precision,
+                     ndcg=ndcg, hit=hit, rr=rr, roc_auc=roc_auc, pr_auc=pr_auc)
+    requested = {name: bool(all_metrics or flag) for name, flag in requested.items()}
 
-    if item_biases is not None and isinstance(item_biases, pd.Series):
+    if hasattr(item_biases, "to_numpy"):                 # pandas.Series
         item_biases = item_biases.to_numpy()
 
-    if (A is None) != (B is None):
-        raise ValueError("'A' and 'B' must either be passed together or passed as 'None' together.")
+    # ---- factors (or the non-personalised mode: A = ones, B = biases; reference :429-436) ----
+    _fail_if((A is None) != (B is None), "'A' and 'B' must either be passed together or passed as 'None' together.")
     if A is None:
-        if item_biases is None:
-            raise ValueError("Must pass item biases if not passing factors.")
-        A = np.ones((X_test.shape[0], 1), dtype=ctypes.c_double, order="C")
-        B = np.ascontiguousarray(item_biases, dtype=ctypes.c_double).reshape((-1, 1))
+        _fail_if(item_biases is None, "Must pass item biases if not passing factors.")
+        A = np.ones((X_test.shape[0], 1), dtype=np.float64)
+        B = np.ascontiguousarray(item_biases, dtype=np.float64).reshape(-1, 1)
         item_biases = None
-
-    assert isinstance(A, np.ndarray)
-    assert isinstance(B, np.ndarray)
+    assert isinstance(A, np.ndarray) and isinstance(B, np.ndarray)
     assert issparse(X_test)
+    n_users, n_items = X_test.shape
+    _fail_if(n_users >= _INT32_MAX, "Number of test user is larger than maximum supported.")
+    _fail_if(n_items >= _INT32_MAX, "Number of items is larger than maximum supported.")
+    _fail_if(X_test.data.shape[0] == 0, "'X_test' is empty.")
+    A, B = _check_factors(A, B, n_users, n_items)
 
-    if X_test.shape[0] >= np.iinfo(np.int32).max:
-        raise ValueError("Number of test user is larger than maximum supported.")
-    if X_test.shape[1] >= np.iinfo(np.int32).max:
-        raise ValueError("Number of items is larger than maximum supported.")
-    if not X_test.data.shape[0]:
-        raise ValueError("'X_test' is empty.")
-    if len(A.shape) != 2:
-        raise ValueError("'A' must be a 2-dimensional array.")
-    if len(B.shape) != 2:
-        raise ValueError("'B' must be a 2-dimensional array.")
-    if A.shape[1] != B.shape[1]:
-        raise ValueError("'A' and 'B' must have the same number of columns.")
-    if (not A.shape[0]) or (not A.shape[1]) or (not B.shape[1]) or (not X_test.shape[0]) or (not X_test.shape[1]):
-        raise ValueError("Input matrices cannot be empty.")
-    if A.shape[0] < X_test.shape[0]:
-        raise ValueError("Number of users in 'A' and 'X_test' does not match.")
-    if B.shape[0] < X_test.shape[1]:
-        raise ValueError("Number of items in 'B' and 'X_test' does not match.")
-    if A.shape[0] > X_test.shape[0]:
-        warn("'A' has more users than 'X_test'.")
-        A = A[:X_test.shape[0], :]
-    if B.shape[0] > X_test.shape[1]:
-        warn("'B' has more items than 'X_test'.")
-        B = B[:X_test.shape[1], :]
+    # float32 only when BOTH factor matrices are float32 (reference :469)
+    dtype = np.float32 if (A.dtype == np.float32 and B.dtype == np.float32) else np.float64
 
-    # float32 only when BOTH factor matrices are float32 (reference __init__.py:469)
-    use_float = (A.dtype == ctypes.c_float) and (B.dtype == ctypes.c_float)
-    dtype = np.float32 if use_float else np.float64
-
+    # ---- train matrix ----
     if X_train is None:
         X_train = csr_array(X_test.shape, dtype=dtype)
         consider_cold_start = True
     assert issparse(X_train)
-    assert X_train.shape[1] == X_test.shape[1]
-    if X_train.shape[0] < X_test.shape[0]:
-        raise ValueError("'X_train' and 'X_test' should have the same number of rows.")
-    elif X_train.shape[0] > X_test.shape[0]:
+    assert X_train.shape[1] == n_items
+    _fail_if(X_train.shape[0] < n_users, "'X_train' and 'X_test' should have the same number of rows.")
+    if X_train.shape[0] > n_users:
         warn("'X_train' mas more rows than 'X_test'.")
 
-    as_df, rename_k, cumulative = bool(as_df), bool(rename_k), bool(cumulative)
-    break_ties_with_noise, consider_cold_start = bool(break_ties_with_noise), bool(consider_cold_start)
-    flags = dict(precision=bool(precision), trunc_precision=bool(trunc_precision), recall=bool(recall),
-                 average_precision=bool(average_precision), trunc_average_precision=bool(trunc_average_precision),
-                 ndcg=bool(ndcg), hit=bool(hit), rr=bool(rr), roc_auc=bool(roc_auc), pr_auc=bool(pr_auc))
-    if not (flags["precision"] or flags["average_precision"] or flags["ndcg"] or flags["hit"] or flags["rr"] or flags["roc_auc"]):
-        raise ValueError("Must pass at least one metric to calculate.")
+    _fail_if(not (requested["precision"] or requested["average_precision"] or requested["ndcg"]
+                  or requested["hit"] or requested["rr"] or requested["roc_auc"]),
+             "Must pass at least one metric to calculate.")
 
+    # ---- scalars ----
     if isinstance(seed, np.random.RandomState):
-        seed = int(seed.randint(np.iinfo(np.int32).max))
+        seed = seed.randint(_INT32_MAX)
     elif isinstance(seed, np.random.Generator):
-        seed = int(seed.integers(np.iinfo(np.int32).max))
-    nthreads, seed, k = int(nthreads), int(seed), int(k)
+        seed = seed.integers(_INT32_MAX)
+    seed, k, nthreads = int(seed), int(k), int(nthreads)
     min_pos_test, min_items_pool = int(min_pos_test), int(min_items_pool)
-    assert seed >= 1
-    assert k >= 1
-    assert min_pos_test >= 1
-    assert min_items_pool >= 1
+    assert seed >= 1 and k >= 1 and min_pos_test >= 1 and min_items_pool >= 1
     if nthreads < 0:
-        nthreads = multiprocessing.cpu_count() + 1 + nthreads
+        nthreads += multiprocessing.cpu_count() + 1
     assert nthreads > 0
     if nthreads > 1 and not _binding.has_openmp():
         warn("Attempting to use more than 1 thread, but package was built without multi-threading support.")
-
-    if k > X_test.shape[1]:
-        raise ValueError("'k' should be smaller than the number of items.")
+    _fail_if(k > n_items, "'k' should be smaller than the number of items.")
 
     if item_biases is not None:
-        assert isinstance(item_biases, np.ndarray)
-        if len(item_biases.shape) > 2:
-            raise ValueError("'item_biases' should be a 1-d array.")
-        if len(item_biases.shape) != 1:
-            item_biases = item_biases.reshape(-1)
-        if not item_biases.shape[0]:
-            raise ValueError("'item_biases' is empty.")
-        if item_biases.shape[0] < X_test.shape[1]:
-            raise ValueError("Number of items in 'item_biases' must match with 'X_test'.")
-        if item_biases.shape[0] > X_test.shape[1]:
-            item_biases = item_biases[:X_test.shape[1]]
-            warn("'item_biases' has more items than 'X_test'.")
-        # fold the biases in as one more factor: A = [A | 1], B = [B | bias]   (reference __init__.py:549-550)
-        item_biases = _to_dtype(item_biases, dtype)
-        A = np.c_[A, np.ones((A.shape[0], 1), dtype=dtype)]
-        B = np.c_[B, item_biases.reshape((-1, 1))]
+        A, B = _fold_item_biases(A, B, item_biases, n_items, dtype)
 
+    # ---- normalise storage: sorted int32 CSR, test values and factors in `dtype`, row-major factors ----
     X_train = _sorted_csr_int32(X_train)
+    if X_train.shape[0] > n_users:
+        X_train = _sorted_csr_int32(X_train[:n_users])
     X_test = _sorted_csr_int32(X_test)
     if X_test.dtype != dtype:
         X_test = X_test.astype(dtype)
-    if X_train.shape[0] > X_test.shape[0]:
-        X_train = X_train[:X_test.shape[0], :]
-        X_train = _sorted_csr_int32(X_train)
-    A, lda = _row_major_with_ld(_to_dtype(A, dtype))
-    B, ldb = _row_major_with_ld(_to_dtype(B, dtype))
+    A, lda = _row_major_with_ld(A.astype(dtype, copy=False))
+    B, ldb = _row_major_with_ld(B.astype(dtype, copy=False))
 
-    want = {short: flags[flag] for flag, short, _ in _FLAG_TO_KEY}
     arrays = _binding.calc_metrics(
         A, lda, B, ldb, X_train.indptr, X_train.indices, X_test.indptr, X_test.indices, X_test.data,
-        k, want, cumulative, break_ties_with_noise, consider_cold_start, min_items_pool, min_pos_test, nthreads, seed)
+        k, {short: requested[name] for name, short, _ in _METRICS}, bool(cumulative), bool(break_ties_with_noise),
+        bool(consider_cold_start), min_items_pool, min_pos_test, nthreads, seed)
 
-    out = {}
-    for (flag, short, key), arr in zip(_FLAG_TO_KEY, arrays):
-        if arr.shape[0]:
-            out[key] = arr
+    out = {key: arr for (_, _, key), arr in zip(_METRICS, arrays) if arr.shape[0]}
     if not as_df:
         out["K"] = k
         return out
-    if not cumulative:
-        out = pd.DataFrame(out)
-        if rename_k:
-            out.columns = out.columns.str.replace("@K$", "@" + str(k), regex=True)
-        return out
-    frames = []
-    for key, v in out.items():
-        if v.ndim == 1:                      # ROC_AUC / PR_AUC stay single columns (the reference raises IndexError here)
-            frames.append(pd.DataFrame({key: v}))
-        else:
-            frames.append(pd.DataFrame(v, columns=[re.sub("(@)K$", r"\1", key) + str(i + 1) for i in range(v.shape[1])]))
-    return pd.concat(frames, axis=1)
+    return _as_frame(out, k, bool(cumulative), bool(rename_k))

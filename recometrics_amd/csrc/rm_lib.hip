@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <type_traits>
 #include <map>
 #include <mutex>
@@ -248,7 +249,7 @@ void run(const Call<T> &c, hipStream_t stream)
     const size_t lds_b = P::lds_b(NG);
     const size_t lds_auc = want_auc ? (size_t)GROUPS_PER_BLOCK * (1 << jmax) * GU * (sizeof(T) + 4) : 0;
     const size_t lds_lists = 8ull * K * GU * sizeof(typename P::ListT);
-    const bool list_in_lds = lds_b + lds_auc + lds_lists <= LDS_LIMIT;
+    const bool list_in_lds = lds_b + lds_auc + lds_lists <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS");
     const size_t lds_total = lds_b + lds_auc + (list_in_lds ? lds_lists : 0);
 
     Entry<T> *merged = (Entry<T> *)ws.get("merged", sizeof(Entry<T>) * (size_t)m * K);

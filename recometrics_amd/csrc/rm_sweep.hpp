@@ -186,7 +186,11 @@ void k_sweep(SweepArgs a)
     // registers, the wave never waits for the bytes before the end-of-step barrier.  One wave-instruction moves 1 KiB
     // (64 lanes x 16 B) to a lane-linear LDS image, which is exactly how the packed tile is laid out. ----
     auto stage = [&](int unit, int buf) {                     // unit = tile * NC + chunk: contiguous in the packed image
+#ifdef RM_ABL_SAME_TILE
+        const float4 *src = a.Bp + (size_t)(unit & 7) * BUF_F4;
+#else
         const float4 *src = a.Bp + (size_t)unit * BUF_F4;
+#endif
         float4 *dst = ldsB + buf * BUF_F4;
         for (int pc = wave; pc < NG * 2; pc += 8)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + pc * 64 + lane),
@@ -337,7 +341,9 @@ void k_sweep(SweepArgs a)
         const unsigned thr_seen = (primary && !DUMP) ? __hip_atomic_load(a.thr_shared + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         for (int c = 0; c < NC; c++) {
             const int unit = i * NC + c;
+#ifndef RM_ABL_NO_STAGE
             if (unit + 1 < nunits) stage(t0 * NC + unit + 1, (unit + 1) & 1);   // that buffer was last read one step ago
+#endif
 #ifndef RM_ABL_NO_MFMA
             do_mfma(acc, unit & 1, c);
 #endif
@@ -345,7 +351,9 @@ void k_sweep(SweepArgs a)
             if (c == NC - 1) do_epi(acc, t0 + i, thr_seen);
 #endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the DMA of the next unit has landed
+#ifndef RM_ABL_NO_BARRIER
             __syncthreads();
+#endif
         }
     }
     if (DUMP) return;
