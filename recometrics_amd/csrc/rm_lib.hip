@@ -236,7 +236,7 @@ void run(const Call<T> &c, hipStream_t stream)
     // round is fullest (each extra split restarts the streaming top-K lists, hence the small per-split penalty).
     int n_splits = 1;
     if (n_ublocks > 0) {
-        const int n_cu = 256, max_splits = std::max(1, std::min(MAX_PARTS / 2, tiles_total / 256));
+        const int n_cu = 256, max_splits = std::max(1, std::min(MAX_PARTS / 2, tiles_total / 128));
         double best = -1;
         for (int sct = 1; sct <= max_splits; sct++) {
             const long long blocks = (long long)n_ublocks * sct;

@@ -78,7 +78,9 @@ void k_sweep64(Sweep64Args a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gi = wave & 3, sub = wave >> 2;
     const int ul = lane & 15, q = lane >> 4;
-    const int blk_u = blockIdx.x % a.n_ublocks, split = blockIdx.x / a.n_ublocks;
+    // user blocks are sorted by positive-tree depth (cheapest first): launch the deepest (slowest) ones first so that
+    // the last round of the grid is made of the cheap ones
+    const int blk_u = a.n_ublocks - 1 - (int)(blockIdx.x % a.n_ublocks), split = blockIdx.x / a.n_ublocks;
     const int group = blk_u * GROUPS_PER_BLOCK + gi;
     const bool group_ok = group < a.n_groups;
     const int slot = group * GU + ul;
