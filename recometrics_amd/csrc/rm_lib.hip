@@ -249,8 +249,14 @@ void run(const Call<T> &c, hipStream_t stream)
     const size_t lds_b = P::lds_b(NG);
     const size_t lds_auc = want_auc ? (size_t)GROUPS_PER_BLOCK * (1 << jmax) * GU * (sizeof(T) + 4) : 0;
     const size_t lds_lists = 8ull * K * GU * sizeof(typename P::ListT);
-    const bool list_in_lds = lds_b + lds_auc + lds_lists <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS");
-    const size_t lds_total = lds_b + lds_auc + (list_in_lds ? lds_lists : 0);
+    // each group's positives table is aligned to its own size (2^jmax rows of GU scores): worst-case padding = one table
+    const size_t tbytes = want_auc ? ((size_t)1 << jmax) * GU * sizeof(T) : 1;
+    auto lds_need = [&](bool with_lists) {
+        const size_t head = lds_b + (with_lists ? lds_lists : 0);
+        return (want_auc ? (head + tbytes - 1) / tbytes * tbytes : head) + lds_auc;
+    };
+    const bool list_in_lds = lds_need(true) <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS");
+    const size_t lds_total = lds_need(list_in_lds);
 
     Entry<T> *merged = (Entry<T> *)ws.get("merged", sizeof(Entry<T>) * (size_t)m * K);
     T *pos_score = nullptr; unsigned *hist = nullptr; int *pos_order = nullptr, *pos_item = nullptr;

@@ -30,30 +30,37 @@ typedef u32x2 *GblListPtr;
 
 // AUC rank counting for one tile: branchless lower_bound of every score in the lane's user's sorted positives
 // (complete tree of 2^J - 1 rows, +inf padded), then one LDS atomic into the rank histogram.
+typedef __attribute__((address_space(3))) const float *LdsF32Ptr;
+typedef __attribute__((address_space(3))) unsigned *LdsU32Ptr;
+
+// `pos_addr` = LDS byte address of row 0 of the lane's user in its group's table.  The table of a group is 2^jmax rows
+// of 128 B and is ALIGNED to its own size, so "address of row r" = pos_addr | (r << 7): each level of the branchless
+// lower_bound is one OR (candidate address), one compare, one select -- no add.  `hist_delta` = byte distance from the
+// positives table to the histogram table of the same group.
 template <int J>
-__device__ __forceinline__ void auc_pass(const float (&v)[16], const char *posb, char *histb, unsigned &rocacc,
+__device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr, unsigned hist_delta, unsigned &rocacc,
                                          const int *pos_item_g, int sb, int h)
 {
     // The 16 searches are independent: run them level by level (16 LDS reads in flight per level) instead of one
     // dependent 6-deep chain after another, and keep the histogram atomics out of the way until all reads are done
     // (an LDS atomic may alias the table for the compiler and would serialise the chains).
-    unsigned base[16];
+    unsigned at[16];                                           // address of row `base`
     #pragma unroll
-    for (int r = 0; r < 16; r++) base[r] = 0;
+    for (int r = 0; r < 16; r++) at[r] = pos_addr;
     #pragma unroll
     for (int st = (J > 0 ? (1 << (J - 1)) : 0); st >= 1; st >>= 1) {
         float pv[16];
         #pragma unroll
-        for (int r = 0; r < 16; r++) pv[r] = *(const float *)(posb + base[r] + (st - 1) * 128);
+        for (int r = 0; r < 16; r++) pv[r] = *(LdsF32Ptr)(at[r] + (st - 1) * 128);
         #pragma unroll
-        for (int r = 0; r < 16; r++) base[r] = (pv[r] < v[r]) ? base[r] + st * 128 : base[r];
+        for (int r = 0; r < 16; r++) at[r] = (pv[r] < v[r]) ? (at[r] | (st * 128)) : at[r];
     }
     // exact score tie with a positive (row `base` is the first positive not below s; the table has one +inf pad
     // row, so the read is always in range): the total order is (score desc, item asc), i.e. the candidate also
     // outranks the equal-scored positives with a LARGER item id.  Rare; positives' item ids stay in HBM.
     float nx[16];
     #pragma unroll
-    for (int r = 0; r < 16; r++) nx[r] = *(const float *)(posb + base[r]);
+    for (int r = 0; r < 16; r++) nx[r] = *(LdsF32Ptr)(at[r]);
     unsigned long long tie = 0;
     #pragma unroll
     for (int r = 0; r < 16; r++) tie |= __ballot(nx[r] == v[r]);
@@ -62,17 +69,18 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], const char *posb,
         for (int r = 0; r < 16; r++) {
             if (nx[r] == v[r]) {
                 const int item = sb + mfma32_row(r, h);
-                unsigned t = base[r];
-                while (t < (unsigned)(((1 << J) - 1) * 128) && *(const float *)(posb + t) == v[r] && pos_item_g[t >> 2] > item) t += 128;
-                base[r] = t;
+                unsigned t = at[r] - pos_addr;
+                while (t < (unsigned)(((1 << J) - 1) * 128) && *(LdsF32Ptr)(pos_addr + t) == v[r] && pos_item_g[t >> 2] > item) t += 128;
+                at[r] = pos_addr + t;
             }
         }
     }
     #pragma unroll
     for (int r = 0; r < 16; r++) {
-        rocacc += base[r];
-        __hip_atomic_fetch_add((unsigned *)(histb + base[r]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        rocacc += at[r];
+        __hip_atomic_fetch_add((LdsU32Ptr)(at[r] + hist_delta), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    rocacc -= 16u * pos_addr;
 }
 
 template <int NGT, bool AUC, bool DUMP, bool LLDS>
@@ -105,7 +113,10 @@ void k_sweep(SweepArgs a)
     ListEntry *lists_lds = (ListEntry *)p;
     if (LLDS) p += 8 * K * GROUP_USERS * (int)sizeof(ListEntry);
     const int PLmax = (1 << a.jmax) - 1;
-    float *posL = (float *)p;  p += GROUPS_PER_BLOCK * (PLmax + 1) * GROUP_USERS * 4;
+    // each group's positives table (2^jmax rows x 128 B) is aligned to its own size (see auc_pass)
+    const unsigned tbytes = (unsigned)(PLmax + 1) * GROUP_USERS * 4;
+    p = smem + (((unsigned)(p - smem) + tbytes - 1) / tbytes) * tbytes;
+    float *posL = (float *)p;  p += GROUPS_PER_BLOCK * tbytes;
     unsigned *histL = (unsigned *)p;
 
     const int glast = min(a.n_groups, (blk_u + 1) * GROUPS_PER_BLOCK) - 1;
@@ -180,9 +191,9 @@ void k_sweep(SweepArgs a)
         }
         for (int i = tid; i < GROUPS_PER_BLOCK * (PLmax + 1) * GROUP_USERS; i += SWEEP_THREADS) histL[i] = 0;
     }
-    const char *posb = (const char *)(posL + gi * (PLmax + 1) * GROUP_USERS + ul);
+    const unsigned pos_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)(posL + gi * (PLmax + 1) * GROUP_USERS + ul);
+    const unsigned hist_delta = (unsigned)((const char *)histL - (const char *)posL);
     const int *pos_item_g = (AUC && group_ok) ? a.pos_item + (a.grow[group] + group) * GROUP_USERS + ul : nullptr;
-    char *histb = (char *)(histL + gi * (PLmax + 1) * GROUP_USERS + ul);
 
     // ---- staging: packed tile (BUF_F4 float4, contiguous) HBM -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging
     // registers, the wave never waits for the bytes before the end-of-step barrier.  One wave-instruction moves 1 KiB
@@ -318,12 +329,12 @@ void k_sweep(SweepArgs a)
         if (AUC) {
             unsigned rocacc = 0;
             switch (jb) {
-                case 1: auc_pass<1>(v, posb, histb, rocacc, pos_item_g, sb, h); break;
-                case 2: auc_pass<2>(v, posb, histb, rocacc, pos_item_g, sb, h); break;
-                case 3: auc_pass<3>(v, posb, histb, rocacc, pos_item_g, sb, h); break;
-                case 4: auc_pass<4>(v, posb, histb, rocacc, pos_item_g, sb, h); break;
-                case 5: auc_pass<5>(v, posb, histb, rocacc, pos_item_g, sb, h); break;
-                case 6: auc_pass<6>(v, posb, histb, rocacc, pos_item_g, sb, h); break;
+                case 1: auc_pass<1>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h); break;
+                case 2: auc_pass<2>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h); break;
+                case 3: auc_pass<3>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h); break;
+                case 4: auc_pass<4>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h); break;
+                case 5: auc_pass<5>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h); break;
+                case 6: auc_pass<6>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h); break;
                 default: break;
             }
             roc64 += rocacc >> 7;
