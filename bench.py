@@ -42,11 +42,12 @@ def parse():
 class DeviceProblem:
     """Synthetic workload resident in HBM (torch tensors are only the memory owner; the hot path gets raw pointers)."""
 
-    def __init__(self, torch, dev, m, n, k, mean_c, seed, K, dtype=np.float32):
+    def __init__(self, torch, dev, m, n, k, mean_c, seed, K, dtype=np.float32, shard=0):
         from recometrics_amd.synth import make_factors, make_interactions
         self.m, self.n, self.k, self.K, self.dtype = m, n, k, K, dtype
-        A, B = make_factors(m, n, k, dtype, seed)
-        trp, tri, tep, tei, tev = make_interactions(m, n, mean_c, dtype, seed)
+        _, B = make_factors(1, n, k, dtype, seed)                        # item factors: the same replica on every rank
+        A, _ = make_factors(m, 1, k, dtype, seed + 1 + 1000 * shard)     # this rank's user shard
+        trp, tri, tep, tei, tev = make_interactions(m, n, mean_c, dtype, seed + 1000 * shard)
         self.host = dict(A=A, B=B, train=(trp, tri), test=(tep, tei, tev))
         t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
         self.A, self.B = t(A), t(B)
@@ -157,7 +158,7 @@ def main():
         m = m // 8                                           # C3 is quoted user-sharded over 8 GPUs
     if args.users:
         m = args.users
-    prob = DeviceProblem(torch, dev, m, n, k, mean_c, seed + 1000 * rank, K, dtype)
+    prob = DeviceProblem(torch, dev, m, n, k, mean_c, seed, K, dtype, shard=rank)
     gather_buf = torch.empty((world * 10, m), dtype=prob.out.dtype, device=dev) if world > 1 else None
     peak = PEAK_FP32_MFMA_TFLOPS if dtype == np.float32 else PEAK_FP64_MFMA_TFLOPS
     esize = 4.0 if dtype == np.float32 else 8.0
