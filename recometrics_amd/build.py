@@ -22,7 +22,7 @@ def _hipcc():
 
 def _deps():
     root = os.path.dirname(os.path.dirname(CSRC))
-    return (glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp"))
+    return (glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.inc"))
             + glob.glob(os.path.join(root, "include", "*.h")))
 
 

@@ -241,7 +241,8 @@ void run(const Call<T> &c, hipStream_t stream)
         for (int sct = 1; sct <= max_splits; sct++) {
             const long long blocks = (long long)n_ublocks * sct;
             const long long rounds = (blocks + n_cu - 1) / n_cu;
-            const double score = (double)blocks / (double)(rounds * n_cu) - 0.004 * sct;
+            // every split restarts the streaming top-K lists: ~K ln(n / (2 S K)) extra inserts per user and split
+            const double score = (double)blocks / (double)(rounds * n_cu) - 0.004 * sct * std::max(1.0, K / 10.0);
             if (score > best + 1e-9) { best = score; n_splits = sct; }
         }
     }

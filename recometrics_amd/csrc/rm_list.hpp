@@ -170,40 +170,13 @@ __device__ __forceinline__ void keylist_sort_desc(P L, int K)
 // compactions: ~log2(n/K) of them per user and ~K of appends per compaction.
 template <class S>
 __device__ __forceinline__ void wave_compact(typename ListRaw<S>::raw *Gu, int cnt, int K, int lane, S &kth_s, int &kth_idx)
-{
-    constexpr int MAXE = 9;                                   // (2*256 + 32) / 64 rounded up
-    S es[MAXE]; int ei[MAXE]; int rk[MAXE];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the owner lane's appends have reached L2
-    const int E = (cnt + WAVE - 1) / WAVE;
-    #pragma unroll
-    for (int t = 0; t < MAXE; t++) {
-        const int i = lane + t * WAVE;
-        es[t] = 0; ei[t] = IDX_EMPTY; rk[t] = 0;
-        if (t < E && i < cnt) ListRaw<S>::unpack(ListRaw<S>::load_l2(Gu + i), es[t], ei[t]);
-    }
-    for (int b = 0; b < E; b++) {
-        const int nb = min(WAVE, cnt - b * WAVE);
-        S bs = 0; int bi = 0;
-        #pragma unroll
-        for (int t = 0; t < MAXE; t++) if (t == b) { bs = es[t]; bi = ei[t]; }
-        for (int j = 0; j < nb; j++) {
-            const S sj = lane_bcast<S>(bs, j);
-            const int ij = lane_bcast<int>(bi, j);
-            #pragma unroll
-            for (int t = 0; t < MAXE; t++) { if (t >= E) break; rk[t] += (sj > es[t]) || (sj == es[t] && ij < ei[t]); }
-        }
-    }
-    kth_s = -(S)INFINITY; kth_idx = IDX_EMPTY;
-    #pragma unroll
-    for (int t = 0; t < MAXE; t++) {
-        if (t >= E) break;
-        const int i = lane + t * WAVE;
-        const bool live = i < cnt;
-        if (live && rk[t] < K) Gu[rk[t]] = ListRaw<S>::pack(es[t], ei[t]);
-        const unsigned long long hit = __ballot(live && rk[t] == K - 1);
-        if (hit) { const int src = __ffsll((long long)hit) - 1; kth_s = lane_bcast<S>(es[t], src); kth_idx = lane_bcast<int>(ei[t], src); }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // survivors written before anyone appends behind them
-}
+#include "rm_compact_body.inc"
+
+// Out-of-line form for the fp64 sweep: inlined, the nine-entry-per-lane working set is added to a register budget that
+// is already full (256 factors) and the hot loop spills; as a real call only the live registers around this rare path
+// are saved.  The fp32 sweep has the room and keeps the inlined form (a call there costs more than it saves).
+template <class S>
+__device__ __attribute__((noinline)) void wave_compact_call(typename ListRaw<S>::raw *Gu, int cnt, int K, int lane, S &kth_s, int &kth_idx)
+#include "rm_compact_body.inc"
 
 } // namespace rm

@@ -153,7 +153,11 @@ void k_sweep64(Sweep64Args a)
             need &= need - 1;
             const int c = lane_bcast<int>(cnt, l);
             double ks; int ki;
-            wave_compact<double>(Gw + (size_t)l * CAP, c, K, lane, ks, ki);
+#ifdef RM_ABL_NO_COMPACT
+            ks = 1e300; ki = 0;
+#else
+            wave_compact_call<double>(Gw + (size_t)l * CAP, c, K, lane, ks, ki);
+#endif
             if (lane == l) { cnt = c < K ? c : K; if (c >= K) { ws = ks; widx = ki; } }
         }
     };
@@ -278,7 +282,9 @@ void k_sweep64(Sweep64Args a)
     __syncthreads();
     for (int i = 0; i < ntiles; i++) {
         const unsigned long long thr_seen = (primary && !DUMP) ? __hip_atomic_load(a.thr_shared + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        #pragma unroll
+        // resident user factors are indexed af[c * NGC + gl]: the chunk loop must then be unrolled; when each chunk's
+        // factors are re-read the loop stays rolled (4x less code and register pressure at 256 factors)
+        #pragma unroll(AF_RESIDENT ? NC : 1)
         for (int c = 0; c < NC; c++) {
             const int unit = i * NC + c;
             const int buf = unit & 1;
