@@ -210,11 +210,18 @@ def test_north_star_shape_vs_oracle(hip, oracle):
     _check_against_oracle(hip, oracle, pr, 10)
 
 
-def test_full_size_properties(hip):
-    """BASELINE-scale shape (C2-like slice): size-independent properties instead of an oracle run"""
+def test_full_size_properties(hip, oracle):
+    """BASELINE-scale shape (C2-like slice): size-independent properties, plus the oracle on a sub-sample of the users
+    (users are independent, so rows [0, 384) of the big run must equal the oracle run on those rows alone)"""
+    from recometrics_amd.sharding import slice_csr
     from recometrics_amd.synth import make_problem
     pr = make_problem(4096, 26744, 64, np.float32, mean_c=144, seed=102)
     single = hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], 10)
+    sub_tr = slice_csr(pr["train"][0], pr["train"][1], None, 0, 384)[:2]
+    sub_te = slice_csr(pr["test"][0], pr["test"][1], pr["test"][2], 0, 384)
+    want = oracle.calc(pr["A"][:384], pr["B"], sub_tr, sub_te, 10, nthreads=8)
+    for name in want:
+        assert_close(single[name][:384], want[name], TOL, "sub-sample " + name)
     cum = hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], 10, cumulative=True)
     for name in ("P@K", "TP@K", "R@K", "AP@K", "TAP@K", "Hit@K", "RR@K"):
         assert_same_bits(cum[name][:, -1], single[name], name + ": cumulative column K == single-K")
