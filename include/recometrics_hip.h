@@ -131,6 +131,25 @@ int rm_get_timings(double *out, int n);
 /* Releases the cached device workspace of the current device. */
 int rm_release_workspace(void);
 
+/* ---- train / test splitting (host only; "next" row N3) ------------------------------------------------------------
+ * Replaces split_data_selected_users_{float,double}, split_data_separate_users_* and split_data_joined_users_*
+ * (src/recometrics_signatures.hpp:100-220), which hand their results back in std::vector& parameters; a C-ABI returns an
+ * opaque result instead.  mode 0 = every row is split ("all"), 1 = separated (test users drawn at random; outputs
+ * rem / train / test / users_test), 2 = joined (train = [train of the test users ; remaining users]).  `n_users_test`,
+ * `consider_cold_start`, `min_items_pool`, `min_pos_test` are ignored in mode 0.  Results are bit-identical to the
+ * reference's for the same seed (both consume std::mt19937 through std::shuffle in the same order).
+ * Arrays of a result, `which`: 0-2 train (indptr, indices, values), 3-5 test, 6-8 rem, 9 users_test. */
+int rm_split_f32(const int32_t *X_csr_p, const int32_t *X_csr_i, const float *X_csr, int32_t m, int32_t n, int mode,
+                 int32_t n_users_test, double test_fraction, int consider_cold_start, int32_t min_items_pool,
+                 int32_t min_pos_test, uint64_t seed, void **result);
+int rm_split_f64(const int32_t *X_csr_p, const int32_t *X_csr_i, const double *X_csr, int32_t m, int32_t n, int mode,
+                 int32_t n_users_test, double test_fraction, int consider_cold_start, int32_t min_items_pool,
+                 int32_t min_pos_test, uint64_t seed, void **result);
+int64_t rm_split_size(const void *result, int which);           /* number of elements of array `which` (-1 = bad argument) */
+int rm_split_copy(const void *result, int which, void *dst);    /* copies array `which` into dst (caller-sized) */
+void rm_split_free(void *result);
+const char *rm_split_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _binding
 
-__all__ = ["calc_reco_metrics"]
+__all__ = ["calc_reco_metrics", "split_reco_train_test"]
 __version__ = "0.1.0"
 
 # (keyword of calc_reco_metrics, name in the C-ABI order, key of the result dict) -- reference __init__.py:590-613
@@ -22,6 +22,12 @@ _METRICS = (
     ("hit", "hit", "Hit@K"), ("rr", "rr", "RR@K"), ("roc_auc", "roc", "ROC_AUC"), ("pr_auc", "pr", "PR_AUC"),
 )
 _INT32_MAX = np.iinfo(np.int32).max
+
+
+def split_reco_train_test(*args, **kwargs):
+    """See :func:`recometrics_amd.split.split_reco_train_test` (imported lazily: it needs SciPy)."""
+    from .split import split_reco_train_test as impl
+    return impl(*args, **kwargs)
 
 
 def _row_major_with_ld(X):

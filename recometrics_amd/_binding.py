@@ -19,6 +19,7 @@ EXPORTS = (
     "rm_calc_metrics_f32", "rm_calc_metrics_f64", "rm_calc_metrics_dev_f32", "rm_calc_metrics_dev_f64",
     "rm_rank_f32", "rm_rank_f64", "rm_debug_scores_f32", "rm_debug_scores_f64", "rm_has_openmp",
     "rm_last_error", "rm_device_count", "rm_set_device", "rm_get_timings", "rm_release_workspace",
+    "rm_split_f32", "rm_split_f64", "rm_split_size", "rm_split_copy", "rm_split_free", "rm_split_last_error",
 )
 
 
@@ -51,6 +52,17 @@ def load():
         getattr(lib, "rm_debug_scores_" + suf).argtypes = [vp, sz, vp, sz, i32, i32, i32, vp]
         for fn in ("rm_calc_metrics_", "rm_calc_metrics_dev_", "rm_rank_", "rm_debug_scores_"):
             getattr(lib, fn + suf).restype = ci
+    split_sig = [vp, vp, vp, i32, i32, ci, i32, C.c_double, ci, i32, i32, u64, C.POINTER(vp)]
+    lib.rm_split_f32.argtypes = split_sig
+    lib.rm_split_f64.argtypes = split_sig
+    lib.rm_split_f32.restype = lib.rm_split_f64.restype = ci
+    lib.rm_split_size.argtypes = [vp, ci]
+    lib.rm_split_size.restype = i64
+    lib.rm_split_copy.argtypes = [vp, ci, vp]
+    lib.rm_split_copy.restype = ci
+    lib.rm_split_free.argtypes = [vp]
+    lib.rm_split_free.restype = None
+    lib.rm_split_last_error.restype = C.c_char_p
     lib.rm_last_error.restype = C.c_char_p
     lib.rm_get_timings.argtypes = [C.POINTER(C.c_double), ci]
     lib.rm_set_device.argtypes = [ci]
@@ -170,3 +182,35 @@ def debug_scores(A, B):
     if rc:
         _raise(lib, rc)
     return out
+
+
+def split_csr(indptr, indices, data, n_items, mode, n_users_test=0, test_fraction=0.3, consider_cold_start=False,
+              min_items_pool=2, min_pos_test=1, seed=1):
+    """Host-side split (rm_split_*): returns a dict of raw arrays -- "train" / "test" / "rem" as (indptr, indices, data)
+    tuples and "users_test".  mode: 0 every row, 1 separated, 2 joined (reference wrapper.pyx:523-818)."""
+    lib = load()
+    dtype = data.dtype.type
+    fn = lib.rm_split_f32 if dtype == np.float32 else lib.rm_split_f64
+    handle = C.c_void_p()
+    m = indptr.shape[0] - 1
+    rc = fn(_p(indptr), _p(indices), _p(data), m, n_items, mode, n_users_test, float(test_fraction),
+            int(bool(consider_cold_start)), min_items_pool, min_pos_test, seed, C.byref(handle))
+    if rc:
+        msg = (lib.rm_split_last_error() or b"").decode(errors="replace")
+        if rc == 3:
+            raise MemoryError(msg)
+        raise RuntimeError(msg)
+    try:
+        def arr(which, dt):
+            cnt = lib.rm_split_size(handle, which)
+            out = np.empty(max(cnt, 0), dtype=dt)
+            if cnt > 0:
+                lib.rm_split_copy(handle, which, out.ctypes.data_as(C.c_void_p))
+            return out
+        res = {}
+        for name, base in (("train", 0), ("test", 3), ("rem", 6)):
+            res[name] = (arr(base, np.int32), arr(base + 1, np.int32), arr(base + 2, dtype))
+        res["users_test"] = arr(9, np.int32)
+        return res
+    finally:
+        lib.rm_split_free(handle)

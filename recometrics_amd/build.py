@@ -9,7 +9,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "librecometrics_hip.so")
-SOURCES = ["rm_lib.hip", "rm_sweep32.hip", "rm_sweep32_large.hip", "rm_sweep64_small.hip", "rm_sweep64_large.hip"]
+SOURCES = ["rm_lib.hip", "rm_sweep32.hip", "rm_sweep32_large.hip", "rm_sweep64_small.hip", "rm_sweep64_large.hip", "rm_split.cpp"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"]
 
 
@@ -22,7 +22,7 @@ def _hipcc():
 
 def _deps():
     root = os.path.dirname(os.path.dirname(CSRC))
-    return (glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.inc"))
+    return (glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(os.path.join(CSRC, "*.cpp"))
             + glob.glob(os.path.join(root, "include", "*.h")))
 
 
@@ -35,8 +35,11 @@ def needs_build():
 
 def _compile(src, extra):
     obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-    res = subprocess.run([_hipcc()] + FLAGS + list(extra) + ["-c", os.path.join(CSRC, src), "-o", obj],
-                         capture_output=True, text=True)
+    if src.endswith(".cpp"):        # host-only translation unit
+        cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+    else:
+        cmd = [_hipcc()] + FLAGS + list(extra) + ["-c", os.path.join(CSRC, src), "-o", obj]
+    res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed on %s:\n%s%s" % (src, res.stdout, res.stderr))
     return obj, res.stderr
