@@ -291,17 +291,33 @@ __global__ void k_pack_users64(const T *A, size_t lda, int k, int NG, const int 
 }
 
 // ---- positives: scores of the user's test items (same k-ordered fma chain as the sweep's MFMA), sorted --------------
+// k-ordered fma chain; 16-byte loads when both rows allow it (the order of the fma's is what matters, not of the loads)
 template <class T> __device__ __forceinline__ T chain_dot(const T *x, const T *y, int k);
 template <> __device__ __forceinline__ float chain_dot<float>(const float *x, const float *y, int k)
 {
     float s = 0.f;
-    for (int t = 0; t < k; t++) s = __builtin_fmaf(x[t], y[t], s);
+    int t = 0;
+    if ((((size_t)x | (size_t)y) & 15) == 0) {
+        for (; t + 4 <= k; t += 4) {
+            const float4 a = *(const float4 *)(x + t), b = *(const float4 *)(y + t);
+            s = __builtin_fmaf(a.x, b.x, s); s = __builtin_fmaf(a.y, b.y, s);
+            s = __builtin_fmaf(a.z, b.z, s); s = __builtin_fmaf(a.w, b.w, s);
+        }
+    }
+    for (; t < k; t++) s = __builtin_fmaf(x[t], y[t], s);
     return s;
 }
 template <> __device__ __forceinline__ double chain_dot<double>(const double *x, const double *y, int k)
 {
     double s = 0.;
-    for (int t = 0; t < k; t++) s = __builtin_fma(x[t], y[t], s);
+    int t = 0;
+    if ((((size_t)x | (size_t)y) & 15) == 0) {
+        for (; t + 2 <= k; t += 2) {
+            const double2 a = *(const double2 *)(x + t), b = *(const double2 *)(y + t);
+            s = __builtin_fma(a.x, b.x, s); s = __builtin_fma(a.y, b.y, s);
+        }
+    }
+    for (; t < k; t++) s = __builtin_fma(x[t], y[t], s);
     return s;
 }
 
