@@ -10,11 +10,15 @@
 //                  quantity of the epilogue (K-th best threshold, min, max, train cursor, AUC partial sum) is then ONE
 //                  VGPR, and the per-user LDS tables (sorted positives, rank histogram, top-K list) are laid out
 //                  [row][32 users] so that lane u always hits bank u: conflict-free whatever the data.
-//   block          512 threads = 8 wavefronts = 4 user groups x 2 item sub-tiles.  Wavefronts w and w+4 share a SIMD
-//                  and a user group; w runs {MFMA(tile t), epilogue(tile t-1)}, w+4 runs {epilogue(t-1), MFMA(t)}, so
-//                  the matrix pipe and the VALU/LDS epilogue of the two overlap inside one barrier interval.
-//   operands       user factors live in registers for the whole sweep (NG float4 per lane); packed item tiles
-//                  (rm_prep.hpp k_pack_items) stream HBM -> registers -> LDS, double buffered, one barrier per tile.
+//   block          512 threads = 8 wavefronts = 4 user groups x 2 item sub-tiles (128 users x 64 items per step).
+//                  Wavefronts w and w+4 share a SIMD and a user group.  An f32-input MFMA chain does not co-execute
+//                  with VALU / LDS work of the SIMD partner (scratch/coexec2.hip: time = sum), so the waves run in
+//                  phase -- MFMA(tile t), then epilogue(tile t) -- and the lever is the epilogue's instruction count.
+//   operands       user factors live in registers for the whole sweep (NG float4 per lane, up to 128 factors; beyond
+//                  that the factor axis is streamed in 128-factor chunks); packed item tiles (rm_prep.hpp
+//                  k_pack_items) stream HBM -> LDS by LDS-DMA, double buffered, one barrier per tile.
+//   diagnostics    the RM_ABL_* macros compile single stages out (wrong results, timing only): they are how the cost
+//                  breakdown in DESIGN.md was measured and are never defined in a product build.
 #pragma once
 #include "rm_device.hpp"
 #include "rm_list.hpp"
