@@ -43,16 +43,29 @@ typedef __attribute__((address_space(3))) unsigned *LdsU32Ptr;
 // positives table to the histogram table of the same group.
 template <int J>
 __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr, unsigned hist_delta, unsigned &rocacc,
-                                         const int *pos_item_g, int sb, int h)
+                                         const int *pos_item_g, int sb, int h, float piv_root, float piv_lo, float piv_hi)
 {
     // The 16 searches are independent: run them level by level (16 LDS reads in flight per level) instead of one
     // dependent 6-deep chain after another, and keep the histogram atomics out of the way until all reads are done
-    // (an LDS atomic may alias the table for the compiler and would serialise the chains).
+    // (an LDS atomic may alias the table for the compiler and would serialise the chains).  The pivots of the two
+    // top levels of the lane's user (root, and the roots of its two subtrees) are per-sweep constants held in
+    // registers: two of the dependent LDS round trips disappear.
     unsigned at[16];                                           // address of row `base`
+    constexpr int TOP = J >= 2 ? 2 : 0;                        // levels resolved from registers
+    if (TOP == 2) {
+        #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const bool c1 = piv_root < v[r];
+            const float p2 = c1 ? piv_hi : piv_lo;
+            const bool c2 = p2 < v[r];
+            at[r] = pos_addr | (c1 ? (128u << (J - 1)) : 0u) | (c2 ? (128u << (J - 2)) : 0u);
+        }
+    } else {
+        #pragma unroll
+        for (int r = 0; r < 16; r++) at[r] = pos_addr;
+    }
     #pragma unroll
-    for (int r = 0; r < 16; r++) at[r] = pos_addr;
-    #pragma unroll
-    for (int st = (J > 0 ? (1 << (J - 1)) : 0); st >= 1; st >>= 1) {
+    for (int st = (J - TOP > 0 ? (1 << (J - TOP - 1)) : 0); st >= 1; st >>= 1) {
         float pv[16];
         #pragma unroll
         for (int r = 0; r < 16; r++) pv[r] = *(LdsF32Ptr)(at[r] + (st - 1) * 128);
@@ -197,6 +210,14 @@ void k_sweep(SweepArgs a)
     }
     const unsigned pos_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)(posL + gi * (PLmax + 1) * GROUP_USERS + ul);
     const unsigned hist_delta = (unsigned)((const char *)histL - (const char *)posL);
+    float piv_root = pos_inf_f(), piv_lo = pos_inf_f(), piv_hi = pos_inf_f();     // top two tree levels of the lane's user
+    if (AUC && jb >= 2) {
+        __syncthreads();                                                           // the tables above are complete
+        const int r0 = (1 << (jb - 1)) - 1, d = 1 << (jb - 2);
+        piv_root = *(LdsF32Ptr)(pos_addr + r0 * 128);
+        piv_lo = *(LdsF32Ptr)(pos_addr + (r0 - d) * 128);
+        piv_hi = *(LdsF32Ptr)(pos_addr + (r0 + d) * 128);
+    }
     const int *pos_item_g = (AUC && group_ok) ? a.pos_item + (a.grow[group] + group) * GROUP_USERS + ul : nullptr;
 
     // ---- staging: packed tile (BUF_F4 float4, contiguous) HBM -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging
@@ -333,12 +354,12 @@ void k_sweep(SweepArgs a)
         if (AUC) {
             unsigned rocacc = 0;
             switch (jb) {
-                case 1: auc_pass<1>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h); break;
-                case 2: auc_pass<2>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h); break;
-                case 3: auc_pass<3>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h); break;
-                case 4: auc_pass<4>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h); break;
-                case 5: auc_pass<5>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h); break;
-                case 6: auc_pass<6>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h); break;
+                case 1: auc_pass<1>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
+                case 2: auc_pass<2>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
+                case 3: auc_pass<3>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
+                case 4: auc_pass<4>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
+                case 5: auc_pass<5>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
+                case 6: auc_pass<6>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
                 default: break;
             }
             roc64 += rocacc >> 7;
