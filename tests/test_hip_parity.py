@@ -202,6 +202,45 @@ def test_python_api_drop_in(hip, oracle):
         calc_reco_metrics(Xtr, Xte, pr["A"], pr["B"], k=n + 1)
 
 
+def test_python_api_modes(hip, oracle):
+    """float64 inputs, strided factor matrices (lda > k), X_train=None, the non-personalised mode (A = B = None with
+    item biases), cumulative DataFrame output -- reference recometrics/__init__.py:429-436,:469-473,:560-562,:615-626"""
+    from scipy.sparse import csr_array
+    from recometrics_amd import calc_reco_metrics
+    from recometrics_amd.synth import make_problem
+    m, n, k = 90, 700, 12
+    pr = make_problem(m, n, k, np.float64, mean_c=25, seed=33)
+    trp, tri = pr["train"]; tep, tei, tev = pr["test"]
+    Xtr = csr_array((np.ones(tri.shape[0]), tri, trp), shape=(m, n))
+    Xte = csr_array((tev, tei, tep), shape=(m, n))
+    # float64 + strided A (a column slice of a wider row-major array keeps lda = 20)
+    wide = np.zeros((m, 20)); wide[:, :k] = pr["A"]
+    d = calc_reco_metrics(Xtr, Xte, wide[:, :k], pr["B"], k=5, all_metrics=True, as_df=False, break_ties_with_noise=False)
+    want = oracle.calc(pr["A"], pr["B"], pr["train"], pr["test"], 5, dtype=np.float64)
+    assert d["P@K"].dtype == np.float64
+    for key in want:
+        assert_close(d[key], want[key], TOL, "f64 strided " + key)
+    # mixed dtypes => float64 (only float32 when BOTH are float32)
+    d = calc_reco_metrics(Xtr, Xte, pr["A"].astype(np.float32), pr["B"], k=5, as_df=False, break_ties_with_noise=False)
+    assert d["P@K"].dtype == np.float64
+    # no train matrix
+    d = calc_reco_metrics(None, Xte, pr["A"], pr["B"], k=5, ndcg=False, roc_auc=True, as_df=False, break_ties_with_noise=False)
+    empty = (np.zeros(m + 1, np.int32), np.zeros(0, np.int32))
+    want = oracle.calc(pr["A"], pr["B"], empty, pr["test"], 5, metrics=("p", "ap", "roc"), dtype=np.float64)
+    for key in want:
+        assert_close(d[key], want[key], TOL, "no train " + key)
+    # non-personalised: scores = item biases
+    bias = np.random.default_rng(1).standard_normal(n)
+    d = calc_reco_metrics(Xtr, Xte, None, None, k=5, item_biases=bias, as_df=False, break_ties_with_noise=False)
+    want = oracle.calc(np.ones((m, 1)), bias.reshape(-1, 1), pr["train"], pr["test"], 5, metrics=("p", "ap", "ndcg"), dtype=np.float64)
+    for key in want:
+        assert_close(d[key], want[key], TOL, "biases only " + key)
+    # cumulative DataFrame with AUC columns (the reference raises IndexError here; documented fix)
+    df = calc_reco_metrics(Xtr, Xte, pr["A"], pr["B"], k=3, precision=True, average_precision=False, ndcg=False,
+                           roc_auc=True, cumulative=True, break_ties_with_noise=False)
+    assert list(df.columns) == ["P@1", "P@2", "P@3", "ROC_AUC"] and df.shape == (m, 4)
+
+
 def test_north_star_shape_vs_oracle(hip, oracle):
     """n = 1M items x 128 factors (the north-star shape), 192 users: item splits + shared thresholds + exact ties at
     scale (fp32 scores collide with positives' scores ~0.5 times per user here)."""
