@@ -126,8 +126,8 @@ template <> struct Prec<float> {
 template <> struct Prec<double> {
     static constexpr int GU = GROUP_USERS64;
     typedef double2 PackT;  typedef u32x4 ListT;  typedef Sweep64Args Args;
-    static int supported_ng(int k) { const int ng = (k + 7) / 8; for (int o : {2, 4, 8, 16, 32}) if (ng <= o) return o; return -1; }
-    static const char *limit() { return "the fp64 path supports up to 256 factors"; }
+    static int supported_ng(int k) { const int ng = (k + 7) / 8; for (int o : {2, 4, 8, 16, 32, 64}) if (ng <= o) return o; return -1; }
+    static const char *limit() { return "the fp64 path supports up to 512 factors"; }
     static size_t lds_b(int NG) { return 2ull * std::min(NG, 8) * 4 * TILE_ITEMS * 16; }
     static long long items_units(int tiles, int NG) { return (long long)tiles * NG * 4 * TILE_ITEMS; }
     static long long users_units(int groups, int NG) { return (long long)groups * NG * 4 * GU; }

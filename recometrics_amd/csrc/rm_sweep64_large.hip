@@ -1,4 +1,4 @@
-// rm_sweep64_large.hip -- translation unit instantiating the fp64 (65..256 factors) sweep kernels.
+// rm_sweep64_large.hip -- translation unit instantiating the fp64 (65..512 factors) sweep kernels.
 #include <hip/hip_runtime.h>
 #include "rm_sweep64.hpp"
 
@@ -15,7 +15,7 @@ static int launch_ng(int NG, dim3 grid, size_t lds, hipStream_t stream, const Sw
         hipLaunchKernelGGL(kern, grid, dim3(SWEEP_THREADS), lds, stream, sa);                                        \
     } break;
     switch (NG) {
-        RM_LAUNCH(16) RM_LAUNCH(32)
+        RM_LAUNCH(16) RM_LAUNCH(32) RM_LAUNCH(64)
         default: return -1;
     }
 #undef RM_LAUNCH

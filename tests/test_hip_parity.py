@@ -47,7 +47,7 @@ def test_mfma_scores_are_the_k_ordered_fma_chain(hip, oracle, k):
     assert_same_bits(got, want, "scores k=%d" % k)
 
 
-@pytest.mark.parametrize("k", [3, 8, 40, 64, 100, 130, 256])
+@pytest.mark.parametrize("k", [3, 8, 40, 64, 100, 130, 256, 300, 512])
 def test_mfma_f64_scores_are_the_k_ordered_fma_chain(hip, oracle, k):
     """v_mfma_f64_16x16x4_f64 contraction == strict index-order fma chain (reference dot1, double), bit for bit."""
     rng = np.random.default_rng(100 + k)
@@ -135,6 +135,7 @@ def test_random_problem_vs_oracle(hip, oracle, m, n, k, K, mean_c):
     (150, 5000, 64, 5, 50),
     (70, 20000, 256, 50, 50),      # BASELINE config C5's factor count and K (fp64, lists out of LDS, item splits)
     (129, 1027, 100, 7, 40),
+    (60, 2000, 400, 5, 30),        # > 256 factors in fp64
 ])
 def test_random_problem_vs_oracle_f64(hip, oracle, m, n, k, K, mean_c):
     from recometrics_amd.synth import make_problem
