@@ -24,6 +24,9 @@ constexpr int GROUPS_PER_BLOCK = 4;
 constexpr int POS_CHUNK = 63;          // positives per slot = rows of a complete binary search tree of depth 6
 constexpr int MAX_J = 6;
 constexpr int IDX_EMPTY = 0x7fffffff;
+// s_waitcnt immediate on gfx9/CDNA: vmcnt = bits [3:0] and [15:14], expcnt = [6:4], lgkmcnt = [11:8]; this one waits for
+// vmcnt == 0 and leaves the other two counters alone
+constexpr int WAIT_VMCNT0 = 0x0F70;
 
 // per-user flags written by k_classify
 enum : int { UF_NAN = 1, UF_ONLY_NDCG = 2, UF_KLEQN = 4, UF_ACTIVE = 8 };

@@ -122,6 +122,8 @@ template <> struct Prec<float> {
     static size_t lds_b(int NG) { return 2ull * std::min(NG, 16) * 2 * TILE_ITEMS * 16; }
     static long long items_units(int tiles, int NG) { return (long long)tiles * NG * 2 * TILE_ITEMS; }
     static long long users_units(int groups, int NG) { return (long long)groups * NG * 2 * GU; }
+    static constexpr bool has_pending = true;
+    static void set_pending(SweepArgs &sa, int cap, int off) { sa.pend_cap = cap; sa.pend_off = off; }
 };
 template <> struct Prec<double> {
     static constexpr int GU = GROUP_USERS64;
@@ -131,6 +133,8 @@ template <> struct Prec<double> {
     static size_t lds_b(int NG) { return 2ull * std::min(NG, 8) * 4 * TILE_ITEMS * 16; }
     static long long items_units(int tiles, int NG) { return (long long)tiles * NG * 4 * TILE_ITEMS; }
     static long long users_units(int groups, int NG) { return (long long)groups * NG * 4 * GU; }
+    static constexpr bool has_pending = false;
+    static void set_pending(Sweep64Args &, int, int) {}
 };
 
 inline void check_launch(int rc)
@@ -257,7 +261,12 @@ void run(const Call<T> &c, hipStream_t stream)
         return (want_auc ? (head + tbytes - 1) / tbytes * tbytes : head) + lds_auc;
     };
     const bool list_in_lds = lds_need(true) <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS");
-    const size_t lds_total = lds_need(list_in_lds);
+    size_t lds_total = lds_need(list_in_lds);
+    // fp32 LDS lists: per-lane pending buffers behind everything else when 8 (or 4) keys per lane still fit
+    int pend_cap = 0; const size_t pend_off = lds_total;
+    if (P::has_pending && list_in_lds && !getenv("RM_DEBUG_NO_PENDING"))
+        for (int cap : {8, 4})
+            if (lds_total + 8ull * cap * WAVE * 8 <= LDS_LIMIT) { pend_cap = cap; lds_total += 8ull * cap * WAVE * 8; break; }
 
     Entry<T> *merged = (Entry<T> *)ws.get("merged", sizeof(Entry<T>) * (size_t)m * K);
     T *pos_score = nullptr; unsigned *hist = nullptr; int *pos_order = nullptr, *pos_item = nullptr;
@@ -305,6 +314,7 @@ void run(const Call<T> &c, hipStream_t stream)
         sa.Ap = (decltype(sa.Ap))Ap; sa.Bp = (decltype(sa.Bp))Bp; sa.slot_user = slot_user; sa.slot_chunk = slot_chunk;
         sa.train_p = c.train_p; sa.train_i = c.train_i; sa.gj = gj; sa.grow = grow;
         sa.pos_score = pos_score; sa.pos_item = pos_item; sa.hist = hist; sa.glists = glists; sa.pl = pl; sa.pst = pst; sa.dump = nullptr;
+        P::set_pending(sa, pend_cap, (int)pend_off);
 
         HIP_CHECK(hipEventRecord(g_ev[1], stream));
         dispatch_sweep(want_auc, false, list_in_lds, NG, dim3(n_blocks), lds_total, stream, sa);

@@ -100,6 +100,13 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
     rocacc -= 16u * pos_addr;
 }
 
+#ifdef RM_STATS
+__device__ unsigned long long g_stats[16];
+#define RM_STAT(i, x) do { if (lane == 0) atomicAdd(&g_stats[i], (unsigned long long)(x)); } while (0)
+#else
+#define RM_STAT(i, x) do {} while (0)
+#endif
+
 template <int NGT, bool AUC, bool DUMP, bool LLDS>
 __global__ __launch_bounds__(SWEEP_THREADS, 2)
 void k_sweep(SweepArgs a)
@@ -187,6 +194,26 @@ void k_sweep(SweepArgs a)
     if (h == 0 && (LLDS || !buffered)) for (int i = 0; i < K; i++) {
         if (LLDS) Ll[i * GROUP_USERS] = 0ull; else Lr[i * GROUP_USERS] = ListRaw<float>::pack(neg_inf_f(), IDX_EMPTY);
     }
+    // LDS lists with pending buffers (a.pend_cap > 0): a candidate is first appended to its LANE's small buffer
+    // ([pend_cap][64 lanes] keys per wave: one LDS write), and the buffers are merged into the lists for all 32 users of
+    // the wave at once when one of them fills up.  Offering candidates one score register at a time keeps 1-2 lanes
+    // busy per replace-the-minimum scan; the merge runs the same scan with every owner lane that has work.
+    const int pend_cap = LLDS ? a.pend_cap : 0;
+    LdsListPtr Pp = (LdsListPtr)((unsigned long long *)(smem + a.pend_off) + wave * pend_cap * WAVE + lane);
+    auto merge_pending = [&]() {
+        const int pc = __shfl_xor(cnt, 32);                       // the partner lane's count (same user, other item rows)
+        const int lim = h == 0 ? (cnt > pc ? cnt : pc) : 0;
+        RM_STAT(5, 1);
+        for (int i = 0; __any(i < lim); i++) {
+            RM_STAT(6, 1); RM_STAT(7, __popcll(__ballot(h == 0 && i < cnt && Pp[i * WAVE] > wkey)) + __popcll(__ballot(h == 0 && i < pc && Pp[i * WAVE + 32] > wkey)));
+            if (h == 0) {
+                if (i < cnt) keylist_offer<GROUP_USERS>(Ll, K, Pp[i * WAVE], wkey, wpos);
+                if (i < pc) keylist_offer<GROUP_USERS>(Ll, K, Pp[i * WAVE + 32], wkey, wpos);
+            }
+        }
+        cnt = 0;
+        ws = (wkey >> 32) ? ord_unkey((unsigned)(wkey >> 32)) : neg_inf_f();
+    };
     // compaction of every owner lane in `need` (wave-uniform mask): K best kept, sorted; (ws, widx) = the K-th
     auto compact_users = [&](unsigned long long need) {
         while (need) {
@@ -230,9 +257,19 @@ void k_sweep(SweepArgs a)
         const float4 *src = a.Bp + (size_t)unit * BUF_F4;
 #endif
         float4 *dst = ldsB + buf * BUF_F4;
-        for (int pc = wave; pc < NG * 2; pc += 8)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + pc * 64 + lane),
-                                             (__attribute__((address_space(3))) void *)(dst + pc * 64), 16, 0, 0);
+        // Issued through inline asm on purpose: with the builtin the compiler assumes every later LDS read may alias
+        // the DMA's LDS write and puts s_waitcnt vmcnt(0) in front of the MFMA operand reads, which serialises the
+        // prefetch with the step it was meant to overlap.  The wait that matters is the explicit one before the
+        // end-of-step barrier.
+        #pragma unroll
+        for (int j = 0; j < (NG * 2 + 7) / 8; j++) {
+            const int pc = wave + 8 * j;
+            if (NG * 2 % 8 == 0 || pc < NG * 2) {
+                const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)(dst + pc * 64));
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                             :: "s"(m0v), "v"(src + pc * 64 + lane) : "memory", "m0");
+            }
+        }
     };
 
     // ---- MFMA: 32 items (registers) x 32 users (lanes), k in index order ----
@@ -280,11 +317,18 @@ void k_sweep(SweepArgs a)
 #endif
         if (slow) {
             unsigned mbits = 0;
-            while (nt < sb + 32) {
+            // `nt2` was loaded when the previous item was consumed, in an earlier step, and is drained by that step's
+            // closing wait: the first consumption of a step (peeled) needs no wait-count.  Only a lane that consumes a
+            // second item in the same step waits for its own fresh load (and with it for the tile prefetch).
+            auto consume = [&]() {
                 if (nt >= sb) mbits |= 1u << (nt - sb);
                 ntc++;
-                nt = nt2;                                           // loaded when the previous item was consumed:
-                nt2 = ntc + 1 < nte ? a.train_i[ntc + 1] : IDX_EMPTY;   // the HBM latency never sits in front of the barrier
+                nt = nt2;
+                nt2 = ntc + 1 < nte ? a.train_i[ntc + 1] : IDX_EMPTY;
+            };
+            if (nt < sb + 32) {
+                consume();
+                while (nt < sb + 32) consume();
             }
             if (sb + 32 > n) mbits |= (n > sb) ? (0xffffffffu << (n - sb)) : 0xffffffffu;
             // the sentinel is all ones: OR-ing the sign-extended mask bit into the score masks it (2 VALU per register)
@@ -320,11 +364,43 @@ void k_sweep(SweepArgs a)
         // of them is a valid lower bound of the final K-th best, so it filters for all of them
         if (primary && thr_seen > thr_pub) { thr_pub = thr_seen; const float t = ord_unkey(thr_seen); thr = t > thr ? t : thr; }
         const unsigned long long cm = __ballot(tmax >= thr);
-        if (cm) {
+        RM_STAT(0, 1); RM_STAT(1, cm != 0); RM_STAT(2, __popcll(cm));
+        if (cm && pend_cap) {
+            unsigned ov = 0;                                    // score registers that did not fit the lane's buffer
+            #pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const bool c = v[r] >= thr;
+                if (__ballot(c)) {
+                    RM_STAT(3, 1); RM_STAT(4, __popcll(__ballot(c)));
+                    if (c) {
+                        if (cnt < pend_cap) { Pp[cnt * WAVE] = pack_key(v[r], sb + mfma32_row(r, h)); cnt++; }
+                        else ov |= 1u << r;
+                    }
+                }
+            }
+            bool more = __any(ov != 0);
+            if (more || __any(cnt >= pend_cap - 1)) merge_pending();
+            while (more) {                                      // warm-up only: more candidates in one tile than a buffer holds
+                unsigned ov2 = 0;
+                #pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const bool c = ((ov >> r) & 1u) && v[r] >= thr;
+                    if (__ballot(c)) {
+                        if (c) {
+                            if (cnt < pend_cap) { Pp[cnt * WAVE] = pack_key(v[r], sb + mfma32_row(r, h)); cnt++; }
+                            else ov2 |= 1u << r;
+                        }
+                    }
+                }
+                ov = ov2; more = __any(ov != 0);
+                merge_pending();
+            }
+        } else if (cm) {
             #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const unsigned long long hitm = __ballot(v[r] >= thr);
                 if (hitm) {
+                    RM_STAT(3, 1); RM_STAT(4, __popcll(hitm));
                     // the partner's score is only fetched when a lane of the upper half has a candidate
                     const float other = (hitm >> 32) ? __shfl_xor(v[r], 32) : nan_sentinel_f();
                     if (h == 0 && primary) {
@@ -340,6 +416,8 @@ void k_sweep(SweepArgs a)
                 }
             }
             if (!LLDS && buffered) compact_users(__ballot(h == 0 && primary && cnt > 2 * K));
+        }
+        if (cm) {
             const float t2 = __shfl(ws, ul);
             if (primary) {
                 thr = t2 > thr ? t2 : thr;
@@ -373,28 +451,43 @@ void k_sweep(SweepArgs a)
     f32x16 acc;
     const int nunits = ntiles * NC;
     if (ntiles > 0) stage(t0 * NC, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // vmcnt(0) through the builtin (not asm) so that the compiler's own wait-count bookkeeping sees the drain: every
+    // load it issued before this point is known complete and needs no further wait inside the loop.
+    __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);
     __syncthreads();
+    // the shared K-th-best bound is read one tile ahead: its load is drained by the end-of-step wait, never by a
+    // wait in the middle of a step (which would also wait for the tile prefetch)
+    auto load_thr = [&]() -> unsigned {
+#ifdef RM_ABL_NO_THRSEEN
+        return 0u;
+#else
+        return (primary && !DUMP) ? __hip_atomic_load(a.thr_shared + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#endif
+    };
+    unsigned thr_seen = 0u;
     for (int i = 0; i < ntiles; i++) {
-        const unsigned thr_seen = (primary && !DUMP) ? __hip_atomic_load(a.thr_shared + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        unsigned thr_next = thr_seen;
         for (int c = 0; c < NC; c++) {
             const int unit = i * NC + c;
 #ifndef RM_ABL_NO_STAGE
             if (unit + 1 < nunits) stage(t0 * NC + unit + 1, (unit + 1) & 1);   // that buffer was last read one step ago
 #endif
+            if (c == 0) thr_next = load_thr();
 #ifndef RM_ABL_NO_MFMA
             do_mfma(acc, unit & 1, c);
 #endif
 #ifndef RM_ABL_NO_EPI
             if (c == NC - 1) do_epi(acc, t0 + i, thr_seen);
 #endif
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the DMA of the next unit has landed
+            __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                              // the DMA of the next unit has landed
 #ifndef RM_ABL_NO_BARRIER
             __syncthreads();
 #endif
         }
+        thr_seen = thr_next;
     }
     if (DUMP) return;
+    if (pend_cap) merge_pending();
 
     // ---- write this wave's partial: top-K list, validity stats, AUC sum; flush the LDS histogram ----
     const int n_part = a.n_splits * 2;

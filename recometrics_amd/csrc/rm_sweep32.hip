@@ -31,3 +31,13 @@ int launch_sweep32(bool auc, bool dump, bool llds, int NG, dim3 grid, size_t lds
 }
 
 } // namespace rm
+
+#ifdef RM_STATS
+extern "C" int rm_debug_stats(unsigned long long *out, int reset)
+{
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(rm::g_stats), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(rm::g_stats), z, sizeof(z)); }
+    return 0;
+}
+#endif
+

@@ -178,9 +178,15 @@ void k_sweep64(Sweep64Args a)
     auto stage = [&](int tile, int chunk, int buf) {
         const f64x2 *src = a.Bp + ((size_t)tile * NGT + (size_t)chunk * NGC) * 4 * TILE_ITEMS;
         f64x2 *dst = ldsB + buf * BUF_D2;
-        for (int pc = wave; pc < NGC * 4; pc += 8)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + pc * 64 + lane),
-                                             (__attribute__((address_space(3))) void *)(dst + pc * 64), 16, 0, 0);
+        // inline asm, not the builtin: see the note at the fp32 sweep's stage() (the compiler would otherwise wait for
+        // the DMA in front of the next LDS read)
+        #pragma unroll
+        for (int j = 0; j < NGC * 4 / 8; j++) {
+            const int pc = wave + 8 * j;
+            const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)(dst + pc * 64));
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                         :: "s"(m0v), "v"(src + pc * 64 + lane) : "memory", "m0");
+        }
     };
 
     unsigned long long thr_pub = 0;
@@ -200,11 +206,15 @@ void k_sweep64(Sweep64Args a)
         const bool slow = __any(nt < sb + 32) || (sb + 32 > n);
         if (slow) {
             unsigned mbits = 0;
-            while (nt < sb + 32) {
+            auto consume = [&]() {                                  // first consumption of a step peeled: see the fp32 sweep
                 if (nt >= sb) mbits |= 1u << (nt - sb);
                 ntc++;
-                nt = nt2;                                           // loaded when the previous item was consumed:
-                nt2 = ntc + 1 < nte ? a.train_i[ntc + 1] : IDX_EMPTY;   // the HBM latency never sits in front of the barrier
+                nt = nt2;
+                nt2 = ntc + 1 < nte ? a.train_i[ntc + 1] : IDX_EMPTY;
+            };
+            if (nt < sb + 32) {
+                consume();
+                while (nt < sb + 32) consume();
             }
             if (sb + 32 > n) mbits |= (n > sb) ? (0xffffffffu << (n - sb)) : 0xffffffffu;
             #pragma unroll
@@ -278,10 +288,11 @@ void k_sweep64(Sweep64Args a)
     f64x4 clo, chi;
     const int nunits = ntiles * NC;
     if (ntiles > 0) stage(t0, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);      // builtin: the compiler's wait-count bookkeeping sees the drain
     __syncthreads();
+    unsigned long long thr_seen = 0ull;           // shared K-th-best bound, read one tile ahead (drained by the closing wait)
     for (int i = 0; i < ntiles; i++) {
-        const unsigned long long thr_seen = (primary && !DUMP) ? __hip_atomic_load(a.thr_shared + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        const unsigned long long thr_next = (primary && !DUMP) ? __hip_atomic_load(a.thr_shared + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         // resident user factors are indexed af[c * NGC + gl]: the chunk loop must then be unrolled; when each chunk's
         // factors are re-read the loop stays rolled (4x less code and register pressure at 256 factors)
         #pragma unroll(AF_RESIDENT ? NC : 1)
@@ -311,9 +322,10 @@ void k_sweep64(Sweep64Args a)
                 chi = __builtin_amdgcn_mfma_f64_16x16x4f64(b1.y, u.y, chi, 0, 0, 0);
             }
             if (c == NC - 1) do_epi(clo, chi, t0 + i, thr_seen);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                              // the DMA of the next unit has landed
             __syncthreads();
         }
+        thr_seen = thr_next;
     }
     if (DUMP) return;
 

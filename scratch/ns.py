@@ -17,3 +17,12 @@ dt, sw, pr, fi, tm = measure(torch, dist, binding, p, steps, 1, 1, None)
 tf = 2.0 * n * k * m / (sw * 1e-3) / 1e12
 peak = 157.3 if dtype == np.float32 else 78.6
 print(json.dumps({"workload": wl, "users": m, "users_per_s": m * steps / dt, "sweep_ms": sw, "prep_ms": pr, "fin_ms": fi, "TF": tf, "frac": tf / peak, "tm": tm}))
+if os.environ.get("RM_PRINT_STATS"):
+    import ctypes
+    lib = binding.load()
+    lib = lib if hasattr(lib, "rm_debug_stats") else ctypes.CDLL(os.environ["RECOMETRICS_HIP_LIB"])
+    buf = (ctypes.c_ulonglong * 16)()
+    lib.rm_debug_stats(buf, 1)
+    runs = steps + 1
+    names = ["wave_steps", "event_steps", "event_lanes", "hit_cells", "hit_lanes", "merges", "merge_iters", "merge_replacing"]
+    print(json.dumps({nm: buf[i] / runs for i, nm in enumerate(names)}))
