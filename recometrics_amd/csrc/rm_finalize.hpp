@@ -10,13 +10,21 @@
 namespace rm {
 
 constexpr int MAX_PARTS = 128;
+constexpr int FIN_THREADS = 128;      // block size of k_finalize
+constexpr int FIN_TOPV = 64;          // sorted buffer of the largest test values (ideal DCG) per thread
+template <class T> inline size_t finalize_lds_bytes(int K, int n_part) { return (sizeof(T) * (size_t)(K < FIN_TOPV ? K : FIN_TOPV) + 2 * (size_t)n_part) * FIN_THREADS; }
+
+// per-slot result of the rank-histogram walk (k_auc_slots), combined per user by k_finalize
+struct AucPart { unsigned long long sum_ranks; double s1, s2; int nvalid, pad; };
 
 template <class T, class S> struct FinalArgs {     // T = real_t of inputs/outputs, S = score type of the sweep
-    int m, n, K, n_part, req, cumulative, noise, gu;
+    int m, n, K, n_part, req, cumulative, noise, gu, n_slots, debug_stop;
+    const int *slot_user, *slot_chunk;
     const int *train_p, *test_p, *test_i; const T *test_v;
     const int *flags, *user_nslots, *uslot_base, *slot_index;
     const int *gj; const long long *grow;
     const Entry<S> *pl; const PartialStat<S> *pst; const unsigned *hist; const S *pos_score;
+    AucPart *auc_part;           // [n_slots]
     const double *log2tab;
     T *p, *tp, *r, *ap, *tap, *ndcg, *hit, *rr, *roc, *pr;
     Entry<S> *merged;            // [m][K]   final ordered top-K (also the rm_rank_* output)
@@ -47,19 +55,80 @@ template <class S> __device__ __forceinline__ bool ent_before(const Entry<S> &x,
     return x.s > y.s || (x.s == y.s && x.idx < y.idx);
 }
 
+// ROC / PR-AUC ingredients of one slot = one chunk of <= 63 sorted positives of a user (reference :795-865 walks the
+// fully sorted candidate list instead).  Row b of the slot's histogram counts the candidates that rank between positive
+// b - 1 and positive b, so a downward walk yields each positive's 1-based rank in the full ranking.  One thread per slot:
+// the users of a group sit on adjacent threads and each row is one coalesced line; a heavy user's chunks run in parallel
+// instead of back to back on that user's thread.
+//   sum_ranks = sum of the ranks,  s1 = sum 1/rank,  s2 = sum i/rank  (i = 1.. in descending score order inside the chunk).
+// With h0 positives in the higher-scored chunks the chunk adds  h0 * s1 + s2  to sum_i h_i/rank_i; a user with a single
+// chunk gets exactly the reference's left-to-right accumulation.
+template <class T, class S>
+__global__ void k_auc_slots(FinalArgs<T, S> a)
+{
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= a.n_slots) return;
+    const int u = a.slot_user[slot], c = a.slot_chunk[slot];
+    if (a.flags[u] & UF_ONLY_NDCG) return;
+    const int te0 = a.test_p[u], npos = a.test_p[u + 1] - te0;
+    const int GUr = a.gu;
+    const int g = slot / GUr, ul = slot % GUr;
+    const int PLg = (1 << a.gj[g]) - 1;
+    const unsigned *H = a.hist + (a.grow[g] + g) * GUr + ul;
+    const S *PS = a.pos_score + (a.grow[g] + g) * GUr + ul;
+    const int pc = min(POS_CHUNK, npos - c * POS_CHUNK);
+    unsigned long long above = 0, sum_ranks = 0;
+    double s1 = 0, s2 = 0;
+    int nvalid = 0;
+    for (int b = PLg; b >= 1; b--) {
+        above += H[(size_t)b * GUr];
+        const int j = b - 1;
+        if (j >= pc) continue;                                       // padding row above the chunk's positives
+        const S ps = PS[(size_t)j * GUr];
+        if (isinf(ps) && ps > 0) continue;                           // masked by the train row
+        const unsigned long long rank = above + 1;
+        sum_ranks += rank; nvalid++;
+        s1 += 1. / (double)rank;
+        s2 += (double)nvalid / (double)rank;
+        if (a.rank_sorted) a.rank_sorted[te0 + c * POS_CHUNK + j] = (long long)rank;
+    }
+    AucPart r; r.sum_ranks = sum_ranks; r.s1 = s1; r.s2 = s2; r.nvalid = nvalid; r.pad = 0;
+    a.auc_part[slot] = r;
+}
+
+// users that are not evaluated (reference :450-476): NaN in every requested output, empty ranking
+template <class T, class S>
+__global__ void k_finalize_skipped(FinalArgs<T, S> a)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= a.m || !(a.flags[u] & UF_NAN)) return;
+    const int te0 = a.test_p[u], npos = a.test_p[u + 1] - te0;
+    if (a.status) a.status[u] = 1;
+    Entry<S> *M = a.merged + (size_t)u * a.K;
+    for (int i = 0; i < a.K; i++) { M[i].s = (S)qnan<float>(); M[i].idx = -1; }
+    fill_user_nan(a, u);                                            // rank_sorted was zeroed by the host
+}
+
 template <class T, class S>
 __global__ void k_finalize(FinalArgs<T, S> a)
 {
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= a.m) return;
+    // per-thread working arrays live in LDS as columns ([row][thread]): the partial-list cursors and the sorted buffer
+    // of the largest test values are indexed dynamically, which in private memory means a scratch round trip per access
+    extern __shared__ __attribute__((aligned(16))) char fin_smem[];
+    T *topv_base = (T *)fin_smem;                                                     // [min(K, FIN_TOPV)][FIN_THREADS]
+    unsigned short *head_base = (unsigned short *)(fin_smem + sizeof(T) * (a.K < FIN_TOPV ? a.K : FIN_TOPV) * FIN_THREADS);   // [n_part][FIN_THREADS]
+    // One thread per SLOT, not per user: the 32 (16) users of a group sit on adjacent threads, so their reads of the
+    // group's column-major tables (rank histogram, sorted positives: [row][user of the group]) coalesce into one line
+    // per row, and the users of a group have similar row lengths.  Users without a slot are k_finalize_skipped's.
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= a.n_slots || a.slot_chunk[slot] != 0) return;
+    const int u = a.slot_user[slot];
     const int K = a.K, n = a.n;
     const int f = a.flags[u];
     const int te0 = a.test_p[u], npos = a.test_p[u + 1] - te0;
     if (a.status) a.status[u] = 1;
     Entry<S> *M = a.merged + (size_t)u * K;
     for (int i = 0; i < K; i++) { M[i].s = (S)qnan<float>(); M[i].idx = -1; }
-    if (a.rank_sorted) for (int t = 0; t < npos; t++) a.rank_sorted[te0 + t] = 0;
-    if (f & UF_NAN) { fill_user_nan(a, u); return; }
 
     const int ntr = a.train_p[u + 1] - a.train_p[u];
     const int C = n - ntr;
@@ -69,10 +138,10 @@ __global__ void k_finalize(FinalArgs<T, S> a)
     const int NP = a.n_part;
 
     // ---- merge the partial top-K lists (each descending) and the validity stats ----
-    int head[MAX_PARTS];
+    unsigned short *head = head_base + threadIdx.x;               // head[q * FIN_THREADS]: entries of partial list q consumed
     S vmax = -(S)INFINITY, vmin = (S)INFINITY; bool any_nan = false;
     for (int q = 0; q < NP; q++) {
-        head[q] = 0;
+        head[q * FIN_THREADS] = 0;
         const PartialStat<S> ps = a.pst[(size_t)s0 * NP + q];
         vmax = ps.vmax > vmax ? ps.vmax : vmax;
         vmin = ps.vmin < vmin ? ps.vmin : vmin;
@@ -82,11 +151,12 @@ __global__ void k_finalize(FinalArgs<T, S> a)
     for (int i = 0; i < K; i++) {
         int best = -1; Entry<S> be; be.s = 0; be.idx = 0;
         for (int q = 0; q < NP; q++) {
-            if (head[q] >= K) continue;
-            const Entry<S> e = PL[(size_t)q * K + head[q]];
+            const int hq = head[q * FIN_THREADS];
+            if (hq >= K) continue;
+            const Entry<S> e = PL[(size_t)q * K + hq];
             if (best < 0 || ent_before(e, be)) { best = q; be = e; }
         }
-        head[best]++;
+        head[best * FIN_THREADS]++;
         if (be.idx == IDX_EMPTY) { be.idx = -1; be.s = (S)qnan<float>(); }
         M[i] = be;
     }
@@ -102,9 +172,11 @@ __global__ void k_finalize(FinalArgs<T, S> a)
     }
     if (invalid) {
         for (int i = 0; i < K; i++) { M[i].s = (S)qnan<float>(); M[i].idx = -1; }
+        if (a.rank_sorted) for (int t = 0; t < npos; t++) a.rank_sorted[te0 + t] = 0;     // k_auc_slots ranked them already
         fill_user_nan(a, u); return;
     }
     if (a.status) a.status[u] = 0;
+    if (a.debug_stop == 1) return;
 
     const int *ti = a.test_i + te0;
     const T *tv = a.test_v ? a.test_v + te0 : nullptr;
@@ -160,6 +232,7 @@ __global__ void k_finalize(FinalArgs<T, S> a)
         }
     }
 
+    if (a.debug_stop == 2) return;
     // ---- NaN overrides (:750-788) ----
     if (kleqn) {
         if (!cum) {
@@ -186,38 +259,26 @@ __global__ void k_finalize(FinalArgs<T, S> a)
     } else if (a.req & (RQ_ROC | RQ_PR)) {
         const int nsl = a.user_nslots[u];
         unsigned long long sum_ranks = 0; int h = 0; double ap_full = 0;
-        for (int c = nsl - 1; c >= 0; c--) {                       // chunks hold ascending scores: walk them downwards
-            const int slot = a.slot_index[base + c];
-            const int GUr = a.gu;
-            const int g = slot / GUr, ul = slot % GUr;
-            const int PLg = (1 << a.gj[g]) - 1;
-            const unsigned *H = a.hist + (a.grow[g] + g) * GUr + ul;
-            const S *PS = a.pos_score + (a.grow[g] + g) * GUr + ul;
-            const int pc = min(POS_CHUNK, npos - c * POS_CHUNK);
-            unsigned long long above = 0;                           // candidates scored above positive j of the chunk
-            for (int b = PLg; b > pc; b--) above += H[(size_t)b * GUr];
-            for (int j = pc - 1; j >= 0; j--) {
-                above += H[(size_t)(j + 1) * GUr];
-                if (isinf(PS[(size_t)j * GUr]) && PS[(size_t)j * GUr] > 0) continue;   // masked by the train row
-                const unsigned long long rank = above + 1;
-                sum_ranks += rank; h++;
-                ap_full += (double)h / (double)rank;
-                if (a.rank_sorted) a.rank_sorted[te0 + c * POS_CHUNK + j] = (long long)rank;
-            }
+        for (int c = nsl - 1; c >= 0; c--) {                       // chunks hold ascending scores: combine them downwards
+            const AucPart r = a.auc_part[a.slot_index[base + c]];
+            sum_ranks += r.sum_ranks;
+            ap_full = nsl == 1 ? r.s2 : ap_full + ((double)h * r.s1 + r.s2);
+            h += r.nvalid;
         }
         const unsigned long long P = (unsigned long long)npos, Nneg = (unsigned long long)C - P;
         if (a.roc) a.roc[u] = (T)(1. - (double)(sum_ranks - (P * (P + 1)) / 2) / (double)(P * Nneg));
         if (a.pr) a.pr[u] = (T)(ap_full / (double)npos);
     }
 
+    if (a.debug_stop == 3) return;
     // ---- NDCG normalisation (:868-961) ----
     if (a.ndcg) {
         const int L = K < npos ? K : npos;
         // the ideal DCG needs the L largest test values in descending order: ONE pass over the row keeping a small
         // sorted buffer (values only -- equal values are interchangeable in the sums); rows longer than the buffer's
         // K fall back to repeated selection
-        constexpr int TOPV = 64;
-        T topv[TOPV];
+        constexpr int TOPV = FIN_TOPV;
+        T *topv = topv_base + threadIdx.x;                         // topv[i * FIN_THREADS]
         bool has_nan_val = false;
         const bool buffered = L <= TOPV;
         auto pick_next = [&](bool have_prev, T pv, int pi, T &ov, int &oi) {
@@ -231,14 +292,23 @@ __global__ void k_finalize(FinalArgs<T, S> a)
         };
         if (buffered) {
             int cnt = 0;
-            for (int t = 0; t < npos; t++) {
-                const T x = tv[t];
-                has_nan_val |= x != x;
-                if (cnt < L || x > topv[L - 1]) {
-                    int j = cnt < L ? cnt : L - 1;
-                    while (j > 0 && topv[j - 1] < x) { topv[j] = topv[j - 1]; j--; }
-                    topv[j] = x;
-                    cnt = cnt < L ? cnt + 1 : cnt;
+            T kth = 0;                                               // topv[L - 1] once the buffer is full
+            for (int t0 = 0; t0 < npos; t0 += 8) {                 // eight loads in flight: a heavy user's row is thousands long
+                T xb[8];
+                #pragma unroll
+                for (int q = 0; q < 8; q++) xb[q] = t0 + q < npos ? tv[t0 + q] : (T)0;
+                #pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    if (t0 + q >= npos) break;
+                    const T x = xb[q];
+                    has_nan_val |= x != x;
+                    if (cnt < L || x > kth) {
+                        int j = cnt < L ? cnt : L - 1;
+                        while (j > 0 && topv[(j - 1) * FIN_THREADS] < x) { topv[j * FIN_THREADS] = topv[(j - 1) * FIN_THREADS]; j--; }
+                        topv[j * FIN_THREADS] = x;
+                        cnt = cnt < L ? cnt + 1 : cnt;
+                        if (cnt == L) kth = topv[(L - 1) * FIN_THREADS];
+                    }
                 }
             }
         } else {
@@ -247,11 +317,11 @@ __global__ void k_finalize(FinalArgs<T, S> a)
         // value i of the descending order
         T pv = 0; int pi = -1; bool hp = false;
         auto next_value = [&](int i) -> T {
-            if (buffered) return topv[i];
+            if (buffered) return topv[i * FIN_THREADS];
             T x; int xi; pick_next(hp, pv, pi, x, xi); hp = true; pv = x; pi = xi; return x;
         };
         T vmaxv = 0, vlast = 0;
-        if (buffered) { vmaxv = topv[0]; vlast = topv[L - 1]; }
+        if (buffered) { vmaxv = topv[0]; vlast = topv[(L - 1) * FIN_THREADS]; }
         else {
             for (int i = 0; i < L; i++) { const T x = next_value(i); if (i == 0) vmaxv = x; vlast = x; }
             hp = false; pv = 0; pi = -1;

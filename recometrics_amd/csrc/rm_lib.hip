@@ -198,7 +198,7 @@ void run(const Call<T> &c, hipStream_t stream)
     HIP_CHECK(hipMemsetAsync(plan, 0, sizeof(Plan), stream));
     ClassifyArgs ca{m, n, K, c.train_p, c.test_p, req, c.cold ? 1 : 0, min_items_pool, min_pos_test, want_auc ? 1 : 0,
                     flags, user_nslots, plan};
-    hipLaunchKernelGGL(k_classify, dim3(cdiv(m, 256)), dim3(256), 0, stream, ca);
+    hipLaunchKernelGGL(k_classify, dim3(cdiv(m, 1024)), dim3(1024), 0, stream, ca);
     hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, user_nslots, uslot_base, m, &plan->n_slots);
     hipLaunchKernelGGL(k_plan_classes, dim3(1), dim3(1), 0, stream, plan, GU);
     const long long slot_bound = (long long)m + c.nnz_test / POS_CHUNK + 1;
@@ -210,7 +210,7 @@ void run(const Call<T> &c, hipStream_t stream)
     int *gj = (int *)ws.get("gj", sizeof(int) * (size_t)group_bound);
     long long *grow = (long long *)ws.get("grow", sizeof(long long) * (size_t)group_bound);
     AssignArgs aa{m, c.test_p, flags, user_nslots, uslot_base, want_auc ? 1 : 0, plan, slot_user, slot_chunk, slot_index, slot_j};
-    hipLaunchKernelGGL(k_assign_slots, dim3(cdiv(m, 256)), dim3(256), 0, stream, aa);
+    hipLaunchKernelGGL(k_assign_slots, dim3(cdiv(m, ASSIGN_THREADS)), dim3(ASSIGN_THREADS), 0, stream, aa);
     const long long block_bound = group_bound / GROUPS_PER_BLOCK + 2;
     int *blk_j = (int *)ws.get("blk_j", sizeof(int) * (size_t)block_bound);
     int *blk_rows = (int *)ws.get("blk_rows", sizeof(int) * (size_t)block_bound);
@@ -291,7 +291,7 @@ void run(const Call<T> &c, hipStream_t stream)
             HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(unsigned) * (size_t)rows * GU, stream));
             PosArgs<T> pa{m, n, k, c.A, c.lda, c.B, c.ldb, c.train_p, c.train_i, c.test_p, c.test_i,
                           flags, user_nslots, uslot_base, slot_index, grow, pos_tmp, pos_order, pos_score, pos_item, GU};
-            hipLaunchKernelGGL(k_pos_scores<T>, dim3(cdiv((long long)m * WAVE, 256)), dim3(256), 0, stream, pa);
+            hipLaunchKernelGGL(k_pos_scores<T>, dim3(cdiv((long long)n_slots * WAVE, 256)), dim3(256), 0, stream, pa, slot_user, slot_chunk, n_slots);
             hipLaunchKernelGGL(k_pos_place<T>, dim3(cdiv((long long)n_slots * WAVE, 256)), dim3(256), 0, stream, pa, slot_user, slot_chunk, n_slots);
         }
 
@@ -335,6 +335,7 @@ void run(const Call<T> &c, hipStream_t stream)
 
     long long *rank_sorted = nullptr;
     if (c.pos_rank) rank_sorted = (long long *)ws.get("rank_sorted", sizeof(long long) * (size_t)std::max<long long>(c.nnz_test, 1));
+    if (rank_sorted) HIP_CHECK(hipMemsetAsync(rank_sorted, 0, sizeof(long long) * (size_t)std::max<long long>(c.nnz_test, 1), stream));
     FinalArgs<T, T> fa{};
     fa.m = m; fa.n = n; fa.K = K; fa.n_part = n_part; fa.req = req; fa.cumulative = c.cumulative ? 1 : 0; fa.noise = c.noise ? 1 : 0; fa.gu = GU;
     fa.train_p = c.train_p; fa.test_p = c.test_p; fa.test_i = c.test_i; fa.test_v = c.test_v;
@@ -343,7 +344,18 @@ void run(const Call<T> &c, hipStream_t stream)
     fa.p = c.out[0]; fa.tp = c.out[1]; fa.r = c.out[2]; fa.ap = c.out[3]; fa.tap = c.out[4];
     fa.ndcg = c.out[5]; fa.hit = c.out[6]; fa.rr = c.out[7]; fa.roc = c.out[8]; fa.pr = c.out[9];
     fa.merged = merged; fa.rank_sorted = rank_sorted; fa.status = c.status;
-    hipLaunchKernelGGL((k_finalize<T, T>), dim3(cdiv(m, 128)), dim3(128), 0, stream, fa);
+    fa.n_slots = n_slots; fa.slot_user = slot_user; fa.slot_chunk = slot_chunk;
+    { const char *ds = getenv("RM_DEBUG_FIN_STOP"); fa.debug_stop = ds ? atoi(ds) : 0; }
+    hipLaunchKernelGGL((k_finalize_skipped<T, T>), dim3(cdiv(m, 256)), dim3(256), 0, stream, fa);
+    if (n_slots > 0) {
+        if (want_auc) {
+            fa.auc_part = (AucPart *)ws.get("auc_part", sizeof(AucPart) * (size_t)n_slots);
+            hipLaunchKernelGGL((k_auc_slots<T, T>), dim3(cdiv(n_slots, 256)), dim3(256), 0, stream, fa);
+        }
+        const size_t fin_lds = finalize_lds_bytes<T>(K, n_part);
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_finalize<T, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));
+        hipLaunchKernelGGL((k_finalize<T, T>), dim3(cdiv(n_slots, FIN_THREADS)), dim3(FIN_THREADS), fin_lds, stream, fa);
+    }
     HIP_CHECK(hipGetLastError());
     if (c.topk_idx)
         hipLaunchKernelGGL(k_export_rank<T>, dim3(cdiv((long long)m * K, 256)), dim3(256), 0, stream, m, K, merged, c.topk_idx, c.topk_score);

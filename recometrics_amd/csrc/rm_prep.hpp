@@ -51,16 +51,22 @@ __global__ void k_classify(ClassifyArgs a)
             myclass = 0;
         }
     }
-    // one atomic per wave and class instead of one per user (7 hot addresses otherwise)
+    // counts are aggregated per block in LDS, then one global atomic per block and class (the counters share a line)
+    __shared__ int blk_count[MAX_J + 2];                          // [MAX_J + 1] = evaluated users
+    if (threadIdx.x <= MAX_J + 1) blk_count[threadIdx.x] = 0;
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const unsigned long long act = __ballot(!isnan_user);
-    if (act && lane == __ffsll((long long)act) - 1) atomicAdd(&a.plan->n_active, __popcll(act));
+    if (act && lane == __ffsll((long long)act) - 1) atomicAdd(&blk_count[MAX_J + 1], __popcll(act));
     for (int j = 0; j <= MAX_J; j++) {
         const unsigned long long mk = __ballot(myclass == j);
-        if (mk && lane == __ffsll((long long)mk) - 1) atomicAdd(&a.plan->class_count[j], __popcll(mk));
+        if (mk && lane == __ffsll((long long)mk) - 1) atomicAdd(&blk_count[j], __popcll(mk));
     }
-    if (nfull) atomicAdd(&a.plan->class_count[MAX_J], nfull);
+    if (nfull) atomicAdd(&blk_count[MAX_J], nfull);
     if (live) { a.flags[u] = f; a.user_nslots[u] = nsl; }
+    __syncthreads();
+    if (threadIdx.x <= MAX_J && blk_count[threadIdx.x]) atomicAdd(&a.plan->class_count[threadIdx.x], blk_count[threadIdx.x]);
+    if (threadIdx.x == MAX_J + 1 && blk_count[MAX_J + 1]) atomicAdd(&a.plan->n_active, blk_count[MAX_J + 1]);
 }
 
 // exclusive scan of int array by ONE block of 1024 threads (m <= 2^31; a few hundred iterations at m = 1M)
@@ -113,35 +119,47 @@ struct AssignArgs {
     unsigned char *slot_j;
 };
 
-// scatter every (user, chunk) into its depth class; order inside a class is arbitrary (results do not depend on it)
-__global__ void k_assign_slots(AssignArgs a)
+// scatter every (user, chunk) into its depth class; order inside a class is arbitrary (results do not depend on it).
+// Cursor bumps are aggregated per block in LDS (ASSIGN_THREADS users): the 8 class cursors share one cache line, and one
+// returning atomic per wave and class serialised the whole kernel behind that line.
+constexpr int ASSIGN_THREADS = 1024;
+__global__ __launch_bounds__(ASSIGN_THREADS) void k_assign_slots(AssignArgs a)
 {
+    __shared__ int blk_count[MAX_J + 1], blk_base[MAX_J + 1];
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    if (threadIdx.x <= MAX_J) blk_count[threadIdx.x] = 0;
+    __syncthreads();
     const int nsl = u < a.m ? a.user_nslots[u] : 0;
     const int npos = nsl ? a.test_p[u + 1] - a.test_p[u] : 0;
     const bool auc_user = nsl && a.want_auc && !(a.flags[u] & UF_ONLY_NDCG);
-    // last (or only) chunk of every user: one cursor bump per wave and class
-    int jlast = -1;
+    // last (or only) chunk of every user: position inside the block's share of its class
+    int jlast = -1, in_blk = 0;
     if (nsl) jlast = auc_user ? chunk_depth(min(POS_CHUNK, npos - (nsl - 1) * POS_CHUNK)) : 0;
     for (int j = 0; j <= MAX_J; j++) {
         const unsigned long long mk = __ballot(jlast == j);
         if (!mk) continue;
         const int leader = __ffsll((long long)mk) - 1;
         int base = 0;
-        if (lane == leader) base = atomicAdd(&a.plan->class_cursor[j], __popcll(mk));
+        if (lane == leader) base = atomicAdd(&blk_count[j], __popcll(mk));
         base = __shfl(base, leader);
-        if (jlast == j) {
-            const int pos = a.plan->class_offset[j] + base + __popcll(mk & ((1ull << lane) - 1));
-            a.slot_user[pos] = u;
-            a.slot_chunk[pos] = nsl - 1;
-            a.slot_j[pos] = (unsigned char)j;
-            a.slot_index[a.uslot_base[u] + nsl - 1] = pos;
-        }
+        if (jlast == j) in_blk = base + __popcll(mk & ((1ull << lane) - 1));
     }
-    // the full 63-positive chunks of heavy users (rare)
+    // the full 63-positive chunks of heavy users (rare): nsl - 1 consecutive positions each in the deepest class
+    int full_at = 0;
+    if (nsl > 1) full_at = atomicAdd(&blk_count[MAX_J], nsl - 1);
+    __syncthreads();
+    if (threadIdx.x <= MAX_J && blk_count[threadIdx.x]) blk_base[threadIdx.x] = atomicAdd(&a.plan->class_cursor[threadIdx.x], blk_count[threadIdx.x]);
+    __syncthreads();
+    if (nsl) {
+        const int pos = a.plan->class_offset[jlast] + blk_base[jlast] + in_blk;
+        a.slot_user[pos] = u;
+        a.slot_chunk[pos] = nsl - 1;
+        a.slot_j[pos] = (unsigned char)jlast;
+        a.slot_index[a.uslot_base[u] + nsl - 1] = pos;
+    }
     for (int c = 0; c < nsl - 1; c++) {
-        const int pos = a.plan->class_offset[MAX_J] + atomicAdd(&a.plan->class_cursor[MAX_J], 1);
+        const int pos = a.plan->class_offset[MAX_J] + blk_base[MAX_J] + full_at + c;
         a.slot_user[pos] = u;
         a.slot_chunk[pos] = c;
         a.slot_j[pos] = (unsigned char)MAX_J;
@@ -341,22 +359,23 @@ __device__ __forceinline__ bool in_sorted_row(const int *row, int len, int item)
     return lo < len && row[lo] == item;
 }
 
-// one wavefront per user
+// one wavefront per SLOT (= up to 63 test entries of one user, by row position; a heavy user's chunks run in parallel)
 template <class T>
-__global__ void k_pos_scores(PosArgs<T> a)
+__global__ void k_pos_scores(PosArgs<T> a, const int *slot_user, const int *slot_chunk, int n_slots)
 {
-    const int u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (u >= a.m || !(a.flags[u] & UF_ACTIVE) || (a.flags[u] & UF_ONLY_NDCG)) return;
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (w >= n_slots) return;
+    const int u = slot_user[w], c0 = slot_chunk[w];
+    if (a.flags[u] & UF_ONLY_NDCG) return;
     const int te0 = a.test_p[u], te1 = a.test_p[u + 1];
     const int tr0 = a.train_p[u], ntr = a.train_p[u + 1] - tr0;
-    const T *Au = a.A + (size_t)u * a.lda;
-    for (int e = te0 + lane; e < te1; e += WAVE) {
-        const int item = a.test_i[e];
-        T s;
-        if (ntr && in_sorted_row(a.train_i + tr0, ntr, item)) s = (T)__int_as_float(0x7f800000);
-        else s = chain_dot<T>(Au, a.B + (size_t)item * a.ldb, a.k);
-        a.pos_tmp[e] = s;
-    }
+    const int e = te0 + c0 * POS_CHUNK + lane;
+    if (lane >= POS_CHUNK || e >= te1) return;
+    const int item = a.test_i[e];
+    T s;
+    if (ntr && in_sorted_row(a.train_i + tr0, ntr, item)) s = (T)__int_as_float(0x7f800000);
+    else s = chain_dot<T>(a.A + (size_t)u * a.lda, a.B + (size_t)item * a.ldb, a.k);
+    a.pos_tmp[e] = s;
 }
 
 // One wavefront per SLOT (= up to 63 test entries of one user, by row position): rank of each of them among ALL the
