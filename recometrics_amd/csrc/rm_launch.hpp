@@ -18,6 +18,7 @@ struct SweepArgs {
     int check_nan;                        // 0 when the host proved all scores finite (skips the NaN scan)
     int buffered_lists;                   // HBM lists: 1 = append buffer + compaction (large K), 0 = replace-the-minimum
     int pend_cap, pend_off;               // LDS lists: per-lane pending buffers of pend_cap keys at byte offset pend_off (0 = none)
+    int sync_off;                         // byte offset of the split-barrier counter in LDS
     const float4 *Ap, *Bp;
     const int *slot_user, *slot_chunk;
     const int *train_p, *train_i;

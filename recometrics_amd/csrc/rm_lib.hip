@@ -124,6 +124,7 @@ template <> struct Prec<float> {
     static long long users_units(int groups, int NG) { return (long long)groups * NG * 2 * GU; }
     static constexpr bool has_pending = true;
     static void set_pending(SweepArgs &sa, int cap, int off) { sa.pend_cap = cap; sa.pend_off = off; }
+    static void set_sync(SweepArgs &sa, int off) { sa.sync_off = off; }
 };
 template <> struct Prec<double> {
     static constexpr int GU = GROUP_USERS64;
@@ -135,6 +136,7 @@ template <> struct Prec<double> {
     static long long users_units(int groups, int NG) { return (long long)groups * NG * 4 * GU; }
     static constexpr bool has_pending = false;
     static void set_pending(Sweep64Args &, int, int) {}
+    static void set_sync(Sweep64Args &, int) {}
 };
 
 inline void check_launch(int rc)
@@ -260,8 +262,10 @@ void run(const Call<T> &c, hipStream_t stream)
         const size_t head = lds_b + (with_lists ? lds_lists : 0);
         return (want_auc ? (head + tbytes - 1) / tbytes * tbytes : head) + lds_auc;
     };
-    const bool list_in_lds = lds_need(true) <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS");
+    const bool list_in_lds = lds_need(true) + 16 <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS");
     size_t lds_total = lds_need(list_in_lds);
+    const size_t sync_off = lds_total;                     // split-barrier counter of the sweep
+    lds_total += 16;
     // fp32 LDS lists: per-lane pending buffers behind everything else when 8 (or 4) keys per lane still fit
     int pend_cap = 0; const size_t pend_off = lds_total;
     if (P::has_pending && list_in_lds && !getenv("RM_DEBUG_NO_PENDING"))
@@ -315,6 +319,7 @@ void run(const Call<T> &c, hipStream_t stream)
         sa.train_p = c.train_p; sa.train_i = c.train_i; sa.gj = gj; sa.grow = grow;
         sa.pos_score = pos_score; sa.pos_item = pos_item; sa.hist = hist; sa.glists = glists; sa.pl = pl; sa.pst = pst; sa.dump = nullptr;
         P::set_pending(sa, pend_cap, (int)pend_off);
+        P::set_sync(sa, (int)sync_off);
 
         HIP_CHECK(hipEventRecord(g_ev[1], stream));
         dispatch_sweep(want_auc, false, list_in_lds, NG, dim3(n_blocks), lds_total, stream, sa);
@@ -483,7 +488,8 @@ void debug_scores(const T *A, size_t lda, const T *B, size_t ldb, int m, int n, 
     sa.tiles_total = tiles_total; sa.jmax = 0; sa.check_nan = 1; sa.Ap = (decltype(sa.Ap))Ap; sa.Bp = (decltype(sa.Bp))Bp;
     sa.slot_user = slot_user; sa.slot_chunk = zeros; sa.train_p = zeros; sa.train_i = zeros; sa.gj = zeros + m + 1; sa.grow = grow;
     sa.glists = glists; sa.dump = dump;
-    dispatch_sweep(false, true, false, NG, dim3(n_ublocks), P::lds_b(NG), stream, sa);
+    P::set_sync(sa, (int)P::lds_b(NG));
+    dispatch_sweep(false, true, false, NG, dim3(n_ublocks), P::lds_b(NG) + 16, stream, sa);
     HIP_CHECK(hipMemcpyAsync(out, dump, sizeof(T) * (size_t)m * n, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
 }

@@ -450,13 +450,22 @@ void k_sweep(SweepArgs a)
     // two waves of a SIMD run in phase: both chains back to back, then both epilogues sharing the VALU at full rate. ----
     f32x16 acc;
     const int nunits = ntiles * NC;
+    // Synchronisation between the 8 waves is a SPLIT barrier on an LDS counter, not s_barrier: a wave "arrives" for
+    // unit u once it has issued its last MFMA of the unit (its LDS reads of that buffer are done) and its share of the
+    // next unit's DMA has landed; it only "waits" -- for all 8 arrivals of unit u -- right before it touches the
+    // buffers again at the start of unit u + 1.  The whole epilogue sits between the two, so a wave whose epilogue
+    // runs long (train-mask walk, top-K merge, tie path) delays the others only when it is a full epilogue behind,
+    // instead of at every tile.  Arrivals of unit u + 1 cannot start before all of unit u are in, so one monotonic
+    // counter is unambiguous: all arrived for unit u  <=>  counter >= 8 (u + 1).
+    LdsU32Ptr arrive = (LdsU32Ptr)(smem + a.sync_off);
+    if (tid == 0) *arrive = 0u;
     if (ntiles > 0) stage(t0 * NC, 0);
     // vmcnt(0) through the builtin (not asm) so that the compiler's own wait-count bookkeeping sees the drain: every
     // load it issued before this point is known complete and needs no further wait inside the loop.
     __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);
     __syncthreads();
-    // the shared K-th-best bound is read one tile ahead: its load is drained by the end-of-step wait, never by a
-    // wait in the middle of a step (which would also wait for the tile prefetch)
+    // the shared K-th-best bound is read one tile ahead: its load is drained by the wait after the next MFMA phase,
+    // never by a wait in the middle of an epilogue (which would also wait for the tile prefetch)
     auto load_thr = [&]() -> unsigned {
 #ifdef RM_ABL_NO_THRSEEN
         return 0u;
@@ -469,18 +478,28 @@ void k_sweep(SweepArgs a)
         unsigned thr_next = thr_seen;
         for (int c = 0; c < NC; c++) {
             const int unit = i * NC + c;
+#if !defined(RM_FULL_BARRIER) && !defined(RM_ABL_NO_BARRIER)
+            if (unit > 0) {                                                       // wait half of the split barrier
+                const unsigned target = 8u * (unsigned)unit;
+                while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+            }
+#endif
 #ifndef RM_ABL_NO_STAGE
-            if (unit + 1 < nunits) stage(t0 * NC + unit + 1, (unit + 1) & 1);   // that buffer was last read one step ago
+            if (unit + 1 < nunits) stage(t0 * NC + unit + 1, (unit + 1) & 1);   // that buffer was last read one unit ago
 #endif
             if (c == 0) thr_next = load_thr();
 #ifndef RM_ABL_NO_MFMA
             do_mfma(acc, unit & 1, c);
 #endif
+#if !defined(RM_FULL_BARRIER) && !defined(RM_ABL_NO_BARRIER)
+            __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                              // arrive half: the next unit's DMA share has landed
+            if (lane == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 #ifndef RM_ABL_NO_EPI
             if (c == NC - 1) do_epi(acc, t0 + i, thr_seen);
 #endif
+#if defined(RM_FULL_BARRIER)
             __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                              // the DMA of the next unit has landed
-#ifndef RM_ABL_NO_BARRIER
             __syncthreads();
 #endif
         }
