@@ -40,6 +40,7 @@ struct Sweep64Args {
     int jmax;
     int check_nan;
     int buffered_lists;
+    int sync_off;                         // byte offset of the split-barrier counter in LDS
     const f64x2 *Ap, *Bp;
     const int *slot_user, *slot_chunk;
     const int *train_p, *train_i;

@@ -136,7 +136,7 @@ template <> struct Prec<double> {
     static long long users_units(int groups, int NG) { return (long long)groups * NG * 4 * GU; }
     static constexpr bool has_pending = false;
     static void set_pending(Sweep64Args &, int, int) {}
-    static void set_sync(Sweep64Args &, int) {}
+    static void set_sync(Sweep64Args &sa, int off) { sa.sync_off = off; }
 };
 
 inline void check_launch(int rc)

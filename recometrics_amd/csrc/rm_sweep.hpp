@@ -174,11 +174,10 @@ void k_sweep(SweepArgs a)
     // user factors -> registers (packed: [group][g][h][32][4 floats])
     float4 af[NG];
     const float4 *af_src = a.Ap + ((size_t)(group_ok ? group : 0) * NGT * 2 + h) * GROUP_USERS + ul;      // + g * 2 * GROUP_USERS
-    if (AF_RESIDENT) {
-        #pragma unroll
-        for (int g = 0; g < NG; g++)
-            af[g] = group_ok ? af_src[(size_t)g * 2 * GROUP_USERS] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    // resident factors, or chunk 0 of a streamed axis (every later chunk is prefetched by do_mfma)
+    #pragma unroll
+    for (int g = 0; g < NG; g++)
+        af[g] = (group_ok || !AF_RESIDENT) ? af_src[(size_t)g * 2 * GROUP_USERS] : make_float4(0.f, 0.f, 0.f, 0.f);
 
     // top-K list of this wave, owned by the lanes with h == 0.  LDS: [K][32 users], unsorted, replace-the-minimum.
     // HBM (lists that do not fit LDS): per user an append buffer of 2K + 32 entries + wave-cooperative compaction.
@@ -275,21 +274,23 @@ void k_sweep(SweepArgs a)
     // ---- MFMA: 32 items (registers) x 32 users (lanes), k in index order ----
     auto do_mfma = [&](f32x16 &acc, int buf, int chunk) {
         const float4 *bb = ldsB + buf * BUF_F4 + h * TILE_ITEMS + sub * 32 + ul;
-        if (!AF_RESIDENT) {
-            #pragma unroll
-            for (int g = 0; g < NG; g++) af[g] = af_src[(size_t)(chunk * NG + g) * 2 * GROUP_USERS];
-        }
         if (chunk == 0) {
             #pragma unroll
             for (int r = 0; r < 16; r++) acc[r] = 0.f;
         }
+        // streamed factor axis: as soon as the four MFMAs of a factor group are issued its registers are free, and the
+        // same group of the NEXT chunk is loaded into them -- a whole MFMA phase ahead of its use, drained by the
+        // wait at the arrive point, so the L2 latency of the user factors is never in front of a matrix instruction
+        const int next_chunk = chunk + 1 == NC ? 0 : chunk + 1;
         #pragma unroll
         for (int g = 0; g < NG; g++) {
             const float4 b = bb[g * 2 * TILE_ITEMS];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, af[g].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, af[g].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, af[g].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, af[g].w, acc, 0, 0, 0);
+            const float4 u = af[g];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, u.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, u.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, u.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, u.w, acc, 0, 0, 0);
+            if (!AF_RESIDENT) af[g] = af_src[(size_t)(next_chunk * NG + g) * 2 * GROUP_USERS];
         }
     };
 

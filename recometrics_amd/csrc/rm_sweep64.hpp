@@ -122,17 +122,16 @@ void k_sweep64(Sweep64Args a)
     }
 
     // user factors -> registers: [group][g][q][16 users][2 doubles].  Up to 128 factors (64 VGPRs) they stay resident
-    // for the whole sweep; beyond that each 64-factor chunk is re-read from L2 when its turn comes.
+    // for the whole sweep; beyond that each 64-factor chunk is re-read from L2 one chunk ahead of its turn.
     constexpr bool AF_RESIDENT = NGT <= 16;
     constexpr int NAF = AF_RESIDENT ? NGT : NGC;
     f64x2 af[NAF];
     const f64x2 *af_src = a.Ap + ((size_t)(group_ok ? group : 0) * NGT * 4 + q) * GU + ul;     // + g * 4 * GU
-    if (AF_RESIDENT) {
-        #pragma unroll
-        for (int g = 0; g < NGT; g++) {
-            f64x2 z; z.x = 0; z.y = 0;
-            af[g] = group_ok ? af_src[(size_t)g * 4 * GU] : z;
-        }
+    // resident factors, or chunk 0 of a streamed axis (every later chunk is prefetched inside the MFMA loop)
+    #pragma unroll
+    for (int g = 0; g < NAF; g++) {
+        f64x2 z; z.x = 0; z.y = 0;
+        af[g] = (group_ok || !AF_RESIDENT) ? af_src[(size_t)g * 4 * GU] : z;
     }
 
     // top-K list owned by the q == 0 lane of the user: LDS [K][16 users] replace-the-minimum, or HBM append buffer +
@@ -287,6 +286,11 @@ void k_sweep64(Sweep64Args a)
     // run in phase (MFMA chunks, then the tile's epilogue), as in the fp32 sweep. ----
     f64x4 clo, chi;
     const int nunits = ntiles * NC;
+    // split barrier on an LDS arrival counter (see the fp32 sweep): arrive after the unit's last MFMA, wait before the
+    // next unit touches the buffers; the epilogue in between absorbs the skew between waves
+    typedef __attribute__((address_space(3))) unsigned *LdsSyncPtr;
+    LdsSyncPtr arrive = (LdsSyncPtr)(smem + a.sync_off);
+    if (tid == 0) *arrive = 0u;
     if (ntiles > 0) stage(t0, 0, 0);
     __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);      // builtin: the compiler's wait-count bookkeeping sees the drain
     __syncthreads();
@@ -299,15 +303,15 @@ void k_sweep64(Sweep64Args a)
         for (int c = 0; c < NC; c++) {
             const int unit = i * NC + c;
             const int buf = unit & 1;
+            if (unit > 0) {                                                       // wait half of the split barrier
+                const unsigned target = 8u * (unsigned)unit;
+                while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+            }
             if (unit + 1 < nunits) {
                 const int nu = unit + 1;
                 stage(t0 + nu / NC, nu % NC, nu & 1);
             }
             const f64x2 *bb = ldsB + buf * BUF_D2 + q * TILE_ITEMS + sub * 32 + ul;
-            if (!AF_RESIDENT) {
-                #pragma unroll
-                for (int gl = 0; gl < NGC; gl++) af[gl] = af_src[(size_t)(c * NGC + gl) * 4 * GU];
-            }
             if (c == 0) {
                 #pragma unroll
                 for (int r = 0; r < 4; r++) { clo[r] = 0.; chi[r] = 0.; }
@@ -320,10 +324,13 @@ void k_sweep64(Sweep64Args a)
                 chi = __builtin_amdgcn_mfma_f64_16x16x4f64(b1.x, u.x, chi, 0, 0, 0);
                 clo = __builtin_amdgcn_mfma_f64_16x16x4f64(b0.y, u.y, clo, 0, 0, 0);
                 chi = __builtin_amdgcn_mfma_f64_16x16x4f64(b1.y, u.y, chi, 0, 0, 0);
+                // streamed axis: the group's registers are free once its MFMAs are issued -> load the same group of the
+                // next chunk into them, a whole MFMA phase ahead of its use (drained by the wait below)
+                if (!AF_RESIDENT) af[gl] = af_src[(size_t)((c + 1 == NC ? 0 : c + 1) * NGC + gl) * 4 * GU];
             }
+            __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                              // arrive half: the next unit's DMA share has landed
+            if (lane == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (c == NC - 1) do_epi(clo, chi, t0 + i, thr_seen);
-            __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                              // the DMA of the next unit has landed
-            __syncthreads();
         }
         thr_seen = thr_next;
     }
