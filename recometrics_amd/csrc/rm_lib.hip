@@ -146,7 +146,8 @@ inline void check_launch(int rc)
 }
 inline void dispatch_sweep(bool auc, bool dump, bool llds, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa)
 {
-    check_launch(launch_sweep32(auc, dump, llds, NG, grid, lds, stream, sa));
+    // list mode of the fp32 sweep (rm_sweep.hpp): 0 = LDS, 1 = HBM replace-the-minimum (K <= 32), 2 = HBM append buffers
+    check_launch(launch_sweep32(auc, dump, llds ? 0 : (sa.buffered_lists ? 2 : 1), NG, grid, lds, stream, sa));
 }
 inline void dispatch_sweep(bool auc, bool dump, bool llds, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa)
 {
@@ -266,11 +267,15 @@ void run(const Call<T> &c, hipStream_t stream)
     size_t lds_total = lds_need(list_in_lds);
     const size_t sync_off = lds_total;                     // split-barrier counter of the sweep
     lds_total += 16;
-    // fp32 LDS lists: per-lane pending buffers behind everything else when 8 (or 4) keys per lane still fit
+    // fp32: per-lane pending buffers for top-K candidates behind everything else when 4..8 keys per lane still fit
     int pend_cap = 0; const size_t pend_off = lds_total;
-    if (P::has_pending && list_in_lds && !getenv("RM_DEBUG_NO_PENDING"))
-        for (int cap : {8, 4})
-            if (lds_total + 8ull * cap * WAVE * 8 <= LDS_LIMIT) { pend_cap = cap; lds_total += 8ull * cap * WAVE * 8; break; }
+    // (not for the append-buffer lists of K > 32: their appends are already single stores)
+    if (P::has_pending && (list_in_lds || K <= 32) && !getenv("RM_DEBUG_NO_PENDING")) {
+        const size_t per_key = 8ull * WAVE * 8;                                   // one key per lane, 8 waves
+        pend_cap = (int)std::min<size_t>(8, (LDS_LIMIT - lds_total) / per_key);
+        if (pend_cap < 4) pend_cap = 0;
+        lds_total += pend_cap * per_key;
+    }
 
     Entry<T> *merged = (Entry<T> *)ws.get("merged", sizeof(Entry<T>) * (size_t)m * K);
     T *pos_score = nullptr; unsigned *hist = nullptr; int *pos_order = nullptr, *pos_item = nullptr;

@@ -107,10 +107,18 @@ __device__ unsigned long long g_stats[16];
 #define RM_STAT(i, x) do {} while (0)
 #endif
 
-template <int NGT, bool AUC, bool DUMP, bool LLDS>
+// LMODE = where a wave's top-K lists live: LM_LDS replace-the-minimum lists of packed keys in LDS; LM_HBM the same scheme
+// in HBM (lists that do not fit LDS, K <= 32); LM_HBM_APPEND per-user append buffers in HBM with wave-cooperative
+// compaction (K > 32).  A template parameter, not a run-time switch: the three schemes together do not fit the register
+// budget of the 128-factor kernel without spilling.
+enum : int { LM_LDS = 0, LM_HBM = 1, LM_HBM_APPEND = 2 };
+
+template <int NGT, bool AUC, bool DUMP, int LMODE>
 __global__ __launch_bounds__(SWEEP_THREADS, 2)
 void k_sweep(SweepArgs a)
 {
+    constexpr bool LLDS = LMODE == LM_LDS;
+    constexpr bool buffered = LMODE == LM_HBM_APPEND;
     // factor axis: NGT groups of 8 factors; up to 128 factors (NGT <= 16) a tile is one LDS image and the user factors
     // stay in registers for the whole sweep; beyond that the axis is streamed in chunks of 128 factors (one barrier
     // per chunk) and each chunk of user factors is re-read from L2 when its turn comes.
@@ -187,32 +195,11 @@ void k_sweep(SweepArgs a)
     GblListPtr Gw = LLDS ? nullptr : a.glists + ((size_t)blockIdx.x * 8 + wave) * GROUP_USERS * CAP;    // wave's 32 buffers
     GblListPtr Gu = LLDS ? nullptr : Gw + (size_t)ul * CAP;                                                // this user's
     // small K in HBM: [K][32 users] replace-the-minimum like the LDS list (cheaper than compactions below K ~ 32)
-    const bool buffered = a.buffered_lists != 0;
     GblListPtr Lr = LLDS ? nullptr : a.glists + ((size_t)blockIdx.x * 8 + wave) * GROUP_USERS * CAP + ul;
     float ws = neg_inf_f(); int widx = IDX_EMPTY, wpos = 0, cnt = 0;
     if (h == 0 && (LLDS || !buffered)) for (int i = 0; i < K; i++) {
         if (LLDS) Ll[i * GROUP_USERS] = 0ull; else Lr[i * GROUP_USERS] = ListRaw<float>::pack(neg_inf_f(), IDX_EMPTY);
     }
-    // LDS lists with pending buffers (a.pend_cap > 0): a candidate is first appended to its LANE's small buffer
-    // ([pend_cap][64 lanes] keys per wave: one LDS write), and the buffers are merged into the lists for all 32 users of
-    // the wave at once when one of them fills up.  Offering candidates one score register at a time keeps 1-2 lanes
-    // busy per replace-the-minimum scan; the merge runs the same scan with every owner lane that has work.
-    const int pend_cap = LLDS ? a.pend_cap : 0;
-    LdsListPtr Pp = (LdsListPtr)((unsigned long long *)(smem + a.pend_off) + wave * pend_cap * WAVE + lane);
-    auto merge_pending = [&]() {
-        const int pc = __shfl_xor(cnt, 32);                       // the partner lane's count (same user, other item rows)
-        const int lim = h == 0 ? (cnt > pc ? cnt : pc) : 0;
-        RM_STAT(5, 1);
-        for (int i = 0; __any(i < lim); i++) {
-            RM_STAT(6, 1); RM_STAT(7, __popcll(__ballot(h == 0 && i < cnt && Pp[i * WAVE] > wkey)) + __popcll(__ballot(h == 0 && i < pc && Pp[i * WAVE + 32] > wkey)));
-            if (h == 0) {
-                if (i < cnt) keylist_offer<GROUP_USERS>(Ll, K, Pp[i * WAVE], wkey, wpos);
-                if (i < pc) keylist_offer<GROUP_USERS>(Ll, K, Pp[i * WAVE + 32], wkey, wpos);
-            }
-        }
-        cnt = 0;
-        ws = (wkey >> 32) ? ord_unkey((unsigned)(wkey >> 32)) : neg_inf_f();
-    };
     // compaction of every owner lane in `need` (wave-uniform mask): K best kept, sorted; (ws, widx) = the K-th
     auto compact_users = [&](unsigned long long need) {
         while (need) {
@@ -223,6 +210,36 @@ void k_sweep(SweepArgs a)
             wave_compact<float>(Gw + (size_t)l * CAP, c, K, lane, ks, ki);
             if (lane == l) { cnt = c < K ? c : K; if (c >= K) { ws = ks; widx = ki; } }
         }
+    };
+    // Pending buffers (a.pend_cap > 0, whenever LDS has room): a candidate is first appended to its LANE's small buffer
+    // ([pend_cap][64 lanes] packed keys per wave: one LDS write), and the buffers are merged into the lists for all 32
+    // users of the wave at once when one of them fills up.  Offering candidates one score register at a time keeps 1-2
+    // lanes busy per list update -- a replace-the-minimum scan in LDS, or a store plus K loads with their HBM round
+    // trip when the lists live in HBM; the merge does the same work with every owner lane that has any.
+    const int pend_cap = buffered ? 0 : a.pend_cap;
+    int pcnt = 0;
+    LdsListPtr Pp = (LdsListPtr)((unsigned long long *)(smem + a.pend_off) + wave * pend_cap * WAVE + lane);
+    auto offer_key = [&](unsigned long long key) {                // owner lanes only
+        if (LLDS) { keylist_offer<GROUP_USERS>(Ll, K, key, wkey, wpos); return; }
+        float s; int item;
+        unpack_key(key, s, item);
+        if (buffered) { if (s > ws || (s == ws && item < widx)) Gu[cnt++] = ListRaw<float>::pack(s, item); }
+        else if (s >= ws) list_offer<float, GROUP_USERS>(Lr, K, s, item, ws, widx, wpos);
+    };
+    auto merge_pending = [&]() {
+        const int pc = __shfl_xor(pcnt, 32);                      // the partner lane's count (same user, other item rows)
+        const int lim = h == 0 ? (pcnt > pc ? pcnt : pc) : 0;
+        RM_STAT(5, 1);
+        for (int i = 0; __any(i < lim); i++) {
+            RM_STAT(6, 1);
+            if (h == 0) {
+                if (i < pcnt) offer_key(Pp[i * WAVE]);
+                if (i < pc) offer_key(Pp[i * WAVE + 32]);
+            }
+        }
+        pcnt = 0;
+        if (LLDS) ws = (wkey >> 32) ? ord_unkey((unsigned)(wkey >> 32)) : neg_inf_f();
+        else if (buffered) compact_users(__ballot(h == 0 && primary && cnt > 2 * K));   // <= 2 * pend_cap <= 32 appended since the last check
     };
 
     // positives -> LDS, histogram zeroed
@@ -374,13 +391,13 @@ void k_sweep(SweepArgs a)
                 if (__ballot(c)) {
                     RM_STAT(3, 1); RM_STAT(4, __popcll(__ballot(c)));
                     if (c) {
-                        if (cnt < pend_cap) { Pp[cnt * WAVE] = pack_key(v[r], sb + mfma32_row(r, h)); cnt++; }
+                        if (pcnt < pend_cap) { Pp[pcnt * WAVE] = pack_key(v[r], sb + mfma32_row(r, h)); pcnt++; }
                         else ov |= 1u << r;
                     }
                 }
             }
             bool more = __any(ov != 0);
-            if (more || __any(cnt >= pend_cap - 1)) merge_pending();
+            if (more || __any(pcnt >= pend_cap - 1)) merge_pending();
             while (more) {                                      // warm-up only: more candidates in one tile than a buffer holds
                 unsigned ov2 = 0;
                 #pragma unroll
@@ -388,7 +405,7 @@ void k_sweep(SweepArgs a)
                     const bool c = ((ov >> r) & 1u) && v[r] >= thr;
                     if (__ballot(c)) {
                         if (c) {
-                            if (cnt < pend_cap) { Pp[cnt * WAVE] = pack_key(v[r], sb + mfma32_row(r, h)); cnt++; }
+                            if (pcnt < pend_cap) { Pp[pcnt * WAVE] = pack_key(v[r], sb + mfma32_row(r, h)); pcnt++; }
                             else ov2 |= 1u << r;
                         }
                     }
