@@ -24,6 +24,9 @@ constexpr int GROUPS_PER_BLOCK = 4;
 constexpr int POS_CHUNK = 63;          // positives per slot = rows of a complete binary search tree of depth 6
 constexpr int MAX_J = 6;
 constexpr int IDX_EMPTY = 0x7fffffff;
+// where a sweep wave's top-K lists live: LM_LDS replace-the-minimum lists in LDS; LM_HBM the same scheme in HBM (lists that
+// do not fit LDS, K <= 32); LM_HBM_APPEND per-user append buffers in HBM with wave-cooperative compaction (K > 32)
+enum : int { LM_LDS = 0, LM_HBM = 1, LM_HBM_APPEND = 2 };
 // s_waitcnt immediate on gfx9/CDNA: vmcnt = bits [3:0] and [15:14], expcnt = [6:4], lgkmcnt = [11:8]; this one waits for
 // vmcnt == 0 and leaves the other two counters alone
 constexpr int WAIT_VMCNT0 = 0x0F70;

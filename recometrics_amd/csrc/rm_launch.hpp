@@ -41,6 +41,7 @@ struct Sweep64Args {
     int check_nan;
     int buffered_lists;
     int sync_off;                         // byte offset of the split-barrier counter in LDS
+    int pend_cap, pend_off;               // per-lane pending buffers (scores [cap][8 waves][64] then items), 0 = none
     const f64x2 *Ap, *Bp;
     const int *slot_user, *slot_chunk;
     const int *train_p, *train_i;
@@ -58,8 +59,8 @@ struct Sweep64Args {
 // return 0 = launched, -1 = unsupported factor-group count, otherwise a hipError_t
 int launch_sweep32(bool auc, bool dump, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa);
 int launch_sweep32_large(bool auc, bool dump, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa);
-int launch_sweep64(bool auc, bool dump, bool llds, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa);
-int launch_sweep64_small(bool auc, bool dump, bool llds, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa);
-int launch_sweep64_large(bool auc, bool dump, bool llds, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa);
+int launch_sweep64(bool auc, bool dump, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa);
+int launch_sweep64_small(bool auc, bool dump, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa);
+int launch_sweep64_large(bool auc, bool dump, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa);
 
 } // namespace rm

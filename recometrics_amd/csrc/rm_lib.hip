@@ -122,7 +122,8 @@ template <> struct Prec<float> {
     static size_t lds_b(int NG) { return 2ull * std::min(NG, 16) * 2 * TILE_ITEMS * 16; }
     static long long items_units(int tiles, int NG) { return (long long)tiles * NG * 2 * TILE_ITEMS; }
     static long long users_units(int groups, int NG) { return (long long)groups * NG * 2 * GU; }
-    static constexpr bool has_pending = true;
+    static constexpr bool has_pending = true, pending_for_append = false;   // appends of K > 32 are single stores already
+    static constexpr size_t pend_key_bytes = 8;
     static void set_pending(SweepArgs &sa, int cap, int off) { sa.pend_cap = cap; sa.pend_off = off; }
     static void set_sync(SweepArgs &sa, int off) { sa.sync_off = off; }
 };
@@ -134,8 +135,9 @@ template <> struct Prec<double> {
     static size_t lds_b(int NG) { return 2ull * std::min(NG, 8) * 4 * TILE_ITEMS * 16; }
     static long long items_units(int tiles, int NG) { return (long long)tiles * NG * 4 * TILE_ITEMS; }
     static long long users_units(int groups, int NG) { return (long long)groups * NG * 4 * GU; }
-    static constexpr bool has_pending = false;
-    static void set_pending(Sweep64Args &, int, int) {}
+    static constexpr bool has_pending = true, pending_for_append = true;    // saves four 64-bit shuffles per candidate register
+    static constexpr size_t pend_key_bytes = 12;
+    static void set_pending(Sweep64Args &sa, int cap, int off) { sa.pend_cap = cap; sa.pend_off = off; }
     static void set_sync(Sweep64Args &sa, int off) { sa.sync_off = off; }
 };
 
@@ -151,7 +153,7 @@ inline void dispatch_sweep(bool auc, bool dump, bool llds, int NG, dim3 grid, si
 }
 inline void dispatch_sweep(bool auc, bool dump, bool llds, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa)
 {
-    check_launch(launch_sweep64(auc, dump, llds, NG, grid, lds, stream, sa));
+    check_launch(launch_sweep64(auc, dump, llds ? 0 : (sa.buffered_lists ? 2 : 1), NG, grid, lds, stream, sa));
 }
 
 inline void pack_operands(const float *A, size_t lda, const float *B, size_t ldb, int n, int k, int NG, const int *slot_user,
@@ -267,11 +269,11 @@ void run(const Call<T> &c, hipStream_t stream)
     size_t lds_total = lds_need(list_in_lds);
     const size_t sync_off = lds_total;                     // split-barrier counter of the sweep
     lds_total += 16;
-    // fp32: per-lane pending buffers for top-K candidates behind everything else when 4..8 keys per lane still fit
+    // per-lane pending buffers for top-K candidates behind everything else when 4..8 keys per lane still fit
     int pend_cap = 0; const size_t pend_off = lds_total;
-    // (not for the append-buffer lists of K > 32: their appends are already single stores)
-    if (P::has_pending && (list_in_lds || K <= 32) && !getenv("RM_DEBUG_NO_PENDING")) {
-        const size_t per_key = 8ull * WAVE * 8;                                   // one key per lane, 8 waves
+    // (fp32: not for the append-buffer lists of K > 32, whose appends are already single stores)
+    if (P::has_pending && (list_in_lds || K <= 32 || P::pending_for_append) && !getenv("RM_DEBUG_NO_PENDING")) {
+        const size_t per_key = 8ull * WAVE * P::pend_key_bytes;                   // one key per lane, 8 waves
         pend_cap = (int)std::min<size_t>(8, (LDS_LIMIT - lds_total) / per_key);
         if (pend_cap < 4) pend_cap = 0;
         lds_total += pend_cap * per_key;

@@ -107,11 +107,8 @@ __device__ unsigned long long g_stats[16];
 #define RM_STAT(i, x) do {} while (0)
 #endif
 
-// LMODE = where a wave's top-K lists live: LM_LDS replace-the-minimum lists of packed keys in LDS; LM_HBM the same scheme
-// in HBM (lists that do not fit LDS, K <= 32); LM_HBM_APPEND per-user append buffers in HBM with wave-cooperative
-// compaction (K > 32).  A template parameter, not a run-time switch: the three schemes together do not fit the register
-// budget of the 128-factor kernel without spilling.
-enum : int { LM_LDS = 0, LM_HBM = 1, LM_HBM_APPEND = 2 };
+// LMODE (rm_device.hpp) is a template parameter, not a run-time switch: the three list schemes together do not fit the
+// register budget of the 128-factor kernel without spilling.
 
 template <int NGT, bool AUC, bool DUMP, int LMODE>
 __global__ __launch_bounds__(SWEEP_THREADS, 2)
@@ -125,6 +122,7 @@ void k_sweep(SweepArgs a)
     constexpr int NG = NGT < 16 ? NGT : 16;                    // groups per LDS chunk
     constexpr int NC = NGT / NG;                                // chunks per tile
     constexpr bool AF_RESIDENT = NC == 1;
+    constexpr bool AF_PREFETCH = !AF_RESIDENT && LMODE != LM_HBM_APPEND;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BUF_F4 = NG * 2 * TILE_ITEMS;                 // float4 per packed tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -291,13 +289,18 @@ void k_sweep(SweepArgs a)
     // ---- MFMA: 32 items (registers) x 32 users (lanes), k in index order ----
     auto do_mfma = [&](f32x16 &acc, int buf, int chunk) {
         const float4 *bb = ldsB + buf * BUF_F4 + h * TILE_ITEMS + sub * 32 + ul;
+        if (!AF_RESIDENT && !AF_PREFETCH) {
+            #pragma unroll
+            for (int g = 0; g < NG; g++) af[g] = af_src[(size_t)(chunk * NG + g) * 2 * GROUP_USERS];
+        }
         if (chunk == 0) {
             #pragma unroll
             for (int r = 0; r < 16; r++) acc[r] = 0.f;
         }
         // streamed factor axis: as soon as the four MFMAs of a factor group are issued its registers are free, and the
         // same group of the NEXT chunk is loaded into them -- a whole MFMA phase ahead of its use, drained by the
-        // wait at the arrive point, so the L2 latency of the user factors is never in front of a matrix instruction
+        // wait at the arrive point, so the L2 latency of the user factors is never in front of a matrix instruction.
+        // (Not with the append-buffer lists: that variant has no registers to spare and the prefetch turns into spills.)
         const int next_chunk = chunk + 1 == NC ? 0 : chunk + 1;
         #pragma unroll
         for (int g = 0; g < NG; g++) {
@@ -307,7 +310,7 @@ void k_sweep(SweepArgs a)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, u.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, u.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, u.w, acc, 0, 0, 0);
-            if (!AF_RESIDENT) af[g] = af_src[(size_t)(next_chunk * NG + g) * 2 * GROUP_USERS];
+            if (AF_PREFETCH) af[g] = af_src[(size_t)(next_chunk * NG + g) * 2 * GROUP_USERS];
         }
     };
 

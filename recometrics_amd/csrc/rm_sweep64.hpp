@@ -66,10 +66,12 @@ __device__ __forceinline__ void auc_pass64(const double (&v)[8], const char *pos
     }
 }
 
-template <int NGT, bool AUC, bool DUMP, bool LLDS>
+template <int NGT, bool AUC, bool DUMP, int LMODE>
 __global__ __launch_bounds__(SWEEP_THREADS, 2)
 void k_sweep64(Sweep64Args a)
 {
+    constexpr bool LLDS = LMODE == LM_LDS;
+    constexpr bool buffered = LMODE == LM_HBM_APPEND;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int GU = GROUP_USERS64;
     constexpr int NGC = NGT < 8 ? NGT : 8;                      // factor groups (of 8) per LDS chunk
@@ -122,16 +124,17 @@ void k_sweep64(Sweep64Args a)
     }
 
     // user factors -> registers: [group][g][q][16 users][2 doubles].  Up to 128 factors (64 VGPRs) they stay resident
-    // for the whole sweep; beyond that each 64-factor chunk is re-read from L2 one chunk ahead of its turn.
+    // for the whole sweep; beyond that each 64-factor chunk is re-read from L2 when its turn comes.
     constexpr bool AF_RESIDENT = NGT <= 16;
     constexpr int NAF = AF_RESIDENT ? NGT : NGC;
     f64x2 af[NAF];
     const f64x2 *af_src = a.Ap + ((size_t)(group_ok ? group : 0) * NGT * 4 + q) * GU + ul;     // + g * 4 * GU
-    // resident factors, or chunk 0 of a streamed axis (every later chunk is prefetched inside the MFMA loop)
-    #pragma unroll
-    for (int g = 0; g < NAF; g++) {
-        f64x2 z; z.x = 0; z.y = 0;
-        af[g] = (group_ok || !AF_RESIDENT) ? af_src[(size_t)g * 4 * GU] : z;
+    if (AF_RESIDENT) {
+        #pragma unroll
+        for (int g = 0; g < NGT; g++) {
+            f64x2 z; z.x = 0; z.y = 0;
+            af[g] = group_ok ? af_src[(size_t)g * 4 * GU] : z;
+        }
     }
 
     // top-K list owned by the q == 0 lane of the user: LDS [K][16 users] replace-the-minimum, or HBM append buffer +
@@ -140,7 +143,6 @@ void k_sweep64(Sweep64Args a)
     LdsList64Ptr Ll = (LdsList64Ptr)((GblList64Ptr)lists_lds + wave * K * GU + ul);
     GblList64Ptr Gw = LLDS ? nullptr : a.glists + ((size_t)blockIdx.x * 8 + wave) * GU * CAP;
     GblList64Ptr Gu = LLDS ? nullptr : Gw + (size_t)ul * CAP;
-    const bool buffered = a.buffered_lists != 0;
     GblList64Ptr Lr = LLDS ? nullptr : a.glists + ((size_t)blockIdx.x * 8 + wave) * GU * CAP + ul;
     double ws = neg_inf_d(); int widx = IDX_EMPTY, wpos = 0, cnt = 0;
     if (q == 0 && (LLDS || !buffered)) for (int i = 0; i < K; i++) {
@@ -159,6 +161,37 @@ void k_sweep64(Sweep64Args a)
 #endif
             if (lane == l) { cnt = c < K ? c : K; if (c >= K) { ws = ks; widx = ki; } }
         }
+    };
+
+    // Pending buffers (a.pend_cap > 0): every lane appends its own candidates to a small LDS buffer ([pend_cap][64 lanes],
+    // scores and items in separate arrays), and the buffers of all 16 users of the wave are merged into their lists
+    // together when one fills up -- instead of four 64-bit shuffles and up to four list updates by one owner lane per
+    // score register that holds a candidate.  See the fp32 sweep.
+    typedef __attribute__((address_space(3))) double *LdsF64Ptr;
+    typedef __attribute__((address_space(3))) int *LdsI32Ptr;
+    const int pend_cap = a.pend_cap;
+    int pcnt = 0;
+    LdsF64Ptr Ps = (LdsF64Ptr)(smem + a.pend_off) + wave * pend_cap * WAVE + lane;
+    LdsI32Ptr Pi = (LdsI32Ptr)(smem + a.pend_off + 8 * pend_cap * WAVE * 8) + wave * pend_cap * WAVE + lane;
+    auto offer_entry = [&](double s, int item) {                  // owner lanes only
+        if (LLDS) { if (s >= ws) list_offer<double, GU>(Ll, K, s, item, ws, widx, wpos); }
+        else if (buffered) { if (s > ws || (s == ws && item < widx)) Gu[cnt++] = ListRaw<double>::pack(s, item); }
+        else if (s >= ws) list_offer<double, GU>(Lr, K, s, item, ws, widx, wpos);
+    };
+    auto merge_pending = [&]() {
+        const int c1 = __shfl(pcnt, ul + 16), c2 = __shfl(pcnt, ul + 32), c3 = __shfl(pcnt, ul + 48);
+        const int m01 = pcnt > c1 ? pcnt : c1, m23 = c2 > c3 ? c2 : c3;
+        const int lim = q == 0 ? (m01 > m23 ? m01 : m23) : 0;
+        for (int i = 0; __any(i < lim); i++) {
+            if (q == 0) {
+                if (i < pcnt) offer_entry(Ps[i * WAVE], Pi[i * WAVE]);
+                if (i < c1) offer_entry(Ps[i * WAVE + 16], Pi[i * WAVE + 16]);
+                if (i < c2) offer_entry(Ps[i * WAVE + 32], Pi[i * WAVE + 32]);
+                if (i < c3) offer_entry(Ps[i * WAVE + 48], Pi[i * WAVE + 48]);
+            }
+        }
+        pcnt = 0;
+        if (buffered) compact_users(__ballot(q == 0 && primary && cnt > 2 * K));     // <= 4 * pend_cap <= 32 appended since the last check
     };
 
     if (AUC) {
@@ -232,7 +265,36 @@ void k_sweep64(Sweep64Args a)
         unsigned long long cm = 0;
         #pragma unroll
         for (int r = 0; r < 8; r++) cm |= __ballot(v[r] >= thr);
-        if (cm) {
+        if (cm && pend_cap) {
+            unsigned ov = 0;                                    // score registers that did not fit the lane's buffer
+            #pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const bool c = v[r] >= thr;
+                if (__ballot(c)) {
+                    if (c) {
+                        if (pcnt < pend_cap) { Ps[pcnt * WAVE] = v[r]; Pi[pcnt * WAVE] = sb + (r >> 2) * 16 + 4 * (r & 3) + q; pcnt++; }
+                        else ov |= 1u << r;
+                    }
+                }
+            }
+            bool more = __any(ov != 0);
+            if (more || __any(pcnt >= pend_cap - 1)) merge_pending();
+            while (more) {                                      // warm-up only
+                unsigned ov2 = 0;
+                #pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const bool c = ((ov >> r) & 1u) && v[r] >= thr;
+                    if (__ballot(c)) {
+                        if (c) {
+                            if (pcnt < pend_cap) { Ps[pcnt * WAVE] = v[r]; Pi[pcnt * WAVE] = sb + (r >> 2) * 16 + 4 * (r & 3) + q; pcnt++; }
+                            else ov2 |= 1u << r;
+                        }
+                    }
+                }
+                ov = ov2; more = __any(ov != 0);
+                merge_pending();
+            }
+        } else if (cm) {
             #pragma unroll
             for (int r = 0; r < 8; r++) {
                 if (__any(v[r] >= thr)) {
@@ -259,6 +321,8 @@ void k_sweep64(Sweep64Args a)
                 }
             }
             if (!LLDS && buffered) compact_users(__ballot(q == 0 && primary && cnt > 2 * K));
+        }
+        if (cm) {
             const double t2 = __shfl(ws, ul);
             if (primary) {
                 thr = t2 > thr ? t2 : thr;
@@ -312,6 +376,12 @@ void k_sweep64(Sweep64Args a)
                 stage(t0 + nu / NC, nu % NC, nu & 1);
             }
             const f64x2 *bb = ldsB + buf * BUF_D2 + q * TILE_ITEMS + sub * 32 + ul;
+            // streamed factor axis: this chunk's user factors come from L2 right before use.  (Prefetching them one chunk
+            // ahead into the registers just consumed, as the fp32 sweep does, costs more in spills here than it hides.)
+            if (!AF_RESIDENT) {
+                #pragma unroll
+                for (int gl = 0; gl < NGC; gl++) af[gl] = af_src[(size_t)(c * NGC + gl) * 4 * GU];
+            }
             if (c == 0) {
                 #pragma unroll
                 for (int r = 0; r < 4; r++) { clo[r] = 0.; chi[r] = 0.; }
@@ -324,9 +394,6 @@ void k_sweep64(Sweep64Args a)
                 chi = __builtin_amdgcn_mfma_f64_16x16x4f64(b1.x, u.x, chi, 0, 0, 0);
                 clo = __builtin_amdgcn_mfma_f64_16x16x4f64(b0.y, u.y, clo, 0, 0, 0);
                 chi = __builtin_amdgcn_mfma_f64_16x16x4f64(b1.y, u.y, chi, 0, 0, 0);
-                // streamed axis: the group's registers are free once its MFMAs are issued -> load the same group of the
-                // next chunk into them, a whole MFMA phase ahead of its use (drained by the wait below)
-                if (!AF_RESIDENT) af[gl] = af_src[(size_t)((c + 1 == NC ? 0 : c + 1) * NGC + gl) * 4 * GU];
             }
             __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                              // arrive half: the next unit's DMA share has landed
             if (lane == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -335,6 +402,7 @@ void k_sweep64(Sweep64Args a)
         thr_seen = thr_next;
     }
     if (DUMP) return;
+    if (pend_cap) merge_pending();
 
     const int n_part = a.n_splits * 2;
     const int part = split * 2 + sub;

@@ -4,12 +4,12 @@
 
 namespace rm {
 
-template <bool AUC, bool DUMP, bool LLDS>
+template <bool AUC, bool DUMP, int LMODE>
 static int launch_ng(int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa)
 {
 #define RM_LAUNCH(NGV)                                                                                               \
     case NGV: {                                                                                                      \
-        auto kern = k_sweep64<NGV, AUC, DUMP, LLDS>;                                                                  \
+        auto kern = k_sweep64<NGV, AUC, DUMP, LMODE>;                                                                  \
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return (int)e;                                                                          \
         hipLaunchKernelGGL(kern, grid, dim3(SWEEP_THREADS), lds, stream, sa);                                        \
@@ -22,17 +22,25 @@ static int launch_ng(int NG, dim3 grid, size_t lds, hipStream_t stream, const Sw
     return (int)hipGetLastError();
 }
 
-int launch_sweep64_large(bool auc, bool dump, bool llds, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa)
+int launch_sweep64_large(bool auc, bool dump, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa)
 {
-    if (dump) return launch_ng<false, true, false>(NG, grid, lds, stream, sa);
-    if (auc) return llds ? launch_ng<true, false, true>(NG, grid, lds, stream, sa) : launch_ng<true, false, false>(NG, grid, lds, stream, sa);
-    return llds ? launch_ng<false, false, true>(NG, grid, lds, stream, sa) : launch_ng<false, false, false>(NG, grid, lds, stream, sa);
+    if (dump) return launch_ng<false, true, LM_HBM>(NG, grid, lds, stream, sa);
+    if (auc) switch (lmode) {
+        case LM_LDS: return launch_ng<true, false, LM_LDS>(NG, grid, lds, stream, sa);
+        case LM_HBM: return launch_ng<true, false, LM_HBM>(NG, grid, lds, stream, sa);
+        default: return launch_ng<true, false, LM_HBM_APPEND>(NG, grid, lds, stream, sa);
+    }
+    switch (lmode) {
+        case LM_LDS: return launch_ng<false, false, LM_LDS>(NG, grid, lds, stream, sa);
+        case LM_HBM: return launch_ng<false, false, LM_HBM>(NG, grid, lds, stream, sa);
+        default: return launch_ng<false, false, LM_HBM_APPEND>(NG, grid, lds, stream, sa);
+    }
 }
 
-int launch_sweep64(bool auc, bool dump, bool llds, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa)
+int launch_sweep64(bool auc, bool dump, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa)
 {
-    return NG <= 8 ? launch_sweep64_small(auc, dump, llds, NG, grid, lds, stream, sa)
-                   : launch_sweep64_large(auc, dump, llds, NG, grid, lds, stream, sa);
+    return NG <= 8 ? launch_sweep64_small(auc, dump, lmode, NG, grid, lds, stream, sa)
+                   : launch_sweep64_large(auc, dump, lmode, NG, grid, lds, stream, sa);
 }
 
 } // namespace rm

@@ -11,6 +11,7 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 m, n, k, dtype, K, mean_c, seed = CONFIGS[wl]
 m = users
 K = int(os.environ.get('NS_K', K))
+k = int(os.environ.get('NS_FACTORS', k))
 torch.cuda.set_device(0); binding.load(); binding.set_device(0)
 p = DeviceProblem(torch, torch.device("cuda", 0), m, n, k, mean_c, seed, K, dtype)
 dt, sw, pr, fi, tm = measure(torch, dist, binding, p, steps, 1, 1, None)
