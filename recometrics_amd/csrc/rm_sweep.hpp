@@ -12,11 +12,13 @@
 //                  [row][32 users] so that lane u always hits bank u: conflict-free whatever the data.
 //   block          512 threads = 8 wavefronts = 4 user groups x 2 item sub-tiles (128 users x 64 items per step).
 //                  Wavefronts w and w+4 share a SIMD and a user group.  An f32-input MFMA chain does not co-execute
-//                  with VALU / LDS work of the SIMD partner (scratch/coexec2.hip: time = sum), so the waves run in
-//                  phase -- MFMA(tile t), then epilogue(tile t) -- and the lever is the epilogue's instruction count.
+//                  with VALU / LDS work of the SIMD partner (scratch/coexec2.hip: time = sum), so the epilogue's
+//                  instructions add to the MFMA time and the lever is the epilogue's instruction count.
 //   operands       user factors live in registers for the whole sweep (NG float4 per lane, up to 128 factors; beyond
 //                  that the factor axis is streamed in 128-factor chunks); packed item tiles (rm_prep.hpp
-//                  k_pack_items) stream HBM -> LDS by LDS-DMA, double buffered, one barrier per tile.
+//                  k_pack_items) stream HBM -> LDS by LDS-DMA (inline asm), double buffered.
+//   synchronisation  a split barrier on an LDS arrival counter instead of s_barrier per tile: arrive after the tile's
+//                  last MFMA, wait before the next tile touches the buffers, the whole epilogue in between.
 //   diagnostics    the RM_ABL_* macros compile single stages out (wrong results, timing only): they are how the cost
 //                  breakdown in DESIGN.md was measured and are never defined in a product build.
 #pragma once

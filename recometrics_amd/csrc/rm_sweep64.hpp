@@ -7,8 +7,8 @@
 //   * D is 16 items x 16 users: column (user) = lane & 15, row (item) = (lane >> 4) + 4*reg -- a user sits on FOUR lanes
 //     (q = lane >> 4), a group is 16 users, a wave owns 16 users x 32 items per tile (two MFMA tiles, 8 values per lane);
 //   * the packed operand image is [g][q][row][2 doubles]: a b128 read gives the lane its factors k = 8g + q and 8g + 4 + q;
-//   * the factor axis is streamed in chunks of 64 factors (32 KiB LDS per buffer); user factors stay in registers
-//     (2 doubles per 8 factors), so 256 factors cost 128 VGPRs.
+//   * the factor axis is streamed in chunks of 64 factors (32 KiB LDS per buffer); up to 128 factors the user factors
+//     stay in registers for the whole sweep (64 VGPRs), beyond that each chunk's are re-read from L2.
 #pragma once
 #include "rm_device.hpp"
 #include "rm_list.hpp"
