@@ -129,6 +129,9 @@ def _check_against_oracle(hip, oracle, pr, k, dtype=np.float32, **kw):
     (300, 9000, 100, 256, 30),     # largest supported K for HBM lists
     (150, 4000, 200, 10, 40),      # > 128 factors: the factor axis is streamed in chunks of 128
     (90, 3000, 500, 5, 30),
+    (200, 5000, 128, 20, 120),     # BASELINE config C3's factor count and K: replace-the-minimum lists in HBM + pending buffers
+    (160, 7000, 128, 32, 120),     # largest K of that scheme
+    (100, 6000, 256, 20, 100),     # the same with a streamed factor axis (prefetched user factors)
 ])
 def test_random_problem_vs_oracle(hip, oracle, m, n, k, K, mean_c):
     from recometrics_amd.synth import make_problem
@@ -142,11 +145,26 @@ def test_random_problem_vs_oracle(hip, oracle, m, n, k, K, mean_c):
     (70, 20000, 256, 50, 50),      # BASELINE config C5's factor count and K (fp64, lists out of LDS, item splits)
     (129, 1027, 100, 7, 40),
     (60, 2000, 400, 5, 30),        # > 256 factors in fp64
+    (80, 6000, 256, 30, 120),      # fp64 replace-the-minimum lists in HBM (too large for LDS, K <= 32) + pending buffers
+    (96, 9000, 64, 12, 60),        # fp64 LDS lists + pending buffers
 ])
 def test_random_problem_vs_oracle_f64(hip, oracle, m, n, k, K, mean_c):
     from recometrics_amd.synth import make_problem
     pr = make_problem(m, n, k, np.float64, mean_c=mean_c, seed=m + n + 1)
     _check_against_oracle(hip, oracle, pr, K, dtype=np.float64)
+
+
+@pytest.mark.parametrize("env", [{"RM_DEBUG_NO_PENDING": "1"}, {"RM_DEBUG_HBM_LISTS": "1"},
+                                 {"RM_DEBUG_HBM_LISTS": "1", "RM_DEBUG_NO_PENDING": "1"}])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_list_schemes_agree(hip, oracle, env, dtype, monkeypatch):
+    """the same problem through every top-K list scheme the sweep has (the library reads the switches per call):
+    LDS lists without pending buffers, HBM replace-the-minimum lists with and without them"""
+    from recometrics_amd.synth import make_problem
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    pr = make_problem(150, 9000, 48, dtype, mean_c=60, seed=5)
+    _check_against_oracle(hip, oracle, pr, 12, dtype=dtype)
 
 
 def test_heavy_users_many_positives(hip, oracle):
