@@ -119,11 +119,12 @@ template <> struct Prec<float> {
     typedef float4 PackT;  typedef u32x2 ListT;  typedef SweepArgs Args;
     static int supported_ng(int k) { const int ng = (k + 7) / 8; for (int o : {2, 4, 8, 16, 32, 64}) if (ng <= o) return o; return -1; }
     static const char *limit() { return "the fp32 path supports up to 512 factors"; }
-    static size_t lds_b(int NG) { return 2ull * std::min(NG, 16) * 2 * TILE_ITEMS * 16; }
-    static long long items_units(int tiles, int NG) { return (long long)tiles * NG * 2 * TILE_ITEMS; }
+    static size_t lds_b(int NG, int tile = TILE_ITEMS) { return 2ull * std::min(NG, 16) * 2 * tile * 16; }
+    static long long items_units(int tiles, int NG, int tile = TILE_ITEMS) { return (long long)tiles * NG * 2 * tile; }
     static long long users_units(int groups, int NG) { return (long long)groups * NG * 2 * GU; }
     static constexpr bool has_pending = true, pending_for_append = false;   // appends of K > 32 are single stores already
     static constexpr size_t pend_key_bytes = 8;
+    static constexpr int max_nsub = 3;
     static void set_pending(SweepArgs &sa, int cap, int off) { sa.pend_cap = cap; sa.pend_off = off; }
     static void set_sync(SweepArgs &sa, int off) { sa.sync_off = off; }
 };
@@ -132,11 +133,12 @@ template <> struct Prec<double> {
     typedef double2 PackT;  typedef u32x4 ListT;  typedef Sweep64Args Args;
     static int supported_ng(int k) { const int ng = (k + 7) / 8; for (int o : {2, 4, 8, 16, 32, 64}) if (ng <= o) return o; return -1; }
     static const char *limit() { return "the fp64 path supports up to 512 factors"; }
-    static size_t lds_b(int NG) { return 2ull * std::min(NG, 8) * 4 * TILE_ITEMS * 16; }
-    static long long items_units(int tiles, int NG) { return (long long)tiles * NG * 4 * TILE_ITEMS; }
+    static size_t lds_b(int NG, int = TILE_ITEMS) { return 2ull * std::min(NG, 8) * 4 * TILE_ITEMS * 16; }
+    static long long items_units(int tiles, int NG, int = TILE_ITEMS) { return (long long)tiles * NG * 4 * TILE_ITEMS; }
     static long long users_units(int groups, int NG) { return (long long)groups * NG * 4 * GU; }
     static constexpr bool has_pending = true, pending_for_append = true;    // saves four 64-bit shuffles per candidate register
     static constexpr size_t pend_key_bytes = 12;
+    static constexpr int max_nsub = 2;
     static void set_pending(Sweep64Args &sa, int cap, int off) { sa.pend_cap = cap; sa.pend_off = off; }
     static void set_sync(Sweep64Args &sa, int off) { sa.sync_off = off; }
 };
@@ -146,23 +148,23 @@ inline void check_launch(int rc)
     if (rc == -1) throw RmError{RM_ERR_UNSUPPORTED, "unsupported factor count"};
     if (rc != 0) throw RmError{RM_ERR_HIP, std::string("sweep launch: ") + hipGetErrorString((hipError_t)rc)};
 }
-inline void dispatch_sweep(bool auc, bool dump, bool llds, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa)
+inline void dispatch_sweep(bool auc, bool dump, bool llds, int nsub, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa)
 {
     // list mode of the fp32 sweep (rm_sweep.hpp): 0 = LDS, 1 = HBM replace-the-minimum (K <= 32), 2 = HBM append buffers
-    check_launch(launch_sweep32(auc, dump, llds ? 0 : (sa.buffered_lists ? 2 : 1), NG, grid, lds, stream, sa));
+    check_launch(launch_sweep32(auc, dump, llds ? 0 : (sa.buffered_lists ? 2 : 1), nsub, NG, grid, lds, stream, sa));
 }
-inline void dispatch_sweep(bool auc, bool dump, bool llds, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa)
+inline void dispatch_sweep(bool auc, bool dump, bool llds, int, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa)
 {
     check_launch(launch_sweep64(auc, dump, llds ? 0 : (sa.buffered_lists ? 2 : 1), NG, grid, lds, stream, sa));
 }
 
-inline void pack_operands(const float *A, size_t lda, const float *B, size_t ldb, int n, int k, int NG, const int *slot_user,
+inline void pack_operands(const float *A, size_t lda, const float *B, size_t ldb, int n, int k, int NG, int tile_items, const int *slot_user,
                           int n_slots, float4 *Ap, long long ap, float4 *Bp, long long bp, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_pack_items<float>, dim3(cdiv(bp, 256)), dim3(256), 0, stream, B, ldb, n, k, NG, Bp, bp);
+    hipLaunchKernelGGL(k_pack_items<float>, dim3(cdiv(bp, 256)), dim3(256), 0, stream, B, ldb, n, k, NG, tile_items, Bp, bp);
     hipLaunchKernelGGL(k_pack_users<float>, dim3(cdiv(ap, 256)), dim3(256), 0, stream, A, lda, k, NG, slot_user, n_slots, Ap, ap);
 }
-inline void pack_operands(const double *A, size_t lda, const double *B, size_t ldb, int n, int k, int NG, const int *slot_user,
+inline void pack_operands(const double *A, size_t lda, const double *B, size_t ldb, int n, int k, int NG, int, const int *slot_user,
                           int n_slots, double2 *Ap, long long ap, double2 *Bp, long long bp, hipStream_t stream)
 {
     hipLaunchKernelGGL(k_pack_items64<double>, dim3(cdiv(bp, 256)), dim3(256), 0, stream, B, ldb, n, k, NG, Bp, bp);
@@ -237,15 +239,28 @@ void run(const Call<T> &c, hipStream_t stream)
     std::memcpy(&amax_a, &hp.amax_a, 8); std::memcpy(&amax_b, &hp.amax_b, 8);
     const double tmax = std::is_same<T, float>::value ? 3.0e38 : 1.0e308;
     const bool check_nan = hp.nonfinite || !((double)k * amax_a * 1.001 < tmax / std::max(amax_b, 1e-300));
-    const int tiles_total = (n + TILE_ITEMS - 1) / TILE_ITEMS;
     const int n_ublocks = (n_groups + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK;
 
     // ---- sweep geometry ----
+    const size_t lds_auc = want_auc ? (size_t)GROUPS_PER_BLOCK * (1 << jmax) * GU * (sizeof(T) + 4) : 0;
+    // each group's positives table is aligned to its own size (2^jmax rows of GU scores): worst-case padding = one table
+    const size_t tbytes = want_auc ? ((size_t)1 << jmax) * GU * sizeof(T) : 1;
+    // sub-tiles per step (waves per block = 4 nsub): three when the fp32 kernel for <= 64 factors keeps its lists in LDS
+    // next to the larger item tile -- the third wave per SIMD fills the vector pipe the epilogue leaves idle
+    int nsub = 2;
+    auto lds_need_n = [&](bool with_lists, int ns) {
+        const size_t head = P::lds_b(NG, 32 * ns) + (with_lists ? 4ull * ns * K * GU * sizeof(typename P::ListT) : 0);
+        return (want_auc ? (head + tbytes - 1) / tbytes * tbytes : head) + lds_auc;
+    };
+    if (P::max_nsub >= 3 && NG <= 8 && lds_need_n(true, 3) + 16 <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS") && !getenv("RM_DEBUG_NSUB2"))
+        nsub = 3;
+    const int tile_items = 32 * nsub, n_waves = 4 * nsub;
+    const int tiles_total = (n + tile_items - 1) / tile_items;
     // LDS admits one block per CU, so the grid runs in rounds of 256 blocks: pick the item split count whose last
     // round is fullest (each extra split restarts the streaming top-K lists, hence the small per-split penalty).
     int n_splits = 1;
     if (n_ublocks > 0) {
-        const int n_cu = 256, max_splits = std::max(1, std::min(MAX_PARTS / 2, tiles_total / 128));
+        const int n_cu = 256, max_splits = std::max(1, std::min(MAX_PARTS / nsub, tiles_total / 128));
         double best = -1;
         for (int sct = 1; sct <= max_splits; sct++) {
             const long long blocks = (long long)n_ublocks * sct;
@@ -255,27 +270,19 @@ void run(const Call<T> &c, hipStream_t stream)
             if (score > best + 1e-9) { best = score; n_splits = sct; }
         }
     }
-    const int n_part = 2 * n_splits;
-    const size_t lds_b = P::lds_b(NG);
-    const size_t lds_auc = want_auc ? (size_t)GROUPS_PER_BLOCK * (1 << jmax) * GU * (sizeof(T) + 4) : 0;
-    const size_t lds_lists = 8ull * K * GU * sizeof(typename P::ListT);
-    // each group's positives table is aligned to its own size (2^jmax rows of GU scores): worst-case padding = one table
-    const size_t tbytes = want_auc ? ((size_t)1 << jmax) * GU * sizeof(T) : 1;
-    auto lds_need = [&](bool with_lists) {
-        const size_t head = lds_b + (with_lists ? lds_lists : 0);
-        return (want_auc ? (head + tbytes - 1) / tbytes * tbytes : head) + lds_auc;
-    };
+    const int n_part = nsub * n_splits;
+    auto lds_need = [&](bool with_lists) { return lds_need_n(with_lists, nsub); };
     const bool list_in_lds = lds_need(true) + 16 <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS");
     size_t lds_total = lds_need(list_in_lds);
     const size_t sync_off = lds_total;                     // split-barrier counter of the sweep
     lds_total += 16;
-    // per-lane pending buffers for top-K candidates behind everything else when 4..8 keys per lane still fit
+    // per-lane pending buffers for top-K candidates behind everything else when 2..8 keys per lane still fit
     int pend_cap = 0; const size_t pend_off = lds_total;
     // (fp32: not for the append-buffer lists of K > 32, whose appends are already single stores)
     if (P::has_pending && (list_in_lds || K <= 32 || P::pending_for_append) && !getenv("RM_DEBUG_NO_PENDING")) {
-        const size_t per_key = 8ull * WAVE * P::pend_key_bytes;                   // one key per lane, 8 waves
+        const size_t per_key = (size_t)n_waves * WAVE * P::pend_key_bytes;        // one key per lane and wave
         pend_cap = (int)std::min<size_t>(8, (LDS_LIMIT - lds_total) / per_key);
-        if (pend_cap < 4) pend_cap = 0;
+        if (pend_cap < 2) pend_cap = 0;
         lds_total += pend_cap * per_key;
     }
 
@@ -285,10 +292,10 @@ void run(const Call<T> &c, hipStream_t stream)
 
     if (n_slots > 0) {
         // ---- pack operands into the MFMA images ----
-        const long long bp_units = P::items_units(tiles_total, NG), ap_units = P::users_units(n_groups, NG);
+        const long long bp_units = P::items_units(tiles_total, NG, tile_items), ap_units = P::users_units(n_groups, NG);
         typename P::PackT *Bp = (typename P::PackT *)ws.get("Bp", 16 * (size_t)bp_units);
         typename P::PackT *Ap = (typename P::PackT *)ws.get("Ap", 16 * (size_t)ap_units);
-        pack_operands(c.A, c.lda, c.B, c.ldb, n, k, NG, slot_user, n_slots, Ap, ap_units, Bp, bp_units, stream);
+        pack_operands(c.A, c.lda, c.B, c.ldb, n, k, NG, tile_items, slot_user, n_slots, Ap, ap_units, Bp, bp_units, stream);
 
         // ---- positives ----
         if (want_auc) {
@@ -312,7 +319,7 @@ void run(const Call<T> &c, hipStream_t stream)
         const unsigned n_blocks = (unsigned)n_ublocks * n_splits;
         if (!list_in_lds) {
             if (K > 256) throw RmError{RM_ERR_UNSUPPORTED, "k_metrics > 256 is not supported when the top-K lists do not fit LDS"};
-            glists = (typename P::ListT *)ws.get("glists", sizeof(typename P::ListT) * (size_t)n_blocks * 8 * GU * (2 * K + 32));
+            glists = (typename P::ListT *)ws.get("glists", sizeof(typename P::ListT) * (size_t)n_blocks * n_waves * GU * (2 * K + 32));
         }
 
         typedef typename std::remove_pointer<decltype(typename P::Args{}.thr_shared)>::type ThrT;
@@ -329,7 +336,7 @@ void run(const Call<T> &c, hipStream_t stream)
         P::set_sync(sa, (int)sync_off);
 
         HIP_CHECK(hipEventRecord(g_ev[1], stream));
-        dispatch_sweep(want_auc, false, list_in_lds, NG, dim3(n_blocks), lds_total, stream, sa);
+        dispatch_sweep(want_auc, false, list_in_lds, nsub, NG, dim3(n_blocks), lds_total, stream, sa);
         HIP_CHECK(hipEventRecord(g_ev[2], stream));
         g_timings[4] = 1; g_timings[5] = n_splits; g_timings[6] = n_blocks; g_timings[7] = (double)lds_total;
     } else {
@@ -486,7 +493,7 @@ void debug_scores(const T *A, size_t lda, const T *B, size_t ldb, int m, int n, 
     const long long bp_units = P::items_units(tiles_total, NG), ap_units = P::users_units(n_groups, NG);
     typename P::PackT *Bp = (typename P::PackT *)ws.get("Bp", 16 * (size_t)bp_units);
     typename P::PackT *Ap = (typename P::PackT *)ws.get("Ap", 16 * (size_t)ap_units);
-    pack_operands(dA, (size_t)k, dB, (size_t)k, n, k, NG, slot_user, m, Ap, ap_units, Bp, bp_units, stream);
+    pack_operands(dA, (size_t)k, dB, (size_t)k, n, k, NG, TILE_ITEMS, slot_user, m, Ap, ap_units, Bp, bp_units, stream);
     T *dump = (T *)ws.get("dbg_dump", sizeof(T) * (size_t)m * n);
     const int K = 1;
     typename P::ListT *glists = (typename P::ListT *)ws.get("glists", sizeof(typename P::ListT) * (size_t)n_ublocks * 8 * GU * (2 * K + 32));
@@ -496,7 +503,7 @@ void debug_scores(const T *A, size_t lda, const T *B, size_t ldb, int m, int n, 
     sa.slot_user = slot_user; sa.slot_chunk = zeros; sa.train_p = zeros; sa.train_i = zeros; sa.gj = zeros + m + 1; sa.grow = grow;
     sa.glists = glists; sa.dump = dump;
     P::set_sync(sa, (int)P::lds_b(NG));
-    dispatch_sweep(false, true, false, NG, dim3(n_ublocks), P::lds_b(NG) + 16, stream, sa);
+    dispatch_sweep(false, true, false, 2, NG, dim3(n_ublocks), P::lds_b(NG) + 16, stream, sa);
     HIP_CHECK(hipMemcpyAsync(out, dump, sizeof(T) * (size_t)m * n, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
 }

@@ -225,16 +225,16 @@ template <class T> __global__ void k_fill(T *p, T v, long long count)
 //   packed[tile][g][h][row][i] = X[tile*ROWS + row][8g + 2i + h]        (zero for k >= k or row >= rows)
 // The k order of the accumulate chain is unchanged: step 4g+i adds k = 8g+2i (h = 0) then k = 8g+2i+1 (h = 1).
 template <class T>
-__global__ void k_pack_items(const T *B, size_t ldb, int n, int k, int NG, float4 *Bp, long long total_f4)
+__global__ void k_pack_items(const T *B, size_t ldb, int n, int k, int NG, int tile_items, float4 *Bp, long long total_f4)
 {
     const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // one float4 of the image per thread
     if (o >= total_f4) return;
-    const int row = (int)(o % TILE_ITEMS);
-    const int h = (int)((o / TILE_ITEMS) & 1);
-    const long long tg = o / (2 * TILE_ITEMS);
+    const int row = (int)(o % tile_items);                                      // tile_items = 64 or 96 (rm_sweep.hpp NSUB)
+    const int h = (int)((o / tile_items) & 1);
+    const long long tg = o / (2 * tile_items);
     const int g = (int)(tg % NG);
     const long long tile = tg / NG;
-    const long long item = tile * TILE_ITEMS + row;
+    const long long item = tile * tile_items + row;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (item < n) {
         const T *src = B + (size_t)item * ldb;

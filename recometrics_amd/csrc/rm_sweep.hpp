@@ -112,10 +112,15 @@ __device__ unsigned long long g_stats[16];
 // LMODE (rm_device.hpp) is a template parameter, not a run-time switch: the three list schemes together do not fit the
 // register budget of the 128-factor kernel without spilling.
 
-template <int NGT, bool AUC, bool DUMP, int LMODE>
-__global__ __launch_bounds__(SWEEP_THREADS, 2)
+// NSUB = 32-item sub-tiles per step (2 or 3): a block is 4 user groups x NSUB sub-tiles = 4 NSUB waves, NSUB per SIMD.
+// Three need the LDS room and <= 168 VGPRs, i.e. k <= 64: there the epilogue dominates, two waves per SIMD leave the
+// vector pipe idle a third of the time (profiles/r1_pmc_sq_C2.json), and the third wave fills it.
+template <int NGT, bool AUC, bool DUMP, int LMODE, int NSUB>
+__global__ __launch_bounds__(256 * NSUB)
 void k_sweep(SweepArgs a)
 {
+    constexpr int TILE = 32 * NSUB;                             // items per step and per packed tile
+    constexpr int NWAVES = 4 * NSUB, THREADS = 64 * NWAVES;
     constexpr bool LLDS = LMODE == LM_LDS;
     constexpr bool buffered = LMODE == LM_HBM_APPEND;
     // factor axis: NGT groups of 8 factors; up to 128 factors (NGT <= 16) a tile is one LDS image and the user factors
@@ -126,7 +131,7 @@ void k_sweep(SweepArgs a)
     constexpr bool AF_RESIDENT = NC == 1;
     constexpr bool AF_PREFETCH = !AF_RESIDENT && LMODE != LM_HBM_APPEND;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BUF_F4 = NG * 2 * TILE_ITEMS;                 // float4 per packed tile
+    constexpr int BUF_F4 = NG * 2 * TILE;                 // float4 per packed tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gi = wave & 3, sub = wave >> 2;                   // group in block / 32-item sub-tile
     const int ul = lane & 31, h = lane >> 5;
@@ -143,7 +148,7 @@ void k_sweep(SweepArgs a)
     float4 *ldsB = (float4 *)smem;
     char *p = smem + 2 * BUF_F4 * 16;
     ListEntry *lists_lds = (ListEntry *)p;
-    if (LLDS) p += 8 * K * GROUP_USERS * (int)sizeof(ListEntry);
+    if (LLDS) p += NWAVES * K * GROUP_USERS * (int)sizeof(ListEntry);
     const int PLmax = (1 << a.jmax) - 1;
     // each group's positives table (2^jmax rows x 128 B) is aligned to its own size (see auc_pass)
     const unsigned tbytes = (unsigned)(PLmax + 1) * GROUP_USERS * 4;
@@ -171,7 +176,7 @@ void k_sweep(SweepArgs a)
     if (user >= 0) {
         ntc = a.train_p[user]; nte = a.train_p[user + 1];
         // first train item at or after this wave's first item (lower_bound)
-        const int first_item = t0 * TILE_ITEMS;
+        const int first_item = t0 * TILE;
         int lo = ntc, hi = nte;
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.train_i[mid] < first_item) lo = mid + 1; else hi = mid; }
         ntc = lo;
@@ -192,10 +197,10 @@ void k_sweep(SweepArgs a)
     const int CAP = 2 * K + 32;
     LdsListPtr Ll = (LdsListPtr)((unsigned long long *)lists_lds + wave * K * GROUP_USERS + ul);
     unsigned long long wkey = 0;                                   // LDS list: key of its worst entry (0 = empty slot)
-    GblListPtr Gw = LLDS ? nullptr : a.glists + ((size_t)blockIdx.x * 8 + wave) * GROUP_USERS * CAP;    // wave's 32 buffers
+    GblListPtr Gw = LLDS ? nullptr : a.glists + ((size_t)blockIdx.x * NWAVES + wave) * GROUP_USERS * CAP;    // wave's 32 buffers
     GblListPtr Gu = LLDS ? nullptr : Gw + (size_t)ul * CAP;                                                // this user's
     // small K in HBM: [K][32 users] replace-the-minimum like the LDS list (cheaper than compactions below K ~ 32)
-    GblListPtr Lr = LLDS ? nullptr : a.glists + ((size_t)blockIdx.x * 8 + wave) * GROUP_USERS * CAP + ul;
+    GblListPtr Lr = LLDS ? nullptr : a.glists + ((size_t)blockIdx.x * NWAVES + wave) * GROUP_USERS * CAP + ul;
     float ws = neg_inf_f(); int widx = IDX_EMPTY, wpos = 0, cnt = 0;
     if (h == 0 && (LLDS || !buffered)) for (int i = 0; i < K; i++) {
         if (LLDS) Ll[i * GROUP_USERS] = 0ull; else Lr[i * GROUP_USERS] = ListRaw<float>::pack(neg_inf_f(), IDX_EMPTY);
@@ -244,12 +249,12 @@ void k_sweep(SweepArgs a)
 
     // positives -> LDS, histogram zeroed
     if (AUC) {
-        for (int i = tid; i < GROUPS_PER_BLOCK * (PLb + 1) * GROUP_USERS; i += SWEEP_THREADS) {
+        for (int i = tid; i < GROUPS_PER_BLOCK * (PLb + 1) * GROUP_USERS; i += THREADS) {
             const int g4 = i / ((PLb + 1) * GROUP_USERS), rem = i % ((PLb + 1) * GROUP_USERS);
             const int gg = blk_u * GROUPS_PER_BLOCK + g4;
             posL[g4 * (PLmax + 1) * GROUP_USERS + rem] = gg < a.n_groups ? a.pos_score[(a.grow[gg] + gg) * GROUP_USERS + rem] : pos_inf_f();
         }
-        for (int i = tid; i < GROUPS_PER_BLOCK * (PLmax + 1) * GROUP_USERS; i += SWEEP_THREADS) histL[i] = 0;
+        for (int i = tid; i < GROUPS_PER_BLOCK * (PLmax + 1) * GROUP_USERS; i += THREADS) histL[i] = 0;
     }
     const unsigned pos_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)(posL + gi * (PLmax + 1) * GROUP_USERS + ul);
     const unsigned hist_delta = (unsigned)((const char *)histL - (const char *)posL);
@@ -277,10 +282,11 @@ void k_sweep(SweepArgs a)
         // the DMA's LDS write and puts s_waitcnt vmcnt(0) in front of the MFMA operand reads, which serialises the
         // prefetch with the step it was meant to overlap.  The wait that matters is the explicit one before the
         // end-of-step barrier.
+        constexpr int PIECES = BUF_F4 / 64;                       // 1 KiB each
         #pragma unroll
-        for (int j = 0; j < (NG * 2 + 7) / 8; j++) {
-            const int pc = wave + 8 * j;
-            if (NG * 2 % 8 == 0 || pc < NG * 2) {
+        for (int j = 0; j < (PIECES + NWAVES - 1) / NWAVES; j++) {
+            const int pc = wave + NWAVES * j;
+            if (PIECES % NWAVES == 0 || pc < PIECES) {
                 const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)(dst + pc * 64));
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
                              :: "s"(m0v), "v"(src + pc * 64 + lane) : "memory", "m0");
@@ -290,7 +296,7 @@ void k_sweep(SweepArgs a)
 
     // ---- MFMA: 32 items (registers) x 32 users (lanes), k in index order ----
     auto do_mfma = [&](f32x16 &acc, int buf, int chunk) {
-        const float4 *bb = ldsB + buf * BUF_F4 + h * TILE_ITEMS + sub * 32 + ul;
+        const float4 *bb = ldsB + buf * BUF_F4 + h * TILE + sub * 32 + ul;
         if (!AF_RESIDENT && !AF_PREFETCH) {
             #pragma unroll
             for (int g = 0; g < NG; g++) af[g] = af_src[(size_t)(chunk * NG + g) * 2 * GROUP_USERS];
@@ -306,7 +312,7 @@ void k_sweep(SweepArgs a)
         const int next_chunk = chunk + 1 == NC ? 0 : chunk + 1;
         #pragma unroll
         for (int g = 0; g < NG; g++) {
-            const float4 b = bb[g * 2 * TILE_ITEMS];
+            const float4 b = bb[g * 2 * TILE];
             const float4 u = af[g];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, u.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, u.y, acc, 0, 0, 0);
@@ -319,7 +325,7 @@ void k_sweep(SweepArgs a)
     // ---- epilogue of one 32-item x 32-user tile ----
     unsigned thr_pub = 0;                                       // last key this lane published / observed
     auto do_epi = [&](const f32x16 &acc, int tile, unsigned thr_seen) {
-        const int sb = tile * TILE_ITEMS + sub * 32;            // first item of this wave's sub-tile
+        const int sb = tile * TILE + sub * 32;            // first item of this wave's sub-tile
         float v[16];
         #pragma unroll
         for (int r = 0; r < 16; r++) v[r] = acc[r];
@@ -503,7 +509,7 @@ void k_sweep(SweepArgs a)
             const int unit = i * NC + c;
 #if !defined(RM_FULL_BARRIER) && !defined(RM_ABL_NO_BARRIER)
             if (unit > 0) {                                                       // wait half of the split barrier
-                const unsigned target = 8u * (unsigned)unit;
+                const unsigned target = (unsigned)NWAVES * (unsigned)unit;
                 while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
             }
 #endif
@@ -515,7 +521,9 @@ void k_sweep(SweepArgs a)
             do_mfma(acc, unit & 1, c);
 #endif
 #if !defined(RM_FULL_BARRIER) && !defined(RM_ABL_NO_BARRIER)
+#ifndef RM_ABL_NO_ARRIVE_WAIT
             __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                              // arrive half: the next unit's DMA share has landed
+#endif
             if (lane == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
 #ifndef RM_ABL_NO_EPI
@@ -532,8 +540,8 @@ void k_sweep(SweepArgs a)
     if (pend_cap) merge_pending();
 
     // ---- write this wave's partial: top-K list, validity stats, AUC sum; flush the LDS histogram ----
-    const int n_part = a.n_splits * 2;
-    const int part = split * 2 + sub;
+    const int n_part = a.n_splits * NSUB;
+    const int part = split * NSUB + sub;
     {   // lanes u and u+32 hold two halves of the same user's stats
         const float omax = __shfl_xor(vmax, 32), omin = __shfl_xor(vmin, 32);
         vmax = __builtin_fmaxf(vmax, omax); vmin = __builtin_fminf(vmin, omin);
@@ -566,7 +574,7 @@ void k_sweep(SweepArgs a)
     }
     if (AUC) {
         __syncthreads();
-        for (int i = tid; i < GROUPS_PER_BLOCK * (PLb + 1) * GROUP_USERS; i += SWEEP_THREADS) {
+        for (int i = tid; i < GROUPS_PER_BLOCK * (PLb + 1) * GROUP_USERS; i += THREADS) {
             const int g4 = i / ((PLb + 1) * GROUP_USERS), rem = i % ((PLb + 1) * GROUP_USERS);
             const int gg = blk_u * GROUPS_PER_BLOCK + g4;
             const unsigned c = histL[g4 * (PLmax + 1) * GROUP_USERS + rem];

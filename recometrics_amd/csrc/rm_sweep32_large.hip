@@ -9,7 +9,7 @@ static int launch_ng(int NG, dim3 grid, size_t lds, hipStream_t stream, const Sw
 {
 #define RM_LAUNCH(NGV)                                                                                               \
     case NGV: {                                                                                                      \
-        auto kern = k_sweep<NGV, AUC, DUMP, LMODE>;                                                                  \
+        auto kern = k_sweep<NGV, AUC, DUMP, LMODE, 2>;                                                                  \
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return (int)e;                                                                          \
         hipLaunchKernelGGL(kern, grid, dim3(SWEEP_THREADS), lds, stream, sa);                                        \

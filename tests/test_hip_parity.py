@@ -155,11 +155,13 @@ def test_random_problem_vs_oracle_f64(hip, oracle, m, n, k, K, mean_c):
 
 
 @pytest.mark.parametrize("env", [{"RM_DEBUG_NO_PENDING": "1"}, {"RM_DEBUG_HBM_LISTS": "1"},
-                                 {"RM_DEBUG_HBM_LISTS": "1", "RM_DEBUG_NO_PENDING": "1"}])
+                                 {"RM_DEBUG_HBM_LISTS": "1", "RM_DEBUG_NO_PENDING": "1"},
+                                 {"RM_DEBUG_NSUB2": "1"}, {"RM_DEBUG_NSUB2": "1", "RM_DEBUG_NO_PENDING": "1"}])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_list_schemes_agree(hip, oracle, env, dtype, monkeypatch):
     """the same problem through every top-K list scheme the sweep has (the library reads the switches per call):
-    LDS lists without pending buffers, HBM replace-the-minimum lists with and without them"""
+    LDS lists without pending buffers, HBM replace-the-minimum lists with and without them, and (fp32, <= 64 factors,
+    where three item sub-tiles per step are the default) the two-sub-tile block"""
     from recometrics_amd.synth import make_problem
     for key, val in env.items():
         monkeypatch.setenv(key, val)
