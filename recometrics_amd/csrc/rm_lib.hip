@@ -125,6 +125,7 @@ template <> struct Prec<float> {
     static constexpr bool has_pending = true, pending_for_append = false;   // appends of K > 32 are single stores already
     static constexpr size_t pend_key_bytes = 8;
     static constexpr int max_nsub = 3;
+    static constexpr bool block_carve = true;
     static void set_pending(SweepArgs &sa, int cap, int off) { sa.pend_cap = cap; sa.pend_off = off; }
     static void set_sync(SweepArgs &sa, int off) { sa.sync_off = off; }
 };
@@ -139,6 +140,7 @@ template <> struct Prec<double> {
     static constexpr bool has_pending = true, pending_for_append = true;    // saves four 64-bit shuffles per candidate register
     static constexpr size_t pend_key_bytes = 12;
     static constexpr int max_nsub = 2;
+    static constexpr bool block_carve = false;
     static void set_pending(Sweep64Args &sa, int cap, int off) { sa.pend_cap = cap; sa.pend_off = off; }
     static void set_sync(Sweep64Args &sa, int off) { sa.sync_off = off; }
 };
@@ -274,16 +276,25 @@ void run(const Call<T> &c, hipStream_t stream)
     auto lds_need = [&](bool with_lists) { return lds_need_n(with_lists, nsub); };
     const bool list_in_lds = lds_need(true) + 16 <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS");
     size_t lds_total = lds_need(list_in_lds);
-    const size_t sync_off = lds_total;                     // split-barrier counter of the sweep
-    lds_total += 16;
     // per-lane pending buffers for top-K candidates behind everything else when 2..8 keys per lane still fit
-    int pend_cap = 0; const size_t pend_off = lds_total;
     // (fp32: not for the append-buffer lists of K > 32, whose appends are already single stores)
-    if (P::has_pending && (list_in_lds || K <= 32 || P::pending_for_append) && !getenv("RM_DEBUG_NO_PENDING")) {
-        const size_t per_key = (size_t)n_waves * WAVE * P::pend_key_bytes;        // one key per lane and wave
-        pend_cap = (int)std::min<size_t>(8, (LDS_LIMIT - lds_total) / per_key);
-        if (pend_cap < 2) pend_cap = 0;
-        lds_total += pend_cap * per_key;
+    const bool want_pending = P::has_pending && (list_in_lds || K <= 32 || P::pending_for_append) && !getenv("RM_DEBUG_NO_PENDING");
+    const size_t per_key = (size_t)n_waves * WAVE * P::pend_key_bytes;            // one key per lane and wave
+    int pend_cap = 0; size_t pend_off = 0, sync_off = 0;
+    if (P::block_carve) {
+        // the kernel sizes its tables per block (by the block's own depth) and computes the pending capacity from what
+        // is left below the counter: allocate for the deepest block plus, if it still fits, 8 keys per lane
+        pend_cap = want_pending ? 8 : 0;
+        lds_total = std::min<size_t>(LDS_LIMIT, lds_total + 16 + pend_cap * per_key);
+        sync_off = lds_total - 16;                         // split-barrier counter of the sweep, last 16 bytes
+    } else {
+        sync_off = lds_total; lds_total += 16;
+        pend_off = lds_total;
+        if (want_pending) {
+            pend_cap = (int)std::min<size_t>(8, (LDS_LIMIT - lds_total) / per_key);
+            if (pend_cap < 2) pend_cap = 0;
+            lds_total += pend_cap * per_key;
+        }
     }
 
     Entry<T> *merged = (Entry<T> *)ws.get("merged", sizeof(Entry<T>) * (size_t)m * K);

@@ -144,21 +144,25 @@ void k_sweep(SweepArgs a)
     const bool slot_ok = group_ok && slot < a.n_slots;
     const int K = a.K, n = a.n;
 
-    // ---- LDS carve: [B buf0 | B buf1 | lists (8 waves) | positives (4 groups) | histogram (4 groups)] ----
+    const int glast = min(a.n_groups, (blk_u + 1) * GROUPS_PER_BLOCK) - 1;
+    const int jb = AUC ? a.gj[glast] : 0;                        // block-uniform tree depth
+    const int PLb = (1 << jb) - 1;
+
+    // ---- LDS carve: [B buf0 | B buf1 | lists (per wave) | positives (4 groups) | histogram (4 groups) | pending ... | sync] ----
+    // The launch allocates for the deepest block (jmax); a block sizes its tables by its OWN depth jb and gives what is
+    // left to the pending buffers (one block per CU either way, so the allocation is free).
     float4 *ldsB = (float4 *)smem;
     char *p = smem + 2 * BUF_F4 * 16;
     ListEntry *lists_lds = (ListEntry *)p;
     if (LLDS) p += NWAVES * K * GROUP_USERS * (int)sizeof(ListEntry);
-    const int PLmax = (1 << a.jmax) - 1;
-    // each group's positives table (2^jmax rows x 128 B) is aligned to its own size (see auc_pass)
+    const int PLmax = PLb;
+    // each group's positives table (2^jb rows x 128 B) is aligned to its own size (see auc_pass)
     const unsigned tbytes = (unsigned)(PLmax + 1) * GROUP_USERS * 4;
     p = smem + (((unsigned)(p - smem) + tbytes - 1) / tbytes) * tbytes;
     float *posL = (float *)p;  p += GROUPS_PER_BLOCK * tbytes;
-    unsigned *histL = (unsigned *)p;
-
-    const int glast = min(a.n_groups, (blk_u + 1) * GROUPS_PER_BLOCK) - 1;
-    const int jb = AUC ? a.gj[glast] : 0;                        // block-uniform tree depth
-    const int PLb = (1 << jb) - 1;
+    unsigned *histL = (unsigned *)p;  p += AUC ? GROUPS_PER_BLOCK * tbytes : 0;
+    const int pend_room = (a.sync_off - (int)(p - smem)) / (NWAVES * WAVE * 8);     // keys per lane that still fit
+    char *pend_lds = p;
 
     // ---- per-lane user state ----
     const int user = slot_ok ? a.slot_user[slot] : -1;
@@ -221,9 +225,10 @@ void k_sweep(SweepArgs a)
     // users of the wave at once when one of them fills up.  Offering candidates one score register at a time keeps 1-2
     // lanes busy per list update -- a replace-the-minimum scan in LDS, or a store plus K loads with their HBM round
     // trip when the lists live in HBM; the merge does the same work with every owner lane that has any.
-    const int pend_cap = buffered ? 0 : a.pend_cap;
+    const int pend_want = pend_room < a.pend_cap ? pend_room : a.pend_cap;        // a.pend_cap = the most that is useful (0 = off)
+    const int pend_cap = (buffered || pend_want < 2) ? 0 : pend_want;
     int pcnt = 0;
-    LdsListPtr Pp = (LdsListPtr)((unsigned long long *)(smem + a.pend_off) + wave * pend_cap * WAVE + lane);
+    LdsListPtr Pp = (LdsListPtr)((unsigned long long *)pend_lds + wave * pend_cap * WAVE + lane);
     auto offer_key = [&](unsigned long long key) {                // owner lanes only
         if (LLDS) { keylist_offer<GROUP_USERS>(Ll, K, key, wkey, wpos); return; }
         float s; int item;
