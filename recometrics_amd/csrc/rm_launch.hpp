@@ -11,7 +11,8 @@ constexpr int GROUP_USERS64 = 16;      // users on the lanes of one wavefront in
 
 struct SweepArgs {
     int n, K;
-    int n_slots, n_groups, n_ublocks;     // n_ublocks = ceil(n_groups / 4)
+    int n_slots, n_groups, n_ublocks;     // n_ublocks = user blocks of THIS launch (ceil(n_groups / 4) when there is one)
+    int ublock0;                          // first user block of this launch (depth-split calls launch twice)
     int n_splits, tiles_total;            // item splits (grid = n_ublocks * n_splits)
     int jmax;                             // LDS sizing (all blocks)
     int list_in_lds;

@@ -31,6 +31,8 @@ thread_local double g_timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 thread_local hipEvent_t g_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 thread_local bool g_ev_valid = false;
 thread_local hipStream_t g_ev_stream = nullptr;
+thread_local hipStream_t g_side_stream = nullptr;      // second sweep launch of a depth-split call runs beside the first
+thread_local hipEvent_t g_side_ev[2] = {nullptr, nullptr};
 std::mutex g_mu;
 
 struct RmError { int code; std::string msg; };
@@ -128,6 +130,7 @@ template <> struct Prec<float> {
     static constexpr bool block_carve = true;
     static void set_pending(SweepArgs &sa, int cap, int off) { sa.pend_cap = cap; sa.pend_off = off; }
     static void set_sync(SweepArgs &sa, int off) { sa.sync_off = off; }
+    static void set_ublocks(SweepArgs &sa, int first, int count) { sa.ublock0 = first; sa.n_ublocks = count; }
 };
 template <> struct Prec<double> {
     static constexpr int GU = GROUP_USERS64;
@@ -143,6 +146,7 @@ template <> struct Prec<double> {
     static constexpr bool block_carve = false;
     static void set_pending(Sweep64Args &sa, int cap, int off) { sa.pend_cap = cap; sa.pend_off = off; }
     static void set_sync(Sweep64Args &sa, int off) { sa.sync_off = off; }
+    static void set_ublocks(Sweep64Args &, int, int) {}
 };
 
 inline void check_launch(int rc)
@@ -244,16 +248,16 @@ void run(const Call<T> &c, hipStream_t stream)
     const int n_ublocks = (n_groups + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK;
 
     // ---- sweep geometry ----
-    const size_t lds_auc = want_auc ? (size_t)GROUPS_PER_BLOCK * (1 << jmax) * GU * (sizeof(T) + 4) : 0;
-    // each group's positives table is aligned to its own size (2^jmax rows of GU scores): worst-case padding = one table
-    const size_t tbytes = want_auc ? ((size_t)1 << jmax) * GU * sizeof(T) : 1;
+    // (each group's positives table is aligned to its own size, 2^j rows of GU scores: worst-case padding = one table)
     // sub-tiles per step (waves per block = 4 nsub): three when the fp32 kernel for <= 64 factors keeps its lists in LDS
     // next to the larger item tile -- the third wave per SIMD fills the vector pipe the epilogue leaves idle
     int nsub = 2;
-    auto lds_need_n = [&](bool with_lists, int ns) {
+    auto lds_need_j = [&](bool with_lists, int ns, int j) {                      // LDS of a block of depth j
         const size_t head = P::lds_b(NG, 32 * ns) + (with_lists ? 4ull * ns * K * GU * sizeof(typename P::ListT) : 0);
-        return (want_auc ? (head + tbytes - 1) / tbytes * tbytes : head) + lds_auc;
+        const size_t tb = ((size_t)1 << j) * GU * sizeof(T);
+        return want_auc ? (head + tb - 1) / tb * tb + (size_t)GROUPS_PER_BLOCK * (1 << j) * GU * (sizeof(T) + 4) : head;
     };
+    auto lds_need_n = [&](bool with_lists, int ns) { return lds_need_j(with_lists, ns, jmax); };
     if (P::max_nsub >= 3 && NG <= 8 && lds_need_n(true, 3) + 16 <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS") && !getenv("RM_DEBUG_NSUB2"))
         nsub = 3;
     const int tile_items = 32 * nsub, n_waves = 4 * nsub;
@@ -347,9 +351,38 @@ void run(const Call<T> &c, hipStream_t stream)
         P::set_sync(sa, (int)sync_off);
 
         HIP_CHECK(hipEventRecord(g_ev[1], stream));
-        dispatch_sweep(want_auc, false, list_in_lds, nsub, NG, dim3(n_blocks), lds_total, stream, sa);
+        // Depth split: when only the deepest user blocks force the lists out of LDS (the allocation is sized per launch,
+        // the tables per block), the shallow blocks [0, u_split) get their own launch with LDS lists.  The two launches
+        // run side by side on two streams so that neither pays a partially filled last round of its own.
+        int u_split = 0, j_shallow = -1;
+        if (P::block_carve && !list_in_lds && K <= 32 && want_auc && !getenv("RM_DEBUG_HBM_LISTS") && !getenv("RM_DEBUG_NO_DEPTH_SPLIT")) {
+            for (int j = jmax - 1; j >= 0 && j_shallow < 0; j--)
+                if (lds_need_j(true, nsub, j) + 16 <= LDS_LIMIT) j_shallow = j;
+            if (j_shallow >= 0) u_split = hp.class_offset[j_shallow + 1] / (GROUPS_PER_BLOCK * GU);
+        }
+        if (u_split > 0) {
+            if (!g_side_stream) {
+                HIP_CHECK(hipStreamCreateWithFlags(&g_side_stream, hipStreamNonBlocking));
+                for (auto &e : g_side_ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            }
+            typename P::Args sb = sa;                              // the deep blocks: lists in HBM, as computed above
+            P::set_ublocks(sb, u_split, n_ublocks - u_split);
+            typename P::Args sl = sa;                              // the shallow blocks: lists in LDS
+            P::set_ublocks(sl, 0, u_split);
+            const size_t lds_l = std::min<size_t>(LDS_LIMIT, lds_need_j(true, nsub, j_shallow) + 16 + (want_pending ? 8 : 0) * per_key);
+            P::set_pending(sl, want_pending ? 8 : 0, 0);
+            P::set_sync(sl, (int)lds_l - 16);
+            HIP_CHECK(hipEventRecord(g_side_ev[0], stream));
+            HIP_CHECK(hipStreamWaitEvent(g_side_stream, g_side_ev[0], 0));
+            dispatch_sweep(want_auc, false, false, nsub, NG, dim3((unsigned)(n_ublocks - u_split) * n_splits), lds_total, g_side_stream, sb);
+            HIP_CHECK(hipEventRecord(g_side_ev[1], g_side_stream));
+            dispatch_sweep(want_auc, false, true, nsub, NG, dim3((unsigned)u_split * n_splits), lds_l, stream, sl);
+            HIP_CHECK(hipStreamWaitEvent(stream, g_side_ev[1], 0));
+        } else {
+            dispatch_sweep(want_auc, false, list_in_lds, nsub, NG, dim3(n_blocks), lds_total, stream, sa);
+        }
         HIP_CHECK(hipEventRecord(g_ev[2], stream));
-        g_timings[4] = 1; g_timings[5] = n_splits; g_timings[6] = n_blocks; g_timings[7] = (double)lds_total;
+        g_timings[4] = u_split > 0 ? 2 : 1; g_timings[5] = n_splits; g_timings[6] = n_blocks; g_timings[7] = (double)lds_total;
     } else {
         HIP_CHECK(hipEventRecord(g_ev[1], stream));
         HIP_CHECK(hipEventRecord(g_ev[2], stream));

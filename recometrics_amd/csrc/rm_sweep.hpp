@@ -137,7 +137,7 @@ void k_sweep(SweepArgs a)
     const int ul = lane & 31, h = lane >> 5;
     // user blocks are sorted by positive-tree depth (cheapest first): launch the deepest (slowest) ones first so that
     // the last round of the grid is made of the cheap ones
-    const int blk_u = a.n_ublocks - 1 - (int)(blockIdx.x % a.n_ublocks), split = blockIdx.x / a.n_ublocks;
+    const int blk_u = a.ublock0 + a.n_ublocks - 1 - (int)(blockIdx.x % a.n_ublocks), split = blockIdx.x / a.n_ublocks;
     const int group = blk_u * GROUPS_PER_BLOCK + gi;
     const bool group_ok = group < a.n_groups;
     const int slot = group * GROUP_USERS + ul;

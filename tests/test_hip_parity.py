@@ -131,6 +131,7 @@ def _check_against_oracle(hip, oracle, pr, k, dtype=np.float32, **kw):
     (90, 3000, 500, 5, 30),
     (200, 5000, 128, 20, 120),     # BASELINE config C3's factor count and K: replace-the-minimum lists in HBM + pending buffers
     (160, 7000, 128, 32, 120),     # largest K of that scheme
+    (900, 4000, 128, 20, 90),      # enough users for a depth split: shallow blocks with LDS lists beside deep ones with HBM lists
     (100, 6000, 256, 20, 100),     # the same with a streamed factor axis (prefetched user factors)
 ])
 def test_random_problem_vs_oracle(hip, oracle, m, n, k, K, mean_c):
