@@ -18,7 +18,7 @@ template <class T> inline size_t finalize_lds_bytes(int K, int n_part) { return 
 struct AucPart { unsigned long long sum_ranks; double s1, s2; int nvalid, pad; };
 
 template <class T, class S> struct FinalArgs {     // T = real_t of inputs/outputs, S = score type of the sweep
-    int m, n, K, n_part, req, cumulative, noise, gu, n_slots, debug_stop;
+    int m, n, K, n_part, req, cumulative, noise, gu, n_slots;
     const int *slot_user, *slot_chunk;
     const int *train_p, *test_p, *test_i; const T *test_v;
     const int *flags, *user_nslots, *uslot_base, *slot_index;
@@ -176,7 +176,6 @@ __global__ void k_finalize(FinalArgs<T, S> a)
         fill_user_nan(a, u); return;
     }
     if (a.status) a.status[u] = 0;
-    if (a.debug_stop == 1) return;
 
     const int *ti = a.test_i + te0;
     const T *tv = a.test_v ? a.test_v + te0 : nullptr;
@@ -232,7 +231,6 @@ __global__ void k_finalize(FinalArgs<T, S> a)
         }
     }
 
-    if (a.debug_stop == 2) return;
     // ---- NaN overrides (:750-788) ----
     if (kleqn) {
         if (!cum) {
@@ -270,7 +268,6 @@ __global__ void k_finalize(FinalArgs<T, S> a)
         if (a.pr) a.pr[u] = (T)(ap_full / (double)npos);
     }
 
-    if (a.debug_stop == 3) return;
     // ---- NDCG normalisation (:868-961) ----
     if (a.ndcg) {
         const int L = K < npos ? K : npos;

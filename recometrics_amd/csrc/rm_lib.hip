@@ -408,7 +408,6 @@ void run(const Call<T> &c, hipStream_t stream)
     fa.ndcg = c.out[5]; fa.hit = c.out[6]; fa.rr = c.out[7]; fa.roc = c.out[8]; fa.pr = c.out[9];
     fa.merged = merged; fa.rank_sorted = rank_sorted; fa.status = c.status;
     fa.n_slots = n_slots; fa.slot_user = slot_user; fa.slot_chunk = slot_chunk;
-    { const char *ds = getenv("RM_DEBUG_FIN_STOP"); fa.debug_stop = ds ? atoi(ds) : 0; }
     hipLaunchKernelGGL((k_finalize_skipped<T, T>), dim3(cdiv(m, 256)), dim3(256), 0, stream, fa);
     if (n_slots > 0) {
         if (want_auc) {

@@ -215,6 +215,7 @@ void k_sweep(SweepArgs a)
             const int l = __ffsll((long long)need) - 1;
             need &= need - 1;
             const int c = lane_bcast<int>(cnt, l);
+            RM_STAT(8, 1); RM_STAT(9, c);
             float ks; int ki;
             wave_compact<float>(Gw + (size_t)l * CAP, c, K, lane, ks, ki);
             if (lane == l) { cnt = c < K ? c : K; if (c >= K) { ws = ks; widx = ki; } }

@@ -25,5 +25,5 @@ if os.environ.get("RM_PRINT_STATS"):
     buf = (ctypes.c_ulonglong * 16)()
     lib.rm_debug_stats(buf, 1)
     runs = steps + 1
-    names = ["wave_steps", "event_steps", "event_lanes", "hit_cells", "hit_lanes", "merges", "merge_iters", "merge_replacing"]
+    names = ["wave_steps", "event_steps", "event_lanes", "hit_cells", "hit_lanes", "merges", "merge_iters", "merge_replacing", "compactions", "compacted_entries"]
     print(json.dumps({nm: buf[i] / runs for i, nm in enumerate(names)}))
