@@ -105,13 +105,15 @@ __global__ void k_export_rank(int m, int K, const Entry<S> *merged, int *topk_id
     topk_score[i] = merged[i].s;
 }
 
-__global__ void k_export_pos_rank(long long nnz, int m, const int *test_p, const int *pos_order,
+__global__ void k_export_pos_rank(long long nnz, int m, const int *test_p, const int *flags, const int *pos_order,
                                   const long long *rank_sorted, long long *pos_rank)
 {
-    // one thread per user row (rows are short)
+    // one thread per user row (rows are short).  Users that were never ranked (skipped, or NDCG-only) have no entry in
+    // pos_order -- whatever the workspace held before -- and report rank 0.
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= m) return;
-    for (int e = test_p[u]; e < test_p[u + 1]; e++) pos_rank[e] = rank_sorted[test_p[u] + pos_order[e]];
+    const bool ranked = (flags[u] & UF_ACTIVE) && !(flags[u] & UF_ONLY_NDCG);
+    for (int e = test_p[u]; e < test_p[u + 1]; e++) pos_rank[e] = ranked ? rank_sorted[test_p[u] + pos_order[e]] : 0;
 }
 
 // ---- per-precision traits: which sweep kernel, which operand image, how many users ride on a wavefront ----
@@ -423,7 +425,7 @@ void run(const Call<T> &c, hipStream_t stream)
         hipLaunchKernelGGL(k_export_rank<T>, dim3(cdiv((long long)m * K, 256)), dim3(256), 0, stream, m, K, merged, c.topk_idx, c.topk_score);
     if (c.pos_rank) {
         if (want_auc && n_slots > 0)
-            hipLaunchKernelGGL(k_export_pos_rank, dim3(cdiv(m, 128)), dim3(128), 0, stream, c.nnz_test, m, c.test_p, pos_order, rank_sorted, c.pos_rank);
+            hipLaunchKernelGGL(k_export_pos_rank, dim3(cdiv(m, 128)), dim3(128), 0, stream, c.nnz_test, m, c.test_p, flags, pos_order, rank_sorted, c.pos_rank);
         else
             HIP_CHECK(hipMemsetAsync(c.pos_rank, 0, sizeof(long long) * (size_t)c.nnz_test, stream));
     }

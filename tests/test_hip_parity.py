@@ -170,6 +170,36 @@ def test_list_schemes_agree(hip, oracle, env, dtype, monkeypatch):
     _check_against_oracle(hip, oracle, pr, 12, dtype=dtype)
 
 
+def test_rank_outputs_do_not_depend_on_the_previous_call(hip, oracle):
+    """the device workspace is reused between calls: users that are never ranked (here: all candidates fit into K, no
+    AUC tables) must report rank 0 whatever an earlier, larger problem left behind"""
+    from recometrics_amd.synth import make_problem
+    big = make_problem(1200, 4000, 16, np.float32, mean_c=60, seed=21)
+    _check_against_oracle(hip, oracle, big, 10)
+    small = make_problem(700, 20, 1, np.float32, mean_c=3.3, seed=22)
+    _check_against_oracle(hip, oracle, small, 19)
+
+
+def test_random_shapes_and_options(hip, oracle):
+    """a fixed-seed sample of scratch/fuzz.py: random shapes, precisions and option combinations against the oracle"""
+    from recometrics_amd.synth import make_problem
+    rng = np.random.default_rng(2024)
+    for _ in range(60):
+        dtype = np.float32 if rng.random() < 0.65 else np.float64
+        m = int(rng.choice([1, 7, 33, 100, 300, 700]))
+        n = int(rng.choice([20, 97, 300, 1111, 4000]))
+        k = int(rng.choice([1, 5, 16, 33, 64, 100, 128, 200]))
+        K = int(min(n - 1, rng.choice([1, 3, 10, 20, 33, 60])))
+        mean_c = float(min(n / 6, rng.choice([4, 20, 60, 150, 500])))
+        kw = dict(cold=bool(rng.random() < 0.7), min_items_pool=int(rng.choice([1, 2, 10])), min_pos_test=int(rng.choice([1, 1, 3])))
+        pr = make_problem(m, n, k, dtype, mean_c=mean_c, seed=int(rng.integers(1 << 30)))
+        for cumulative in (False, True):
+            want = oracle.calc(pr["A"], pr["B"], pr["train"], pr["test"], K, cumulative=cumulative, dtype=dtype, nthreads=8, **kw)
+            got = hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], K, cumulative=cumulative, dtype=dtype, **kw)
+            for name in want:
+                assert_close(got[name], want[name], TOL, "%s %s m=%d n=%d k=%d K=%d %s" % (name, dtype.__name__, m, n, k, K, kw))
+
+
 def test_heavy_users_many_positives(hip, oracle):
     """users with far more than 63 positives (multi-slot AUC chunks) and with dense train rows"""
     from recometrics_amd.synth import make_problem
