@@ -189,7 +189,7 @@ def main():
         # the north-star shape (n = 1M items, 128 factors): B = 512 MB does not fit the Infinity Cache
         try:
             m2, n2, k2, _, K2, c2, s2 = CONFIGS["NS"]
-            m2 = 8192
+            m2 = 32768
             del prob.A, prob.B
             p2 = DeviceProblem(torch, dev, m2, n2, k2, c2, s2, K2)
             dt2, sw2, pr2, fi2, _ = measure(torch, dist, binding, p2, 2, 1, 1, None)
