@@ -260,6 +260,22 @@ def test_python_api_drop_in(hip, oracle):
         calc_reco_metrics(Xtr, Xte, pr["A"], pr["B"], k=n + 1)
 
 
+def test_c_abi_error_statuses(hip):
+    """status codes instead of exceptions (include/recometrics_hip.h): unsupported shapes and bad arguments come back
+    as errors with a message, never as wrong numbers; the next valid call works"""
+    from recometrics_amd.synth import make_problem
+    pr = make_problem(40, 300, 8, np.float32, mean_c=20, seed=3)
+    good = hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], 5)
+    wide = np.zeros((40, 520), np.float32)                     # more factors than the kernels are built for
+    with pytest.raises(RuntimeError, match="512 factors"):
+        hip_calc(hip, wide, np.zeros((300, 520), np.float32), pr["train"], pr["test"], 5)
+    with pytest.raises(ValueError, match="k_metrics"):
+        hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], 0)
+    again = hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], 5)
+    for name in good:
+        assert_same_bits(again[name], good[name], "repeat after an error: " + name)
+
+
 def test_python_api_modes(hip, oracle):
     """float64 inputs, strided factor matrices (lda > k), X_train=None, the non-personalised mode (A = B = None with
     item biases), cumulative DataFrame output -- reference recometrics/__init__.py:429-436,:469-473,:560-562,:615-626"""
