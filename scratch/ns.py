@@ -12,6 +12,7 @@ m, n, k, dtype, K, mean_c, seed = CONFIGS[wl]
 m = users
 K = int(os.environ.get('NS_K', K))
 k = int(os.environ.get('NS_FACTORS', k))
+if os.environ.get('NS_DTYPE'): dtype = {'f32': np.float32, 'f64': np.float64}[os.environ['NS_DTYPE']]
 torch.cuda.set_device(0); binding.load(); binding.set_device(0)
 p = DeviceProblem(torch, torch.device("cuda", 0), m, n, k, mean_c, seed, K, dtype)
 dt, sw, pr, fi, tm = measure(torch, dist, binding, p, steps, 1, 1, None)
