@@ -380,10 +380,12 @@ void k_sweep(SweepArgs a)
         }
 #ifndef RM_ABL_NO_STATS
         // (2) min / max over candidates (NaN-ignoring, so the sentinel is invisible) (:519-524): v_max3 / v_min3 trees
-        const float tmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), __builtin_fmaxf(v[2], v[3])),
-                                                           __builtin_fmaxf(__builtin_fmaxf(v[4], v[5]), __builtin_fmaxf(v[6], v[7]))),
-                                           __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(v[8], v[9]), __builtin_fmaxf(v[10], v[11])),
-                                                           __builtin_fmaxf(__builtin_fmaxf(v[12], v[13]), __builtin_fmaxf(v[14], v[15]))));
+        // (the maxima of the four register quads are kept: the top-K path below skips a whole quad with one test)
+        const float qmax[4] = {__builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), __builtin_fmaxf(v[2], v[3])),
+                               __builtin_fmaxf(__builtin_fmaxf(v[4], v[5]), __builtin_fmaxf(v[6], v[7])),
+                               __builtin_fmaxf(__builtin_fmaxf(v[8], v[9]), __builtin_fmaxf(v[10], v[11])),
+                               __builtin_fmaxf(__builtin_fmaxf(v[12], v[13]), __builtin_fmaxf(v[14], v[15]))};
+        const float tmax = __builtin_fmaxf(__builtin_fmaxf(qmax[0], qmax[1]), __builtin_fmaxf(qmax[2], qmax[3]));
         const float tmin = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fminf(v[0], v[1]), __builtin_fminf(v[2], v[3])),
                                                            __builtin_fminf(__builtin_fminf(v[4], v[5]), __builtin_fminf(v[6], v[7]))),
                                            __builtin_fminf(__builtin_fminf(__builtin_fminf(v[8], v[9]), __builtin_fminf(v[10], v[11])),
@@ -403,13 +405,19 @@ void k_sweep(SweepArgs a)
         if (cm && pend_cap) {
             unsigned ov = 0;                                    // score registers that did not fit the lane's buffer
             #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const bool c = v[r] >= thr;
-                if (__ballot(c)) {
-                    RM_STAT(3, 1); RM_STAT(4, __popcll(__ballot(c)));
-                    if (c) {
-                        if (pcnt < pend_cap) { Pp[pcnt * WAVE] = pack_key(v[r], sb + mfma32_row(r, h)); pcnt++; }
-                        else ov |= 1u << r;
+            for (int qd = 0; qd < 4; qd++) {
+#ifndef RM_ABL_NO_STATS
+                if (!__ballot(qmax[qd] >= thr)) continue;         // no lane has a candidate among these four registers
+#endif
+                #pragma unroll
+                for (int r = 4 * qd; r < 4 * qd + 4; r++) {
+                    const bool c = v[r] >= thr;
+                    if (__ballot(c)) {
+                        RM_STAT(3, 1); RM_STAT(4, __popcll(__ballot(c)));
+                        if (c) {
+                            if (pcnt < pend_cap) { Pp[pcnt * WAVE] = pack_key(v[r], sb + mfma32_row(r, h)); pcnt++; }
+                            else ov |= 1u << r;
+                        }
                     }
                 }
             }
