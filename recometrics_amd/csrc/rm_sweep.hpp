@@ -237,7 +237,9 @@ void k_sweep(SweepArgs a)
         if (buffered) { if (s > ws || (s == ws && item < widx)) Gu[cnt++] = ListRaw<float>::pack(s, item); }
         else if (s >= ws) list_offer<float, GROUP_USERS>(Lr, K, s, item, ws, widx, wpos);
     };
+    bool merged = false;                                          // a merge since the bound was last published
     auto merge_pending = [&]() {
+        merged = true;
         const int pc = __shfl_xor(pcnt, 32);                      // the partner lane's count (same user, other item rows)
         const int lim = h == 0 ? (pcnt > pc ? pcnt : pc) : 0;
         RM_STAT(5, 1);
@@ -460,7 +462,8 @@ void k_sweep(SweepArgs a)
             }
             if (!LLDS && buffered) compact_users(__ballot(h == 0 && primary && cnt > 2 * K));
         }
-        if (cm) {
+        if (cm && (!pend_cap || merged)) {                      // with pending buffers the K-th best only moves in a merge
+            merged = false;
             const float t2 = __shfl(ws, ul);
             if (primary) {
                 thr = t2 > thr ? t2 : thr;
