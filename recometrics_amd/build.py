@@ -9,7 +9,8 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "librecometrics_hip.so")
-SOURCES = ["rm_lib.hip", "rm_sweep32.hip", "rm_sweep32_large.hip", "rm_sweep64_small.hip", "rm_sweep64_large.hip", "rm_split.cpp"]
+SOURCES = ["rm_lib.hip", "rm_sweep32.hip", "rm_sweep32_hbm.hip", "rm_sweep32_n3.hip", "rm_sweep32_large.hip",
+           "rm_sweep64_small.hip", "rm_sweep64_large.hip", "rm_split.cpp"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-inline-asm"]   # m0 is clobbered by the LDS-DMA asm on purpose
 
 

@@ -59,6 +59,8 @@ struct Sweep64Args {
 
 // return 0 = launched, -1 = unsupported factor-group count, otherwise a hipError_t
 int launch_sweep32(bool auc, bool dump, int lmode, int nsub, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa);
+int launch_sweep32_hbm(bool auc, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa);
+int launch_sweep32_n3(bool auc, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa);
 int launch_sweep32_large(bool auc, bool dump, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa);
 int launch_sweep64(bool auc, bool dump, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa);
 int launch_sweep64_small(bool auc, bool dump, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa);

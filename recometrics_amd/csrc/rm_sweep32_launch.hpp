@@ -1,0 +1,32 @@
+// rm_sweep32_launch.hpp -- shared by the translation units that instantiate the fp32 sweep (split so that they compile
+// in parallel): one launcher per (AUC, DUMP, list mode, sub-tiles) over the factor-group counts a unit is built for.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rm_sweep.hpp"
+
+namespace rm {
+
+template <int NGV, bool AUC, bool DUMP, int LMODE, int NSUB>
+static int launch_one(dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa)
+{
+    auto kern = k_sweep<NGV, AUC, DUMP, LMODE, NSUB>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, grid, dim3(256 * NSUB), lds, stream, sa);
+    return (int)hipGetLastError();
+}
+
+// factor-group counts 2, 4, 8 (and 16 when WITH16): the kernels for up to 64 (128) factors
+template <bool AUC, bool DUMP, int LMODE, int NSUB, bool WITH16>
+static int launch_small(int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa)
+{
+    switch (NG) {
+        case 2: return launch_one<2, AUC, DUMP, LMODE, NSUB>(grid, lds, stream, sa);
+        case 4: return launch_one<4, AUC, DUMP, LMODE, NSUB>(grid, lds, stream, sa);
+        case 8: return launch_one<8, AUC, DUMP, LMODE, NSUB>(grid, lds, stream, sa);
+        case 16: return WITH16 ? launch_one<WITH16 ? 16 : 8, AUC, DUMP, LMODE, NSUB>(grid, lds, stream, sa) : -1;
+        default: return -1;
+    }
+}
+
+} // namespace rm
