@@ -236,6 +236,12 @@ void run(const Call<T> &c, hipStream_t stream)
     hipLaunchKernelGGL(k_group_rows, dim3(cdiv(group_bound, 256)), dim3(256), 0, stream, plan, blk_j, blk_base, blk_base + block_bound, gj, grow);
     hipLaunchKernelGGL(k_absmax<T>, dim3(512), dim3(256), 0, stream, c.A, c.lda, (long long)m, k, &plan->amax_a, &plan->nonfinite);
     hipLaunchKernelGGL(k_absmax<T>, dim3(1024), dim3(256), 0, stream, c.B, c.ldb, (long long)n, k, &plan->amax_b, &plan->nonfinite);
+    // log2(i + 2) for the DCG discounts, from the host's libm like the reference's (:620,:902, int -> double log2); staged
+    // here so that the one synchronisation of the call (the plan read-back below) also covers this stack-owned buffer
+    std::vector<double> lt((size_t)K);
+    for (int i = 0; i < K; i++) lt[i] = std::log2(i + 2);
+    double *log2tab = (double *)ws.get("log2tab", sizeof(double) * (size_t)K);
+    HIP_CHECK(hipMemcpyAsync(log2tab, lt.data(), sizeof(double) * (size_t)K, hipMemcpyHostToDevice, stream));
     Plan hp;
     HIP_CHECK(hipMemcpyAsync(&hp, plan, sizeof(Plan), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
@@ -392,12 +398,6 @@ void run(const Call<T> &c, hipStream_t stream)
     }
 
     // ---- finalize ----
-    std::vector<double> lt((size_t)K);
-    for (int i = 0; i < K; i++) lt[i] = std::log2(i + 2);          // same call as reference :620,:902 (int -> double log2)
-    double *log2tab = (double *)ws.get("log2tab", sizeof(double) * (size_t)K);
-    HIP_CHECK(hipMemcpyAsync(log2tab, lt.data(), sizeof(double) * (size_t)K, hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));                        // lt is a stack-owned staging buffer
-
     long long *rank_sorted = nullptr;
     if (c.pos_rank) rank_sorted = (long long *)ws.get("rank_sorted", sizeof(long long) * (size_t)std::max<long long>(c.nnz_test, 1));
     if (rank_sorted) HIP_CHECK(hipMemsetAsync(rank_sorted, 0, sizeof(long long) * (size_t)std::max<long long>(c.nnz_test, 1), stream));
