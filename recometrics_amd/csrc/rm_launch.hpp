@@ -36,7 +36,8 @@ struct SweepArgs {
 
 struct Sweep64Args {
     int n, K;
-    int n_slots, n_groups, n_ublocks;
+    int n_slots, n_groups, n_ublocks;     // n_ublocks = user blocks of THIS launch
+    int ublock0;                          // first user block of this launch (depth-split calls launch twice)
     int n_splits, tiles_total;
     int jmax;
     int check_nan;

@@ -128,6 +128,7 @@ template <> struct Prec<float> {
     static long long users_units(int groups, int NG) { return (long long)groups * NG * 2 * GU; }
     static constexpr bool has_pending = true, pending_for_append = false;   // appends of K > 32 are single stores already
     static constexpr size_t pend_key_bytes = 8;
+    static constexpr int pend_cap_max = 8;                // keys per lane: measured flat from 3 to 8 at C2, best at 6-8
     static constexpr int max_nsub = 3;
     static constexpr bool block_carve = true;
     static void set_pending(SweepArgs &sa, int cap, int off) { sa.pend_cap = cap; sa.pend_off = off; }
@@ -144,11 +145,12 @@ template <> struct Prec<double> {
     static long long users_units(int groups, int NG) { return (long long)groups * NG * 4 * GU; }
     static constexpr bool has_pending = true, pending_for_append = true;    // saves four 64-bit shuffles per candidate register
     static constexpr size_t pend_key_bytes = 12;
+    static constexpr int pend_cap_max = 3;                // a user spans four lanes here: larger buffers only delay the bound (measured)
     static constexpr int max_nsub = 2;
-    static constexpr bool block_carve = false;
+    static constexpr bool block_carve = true;
     static void set_pending(Sweep64Args &sa, int cap, int off) { sa.pend_cap = cap; sa.pend_off = off; }
     static void set_sync(Sweep64Args &sa, int off) { sa.sync_off = off; }
-    static void set_ublocks(Sweep64Args &, int, int) {}
+    static void set_ublocks(Sweep64Args &sa, int first, int count) { sa.ublock0 = first; sa.n_ublocks = count; }
 };
 
 inline void check_launch(int rc)
@@ -296,7 +298,7 @@ void run(const Call<T> &c, hipStream_t stream)
     if (P::block_carve) {
         // the kernel sizes its tables per block (by the block's own depth) and computes the pending capacity from what
         // is left below the counter: allocate for the deepest block plus, if it still fits, 8 keys per lane
-        pend_cap = want_pending ? 8 : 0;
+        pend_cap = want_pending ? P::pend_cap_max : 0;
         lds_total = std::min<size_t>(LDS_LIMIT, lds_total + 16 + pend_cap * per_key);
         sync_off = lds_total - 16;                         // split-barrier counter of the sweep, last 16 bytes
     } else {
@@ -377,8 +379,8 @@ void run(const Call<T> &c, hipStream_t stream)
             P::set_ublocks(sb, u_split, n_ublocks - u_split);
             typename P::Args sl = sa;                              // the shallow blocks: lists in LDS
             P::set_ublocks(sl, 0, u_split);
-            const size_t lds_l = std::min<size_t>(LDS_LIMIT, lds_need_j(true, nsub, j_shallow) + 16 + (want_pending ? 8 : 0) * per_key);
-            P::set_pending(sl, want_pending ? 8 : 0, 0);
+            const size_t lds_l = std::min<size_t>(LDS_LIMIT, lds_need_j(true, nsub, j_shallow) + 16 + (want_pending ? P::pend_cap_max : 0) * per_key);
+            P::set_pending(sl, want_pending ? P::pend_cap_max : 0, 0);
             P::set_sync(sl, (int)lds_l - 16);
             HIP_CHECK(hipEventRecord(g_side_ev[0], stream));
             HIP_CHECK(hipStreamWaitEvent(g_side_stream, g_side_ev[0], 0));

@@ -82,25 +82,30 @@ void k_sweep64(Sweep64Args a)
     const int ul = lane & 15, q = lane >> 4;
     // user blocks are sorted by positive-tree depth (cheapest first): launch the deepest (slowest) ones first so that
     // the last round of the grid is made of the cheap ones
-    const int blk_u = a.n_ublocks - 1 - (int)(blockIdx.x % a.n_ublocks), split = blockIdx.x / a.n_ublocks;
+    const int blk_u = a.ublock0 + a.n_ublocks - 1 - (int)(blockIdx.x % a.n_ublocks), split = blockIdx.x / a.n_ublocks;
     const int group = blk_u * GROUPS_PER_BLOCK + gi;
     const bool group_ok = group < a.n_groups;
     const int slot = group * GU + ul;
     const bool slot_ok = group_ok && slot < a.n_slots;
     const int K = a.K, n = a.n;
 
-    // ---- LDS carve: [B buf0 | B buf1 | lists (8 waves) | positives (4 groups) | histogram (4 groups)] ----
+    const int glast = min(a.n_groups, (blk_u + 1) * GROUPS_PER_BLOCK) - 1;
+    const int jb = AUC ? a.gj[glast] : 0;
+    const int PLb = (1 << jb) - 1;
+
+    // ---- LDS carve: [B buf0 | B buf1 | lists (8 waves) | positives (4 groups) | histogram (4 groups) | pending ... | sync] ----
+    // tables are sized by the block's OWN depth; what the launch allocated beyond that (it is sized for the deepest
+    // block) goes to this block's pending buffers
     f64x2 *ldsB = (f64x2 *)smem;
     char *p = smem + 2 * BUF_D2 * 16;
     u32x4 *lists_lds = (u32x4 *)p;
     if (LLDS) p += 8 * K * GU * 16;
-    const int PLmax = (1 << a.jmax) - 1;
+    const int PLmax = PLb;
     double *posL = (double *)p;  p += GROUPS_PER_BLOCK * (PLmax + 1) * GU * 8;
-    unsigned *histL = (unsigned *)p;
-
-    const int glast = min(a.n_groups, (blk_u + 1) * GROUPS_PER_BLOCK) - 1;
-    const int jb = AUC ? a.gj[glast] : 0;
-    const int PLb = (1 << jb) - 1;
+    unsigned *histL = (unsigned *)p;  p += AUC ? GROUPS_PER_BLOCK * (PLmax + 1) * GU * 4 : 0;
+    p = smem + (((int)(p - smem) + 15) & ~15);
+    const int pend_room = (a.sync_off - (int)(p - smem)) / (8 * WAVE * 12);              // entries per lane that still fit
+    char *pend_lds = p;
 
     const int user = slot_ok ? a.slot_user[slot] : -1;
     const bool primary = slot_ok && a.slot_chunk[slot] == 0;
@@ -169,10 +174,11 @@ void k_sweep64(Sweep64Args a)
     // score register that holds a candidate.  See the fp32 sweep.
     typedef __attribute__((address_space(3))) double *LdsF64Ptr;
     typedef __attribute__((address_space(3))) int *LdsI32Ptr;
-    const int pend_cap = a.pend_cap;
+    const int pend_want = pend_room < a.pend_cap ? pend_room : a.pend_cap;        // a.pend_cap = the most that is useful (0 = off)
+    const int pend_cap = pend_want < 2 ? 0 : pend_want;
     int pcnt = 0;
-    LdsF64Ptr Ps = (LdsF64Ptr)(smem + a.pend_off) + wave * pend_cap * WAVE + lane;
-    LdsI32Ptr Pi = (LdsI32Ptr)(smem + a.pend_off + 8 * pend_cap * WAVE * 8) + wave * pend_cap * WAVE + lane;
+    LdsF64Ptr Ps = (LdsF64Ptr)pend_lds + wave * pend_cap * WAVE + lane;
+    LdsI32Ptr Pi = (LdsI32Ptr)(pend_lds + 8 * pend_cap * WAVE * 8) + wave * pend_cap * WAVE + lane;
     auto offer_entry = [&](double s, int item) {                  // owner lanes only
         if (LLDS) { if (s >= ws) list_offer<double, GU>(Ll, K, s, item, ws, widx, wpos); }
         else if (buffered) { if (s > ws || (s == ws && item < widx)) Gu[cnt++] = ListRaw<double>::pack(s, item); }

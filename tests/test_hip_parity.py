@@ -148,6 +148,7 @@ def test_random_problem_vs_oracle(hip, oracle, m, n, k, K, mean_c):
     (60, 2000, 400, 5, 30),        # > 256 factors in fp64
     (80, 6000, 256, 30, 120),      # fp64 replace-the-minimum lists in HBM (too large for LDS, K <= 32) + pending buffers
     (96, 9000, 64, 12, 60),        # fp64 LDS lists + pending buffers
+    (500, 3000, 128, 28, 90),      # fp64 depth split: shallow blocks with LDS lists beside deep ones with HBM lists
 ])
 def test_random_problem_vs_oracle_f64(hip, oracle, m, n, k, K, mean_c):
     from recometrics_amd.synth import make_problem
