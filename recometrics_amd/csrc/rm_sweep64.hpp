@@ -184,7 +184,9 @@ void k_sweep64(Sweep64Args a)
         else if (buffered) { if (s > ws || (s == ws && item < widx)) Gu[cnt++] = ListRaw<double>::pack(s, item); }
         else if (s >= ws) list_offer<double, GU>(Lr, K, s, item, ws, widx, wpos);
     };
+    bool merged = false;                                          // a merge since the bound was last published
     auto merge_pending = [&]() {
+        merged = true;
         const int c1 = __shfl(pcnt, ul + 16), c2 = __shfl(pcnt, ul + 32), c3 = __shfl(pcnt, ul + 48);
         const int m01 = pcnt > c1 ? pcnt : c1, m23 = c2 > c3 ? c2 : c3;
         const int lim = q == 0 ? (m01 > m23 ? m01 : m23) : 0;
@@ -328,7 +330,8 @@ void k_sweep64(Sweep64Args a)
             }
             if (!LLDS && buffered) compact_users(__ballot(q == 0 && primary && cnt > 2 * K));
         }
-        if (cm) {
+        if (cm && (!pend_cap || merged)) {                      // with pending buffers the K-th best only moves in a merge
+            merged = false;
             const double t2 = __shfl(ws, ul);
             if (primary) {
                 thr = t2 > thr ? t2 : thr;
