@@ -42,7 +42,7 @@ typedef Entry<float> ListEntry;
 
 template <class T> struct PartialStat {          // one wavefront's validity / AUC state for one slot
     T vmax, vmin;
-    unsigned long long rocsum;                    // sum over candidates of #positives-in-chunk scored below it
+    unsigned long long rocsum;                    // unused (the rank sums come from the histograms, k_auc_slots); keeps the layout
     int has_nan; int pad;
 };
 

@@ -44,7 +44,7 @@ typedef __attribute__((address_space(3))) unsigned *LdsU32Ptr;
 // lower_bound is one OR (candidate address), one compare, one select -- no add.  `hist_delta` = byte distance from the
 // positives table to the histogram table of the same group.
 template <int J>
-__device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr, unsigned hist_delta, unsigned &rocacc,
+__device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr, unsigned hist_delta,
                                          const int *pos_item_g, int sb, int h, float piv_root, float piv_lo, float piv_hi)
 {
     // The 16 searches are independent: run them level by level (16 LDS reads in flight per level) instead of one
@@ -95,11 +95,8 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
         }
     }
     #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        rocacc += at[r];
+    for (int r = 0; r < 16; r++)
         __hip_atomic_fetch_add((LdsU32Ptr)(at[r] + hist_delta), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    rocacc -= 16u * pos_addr;
 }
 
 #ifdef RM_STATS
@@ -169,7 +166,7 @@ void k_sweep(SweepArgs a)
     const bool primary = slot_ok && a.slot_chunk[slot] == 0;
     float thr = primary ? neg_inf_f() : nan_sentinel_f();        // NaN threshold: "v >= thr" never true
     float vmax = neg_inf_f(), vmin = pos_inf_f();
-    unsigned long long nanmask = 0, roc64 = 0;
+    unsigned long long nanmask = 0;
     int ntc = 0, nte = 0, nt = IDX_EMPTY, nt2 = IDX_EMPTY;     // train cursor: next item and the one after (prefetched)
 
     // item range of this split
@@ -476,17 +473,15 @@ void k_sweep(SweepArgs a)
 #ifndef RM_ABL_NO_AUC
         // (4) AUC rank counting (replaces the full sort of :552 + the walk of :795-865)
         if (AUC) {
-            unsigned rocacc = 0;
             switch (jb) {
-                case 1: auc_pass<1>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
-                case 2: auc_pass<2>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
-                case 3: auc_pass<3>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
-                case 4: auc_pass<4>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
-                case 5: auc_pass<5>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
-                case 6: auc_pass<6>(v, pos_addr, hist_delta, rocacc, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
+                case 1: auc_pass<1>(v, pos_addr, hist_delta, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
+                case 2: auc_pass<2>(v, pos_addr, hist_delta, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
+                case 3: auc_pass<3>(v, pos_addr, hist_delta, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
+                case 4: auc_pass<4>(v, pos_addr, hist_delta, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
+                case 5: auc_pass<5>(v, pos_addr, hist_delta, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
+                case 6: auc_pass<6>(v, pos_addr, hist_delta, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
                 default: break;
             }
-            roc64 += rocacc >> 7;
         }
 #endif
     };
@@ -562,12 +557,10 @@ void k_sweep(SweepArgs a)
     {   // lanes u and u+32 hold two halves of the same user's stats
         const float omax = __shfl_xor(vmax, 32), omin = __shfl_xor(vmin, 32);
         vmax = __builtin_fmaxf(vmax, omax); vmin = __builtin_fminf(vmin, omin);
-        const unsigned long long oroc = __shfl_xor(roc64, 32);
-        roc64 += oroc;
         const bool hn = ((nanmask >> ul) & 1ull) | ((nanmask >> (ul + 32)) & 1ull);
         if (slot_ok && h == 0) {
             PartialStat<float> ps;
-            ps.vmax = vmax; ps.vmin = vmin; ps.rocsum = roc64; ps.has_nan = hn ? 1 : 0; ps.pad = 0;
+            ps.vmax = vmax; ps.vmin = vmin; ps.rocsum = 0; ps.has_nan = hn ? 1 : 0; ps.pad = 0;
             a.pst[(size_t)slot * n_part + part] = ps;
             ListEntry *dst = a.pl + ((size_t)slot * n_part + part) * K;
             if (LLDS) { keylist_sort_desc<GROUP_USERS>(Ll, K); for (int i = 0; i < K; i++) unpack_key(Ll[i * GROUP_USERS], dst[i].s, dst[i].idx); }

@@ -27,7 +27,7 @@ __device__ __forceinline__ double neg_inf_d() { return __longlong_as_double(0xff
 __device__ __forceinline__ double nan_sentinel_d() { return __longlong_as_double(-1ll); }
 
 template <int J>
-__device__ __forceinline__ void auc_pass64(const double (&v)[8], const char *posb, char *histb, unsigned &rocacc,
+__device__ __forceinline__ void auc_pass64(const double (&v)[8], const char *posb, char *histb,
                                            const int *pos_item_g, int sb, int q)
 {
     unsigned base[8];
@@ -60,10 +60,8 @@ __device__ __forceinline__ void auc_pass64(const double (&v)[8], const char *pos
         }
     }
     #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        rocacc += base[r];
+    for (int r = 0; r < 8; r++)
         __hip_atomic_fetch_add((unsigned *)(histb + (base[r] >> 1)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
 }
 
 template <int NGT, bool AUC, bool DUMP, int LMODE>
@@ -111,7 +109,7 @@ void k_sweep64(Sweep64Args a)
     const bool primary = slot_ok && a.slot_chunk[slot] == 0;
     double thr = primary ? neg_inf_d() : nan_sentinel_d();
     double vmax = neg_inf_d(), vmin = pos_inf_d();
-    unsigned long long nanmask = 0, roc64 = 0;
+    unsigned long long nanmask = 0;
     int ntc = 0, nte = 0, nt = IDX_EMPTY, nt2 = IDX_EMPTY;     // train cursor: next item and the one after (prefetched)
 
     const int tiles_per = (a.tiles_total + a.n_splits - 1) / a.n_splits;
@@ -341,17 +339,15 @@ void k_sweep64(Sweep64Args a)
             }
         }
         if (AUC) {
-            unsigned rocacc = 0;
             switch (jb) {
-                case 1: auc_pass64<1>(v, posb, histb, rocacc, pos_item_g, sb, q); break;
-                case 2: auc_pass64<2>(v, posb, histb, rocacc, pos_item_g, sb, q); break;
-                case 3: auc_pass64<3>(v, posb, histb, rocacc, pos_item_g, sb, q); break;
-                case 4: auc_pass64<4>(v, posb, histb, rocacc, pos_item_g, sb, q); break;
-                case 5: auc_pass64<5>(v, posb, histb, rocacc, pos_item_g, sb, q); break;
-                case 6: auc_pass64<6>(v, posb, histb, rocacc, pos_item_g, sb, q); break;
+                case 1: auc_pass64<1>(v, posb, histb, pos_item_g, sb, q); break;
+                case 2: auc_pass64<2>(v, posb, histb, pos_item_g, sb, q); break;
+                case 3: auc_pass64<3>(v, posb, histb, pos_item_g, sb, q); break;
+                case 4: auc_pass64<4>(v, posb, histb, pos_item_g, sb, q); break;
+                case 5: auc_pass64<5>(v, posb, histb, pos_item_g, sb, q); break;
+                case 6: auc_pass64<6>(v, posb, histb, pos_item_g, sb, q); break;
                 default: break;
             }
-            roc64 += rocacc >> 7;
         }
     };
 
@@ -418,11 +414,10 @@ void k_sweep64(Sweep64Args a)
     {   // the four lanes of a user hold four quarters of its stats
         vmax = __builtin_fmax(vmax, __shfl_xor(vmax, 16)); vmax = __builtin_fmax(vmax, __shfl_xor(vmax, 32));
         vmin = __builtin_fmin(vmin, __shfl_xor(vmin, 16)); vmin = __builtin_fmin(vmin, __shfl_xor(vmin, 32));
-        roc64 += __shfl_xor(roc64, 16); roc64 += __shfl_xor(roc64, 32);
         const bool hn = ((nanmask >> ul) | (nanmask >> (ul + 16)) | (nanmask >> (ul + 32)) | (nanmask >> (ul + 48))) & 1ull;
         if (slot_ok && q == 0) {
             PartialStat<double> ps;
-            ps.vmax = vmax; ps.vmin = vmin; ps.rocsum = roc64; ps.has_nan = hn ? 1 : 0; ps.pad = 0;
+            ps.vmax = vmax; ps.vmin = vmin; ps.rocsum = 0; ps.has_nan = hn ? 1 : 0; ps.pad = 0;
             a.pst[(size_t)slot * n_part + part] = ps;
             Entry<double> *dst = a.pl + ((size_t)slot * n_part + part) * K;
             if (LLDS) { list_sort_desc<double, GU>(Ll, K); for (int i = 0; i < K; i++) ListRaw<double>::unpack(Ll[i * GU], dst[i].s, dst[i].idx); }
