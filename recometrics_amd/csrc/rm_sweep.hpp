@@ -39,12 +39,11 @@ typedef u32x2 *GblListPtr;
 typedef __attribute__((address_space(3))) const float *LdsF32Ptr;
 typedef __attribute__((address_space(3))) unsigned *LdsU32Ptr;
 
-// `pos_addr` = LDS byte address of row 0 of the lane's user in its group's table.  The table of a group is 2^jmax rows
+// `pos_addr` = LDS byte address of row 0 of the lane's user in its group's table.  The table of a group is 2^J rows
 // of 128 B and is ALIGNED to its own size, so "address of row r" = pos_addr | (r << 7): each level of the branchless
-// lower_bound is one OR (candidate address), one compare, one select -- no add.  `hist_delta` = byte distance from the
-// positives table to the histogram table of the same group.
+// lower_bound is one OR (candidate address), one compare, one select -- no add.
 template <int J>
-__device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr, unsigned hist_delta,
+__device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr,
                                          const int *pos_item_g, int sb, int h, float piv_root, float piv_lo, float piv_hi)
 {
     // The 16 searches are independent: run them level by level (16 LDS reads in flight per level) instead of one
@@ -52,6 +51,9 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
     // (an LDS atomic may alias the table for the compiler and would serialise the chains).  The pivots of the two
     // top levels of the lane's user (root, and the roots of its two subtrees) are per-sweep constants held in
     // registers: two of the dependent LDS round trips disappear.
+    // the block's histogram tables follow its four positives tables of 2^J rows each (k_sweep's carve): a compile-time
+    // distance, so the LDS atomic below takes it as its immediate offset instead of an address add per score
+    constexpr unsigned HIST_DELTA = (unsigned)GROUPS_PER_BLOCK * (1u << J) * GROUP_USERS * 4u;
     unsigned at[16];                                           // address of row `base`
     constexpr int TOP = J >= 2 ? 2 : 0;                        // levels resolved from registers
     if (TOP == 2) {
@@ -96,7 +98,7 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
     }
     #pragma unroll
     for (int r = 0; r < 16; r++)
-        __hip_atomic_fetch_add((LdsU32Ptr)(at[r] + hist_delta), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add((LdsU32Ptr)at[r] + HIST_DELTA / 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 #ifdef RM_STATS
@@ -262,7 +264,6 @@ void k_sweep(SweepArgs a)
         for (int i = tid; i < GROUPS_PER_BLOCK * (PLmax + 1) * GROUP_USERS; i += THREADS) histL[i] = 0;
     }
     const unsigned pos_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)(posL + gi * (PLmax + 1) * GROUP_USERS + ul);
-    const unsigned hist_delta = (unsigned)((const char *)histL - (const char *)posL);
     float piv_root = pos_inf_f(), piv_lo = pos_inf_f(), piv_hi = pos_inf_f();     // top two tree levels of the lane's user
     if (AUC && jb >= 2) {
         __syncthreads();                                                           // the tables above are complete
@@ -474,12 +475,12 @@ void k_sweep(SweepArgs a)
         // (4) AUC rank counting (replaces the full sort of :552 + the walk of :795-865)
         if (AUC) {
             switch (jb) {
-                case 1: auc_pass<1>(v, pos_addr, hist_delta, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
-                case 2: auc_pass<2>(v, pos_addr, hist_delta, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
-                case 3: auc_pass<3>(v, pos_addr, hist_delta, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
-                case 4: auc_pass<4>(v, pos_addr, hist_delta, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
-                case 5: auc_pass<5>(v, pos_addr, hist_delta, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
-                case 6: auc_pass<6>(v, pos_addr, hist_delta, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
+                case 1: auc_pass<1>(v, pos_addr, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
+                case 2: auc_pass<2>(v, pos_addr, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
+                case 3: auc_pass<3>(v, pos_addr, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
+                case 4: auc_pass<4>(v, pos_addr, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
+                case 5: auc_pass<5>(v, pos_addr, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
+                case 6: auc_pass<6>(v, pos_addr, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;
                 default: break;
             }
         }
