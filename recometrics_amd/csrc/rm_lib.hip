@@ -216,7 +216,16 @@ void run(const Call<T> &c, hipStream_t stream)
     ClassifyArgs ca{m, n, K, c.train_p, c.test_p, req, c.cold ? 1 : 0, min_items_pool, min_pos_test, want_auc ? 1 : 0,
                     flags, user_nslots, plan};
     hipLaunchKernelGGL(k_classify, dim3(cdiv(m, 1024)), dim3(1024), 0, stream, ca);
-    hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, user_nslots, uslot_base, m, &plan->n_slots);
+    if (m > 8192) {                                          // one block walking the whole array costs ~0.5 us per 1024 entries
+        const int n_tiles = (int)cdiv(m, 1024);
+        int *tile_total = (int *)ws.get("scan_tile_total", sizeof(int) * (size_t)n_tiles);
+        int *tile_offset = (int *)ws.get("scan_tile_offset", sizeof(int) * (size_t)n_tiles);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(1024), 0, stream, user_nslots, uslot_base, m, tile_total);
+        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, tile_total, tile_offset, n_tiles, &plan->n_slots);
+        hipLaunchKernelGGL(k_scan_add_offsets, dim3(cdiv(m, 256)), dim3(256), 0, stream, uslot_base, m, tile_offset);
+    } else {
+        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, user_nslots, uslot_base, m, &plan->n_slots);
+    }
     hipLaunchKernelGGL(k_plan_classes, dim3(1), dim3(1), 0, stream, plan, GU);
     const long long slot_bound = (long long)m + c.nnz_test / POS_CHUNK + 1;
     const long long group_bound = slot_bound / GU + 2;

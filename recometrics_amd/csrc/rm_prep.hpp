@@ -69,6 +69,30 @@ __global__ void k_classify(ClassifyArgs a)
     if (threadIdx.x == MAX_J + 1 && blk_count[MAX_J + 1]) atomicAdd(&a.plan->n_active, blk_count[MAX_J + 1]);
 }
 
+// Long arrays are scanned in three launches: k_scan_tiles (every block scans its own 1024 entries and reports its total),
+// k_scan_exclusive over the block totals, k_scan_add_offsets.
+__global__ __launch_bounds__(1024) void k_scan_tiles(const int *in, int *out, int count, int *tile_total)
+{
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * 1024 + tid;
+    const int v = i < count ? in[i] : 0;
+    int x = v;
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; w++) woff += wsum[w];
+    if (i < count) out[i] = woff + x - v;
+    if (tid == 1023) tile_total[blockIdx.x] = woff + x;
+}
+__global__ void k_scan_add_offsets(int *out, int count, const int *tile_offset)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] += tile_offset[i >> 10];
+}
+
 // exclusive scan of int array by ONE block of 1024 threads (m <= 2^31; a few hundred iterations at m = 1M)
 __global__ void k_scan_exclusive(const int *in, int *out, int count, int *total_out)
 {
