@@ -419,15 +419,31 @@ __global__ void k_pos_place(PosArgs<T> a, const int *slot_user, const int *slot_
     const T s = mine ? a.pos_tmp[e] : (T)0;
     const int item = mine ? a.test_i[e] : 0;
     int rank = 0;
-    for (int f0 = te0; f0 < te1; f0 += WAVE) {
-        const int f = f0 + lane;
-        const T sf = f < te1 ? a.pos_tmp[f] : (T)0;
-        const int itf = f < te1 ? a.test_i[f] : 0;
-        const int cnt = min(WAVE, te1 - f0);
-        for (int j = 0; j < cnt; j++) {
-            const T sj = lane_bcast<T>(sf, j);
-            const int ij = lane_bcast<int>(itf, j);
-            rank += (sj < s) || (sj == s && ij > item);
+    if (sizeof(T) == 4) {
+        // fp32: (score asc, item desc) is the order of the packed key (ordered score bits << 32) | ~item, so an entry's rank
+        // is the number of smaller keys: one 64-bit compare per pair (scores are never -0: the chain starts at +0)
+        const unsigned long long key = ((unsigned long long)ord_key((float)s) << 32) | (unsigned)~item;
+        for (int f0 = te0; f0 < te1; f0 += WAVE) {
+            const int f = f0 + lane;
+            const unsigned kh = f < te1 ? ord_key((float)a.pos_tmp[f]) : 0u;
+            const unsigned kl = f < te1 ? (unsigned)~a.test_i[f] : 0u;
+            const int cnt = min(WAVE, te1 - f0);
+            for (int j = 0; j < cnt; j++) {
+                const unsigned long long kj = ((unsigned long long)(unsigned)lane_bcast<int>((int)kh, j) << 32) | (unsigned)lane_bcast<int>((int)kl, j);
+                rank += kj < key;
+            }
+        }
+    } else {
+        for (int f0 = te0; f0 < te1; f0 += WAVE) {
+            const int f = f0 + lane;
+            const T sf = f < te1 ? a.pos_tmp[f] : (T)0;
+            const int itf = f < te1 ? a.test_i[f] : 0;
+            const int cnt = min(WAVE, te1 - f0);
+            for (int j = 0; j < cnt; j++) {
+                const T sj = lane_bcast<T>(sf, j);
+                const int ij = lane_bcast<int>(itf, j);
+                rank += (sj < s) || (sj == s && ij > item);
+            }
         }
     }
     if (mine) {
