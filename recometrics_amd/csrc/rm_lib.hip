@@ -343,7 +343,7 @@ void run(const Call<T> &c, hipStream_t stream)
             HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(unsigned) * (size_t)rows * GU, stream));
             PosArgs<T> pa{m, n, k, c.A, c.lda, c.B, c.ldb, c.train_p, c.train_i, c.test_p, c.test_i,
                           flags, user_nslots, uslot_base, slot_index, grow, pos_tmp, pos_order, pos_score, pos_item, GU};
-            hipLaunchKernelGGL(k_pos_scores<T>, dim3(cdiv((long long)n_slots * WAVE, 256)), dim3(256), 0, stream, pa, slot_user, slot_chunk, n_slots);
+            hipLaunchKernelGGL(k_pos_scores<T>, dim3(cdiv(n_slots, POSS_WAVES)), dim3(POSS_WAVES * WAVE), 0, stream, pa, slot_user, slot_chunk, n_slots);
             hipLaunchKernelGGL(k_pos_place<T>, dim3(cdiv((long long)n_slots * WAVE, 256)), dim3(256), 0, stream, pa, slot_user, slot_chunk, n_slots);
         }
 

@@ -384,22 +384,56 @@ __device__ __forceinline__ bool in_sorted_row(const int *row, int len, int item)
 }
 
 // one wavefront per SLOT (= up to 63 test entries of one user, by row position; a heavy user's chunks run in parallel)
+__device__ __forceinline__ float fma_chain_step(float a, float b, float s) { return __builtin_fmaf(a, b, s); }
+__device__ __forceinline__ double fma_chain_step(double a, double b, double s) { return __builtin_fma(a, b, s); }
+
+// The item-factor rows of the wave's test items are fetched 64 bytes at a time, COALESCED (one load instruction covers
+// that piece of 4 (fp32) or 8 (fp64) rows), into a padded LDS image, and each lane then walks its own row out of LDS; the
+// user's factors ride in one register and are broadcast.  A per-lane gather (16 bytes of 60-odd different rows per
+// instruction) thrashes the vector L1.  The accumulate chain is chain_dot's: k-ordered fma from +0.
+constexpr int POSS_WAVES = 4;                                   // wavefronts (slots) per block
 template <class T>
-__global__ void k_pos_scores(PosArgs<T> a, const int *slot_user, const int *slot_chunk, int n_slots)
+__global__ __launch_bounds__(POSS_WAVES * WAVE) void k_pos_scores(PosArgs<T> a, const int *slot_user, const int *slot_chunk, int n_slots)
 {
-    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    constexpr int CH = 64 / (int)sizeof(T);                     // factors per staged piece: 64 B of a row
+    constexpr int RPI = WAVE / CH;                              // rows covered by one load instruction
+    constexpr int LD = CH + 1;                                  // padded row stride in LDS (conflict-free row walks)
+    __shared__ T rows[POSS_WAVES][WAVE][LD];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = blockIdx.x * POSS_WAVES + wv;
     if (w >= n_slots) return;
     const int u = slot_user[w], c0 = slot_chunk[w];
     if (a.flags[u] & UF_ONLY_NDCG) return;
     const int te0 = a.test_p[u], te1 = a.test_p[u + 1];
     const int tr0 = a.train_p[u], ntr = a.train_p[u + 1] - tr0;
     const int e = te0 + c0 * POS_CHUNK + lane;
-    if (lane >= POS_CHUNK || e >= te1) return;
-    const int item = a.test_i[e];
-    T s;
-    if (ntr && in_sorted_row(a.train_i + tr0, ntr, item)) s = (T)__int_as_float(0x7f800000);
-    else s = chain_dot<T>(a.A + (size_t)u * a.lda, a.B + (size_t)item * a.ldb, a.k);
-    a.pos_tmp[e] = s;
+    const int np = min(POS_CHUNK, te1 - (te0 + c0 * POS_CHUNK));         // entries of this slot: 1 .. 63
+    const bool mine = lane < np;
+    const int item = mine ? a.test_i[e] : 0;
+    const bool masked = mine && ntr && in_sorted_row(a.train_i + tr0, ntr, item);
+    const T *Au = a.A + (size_t)u * a.lda;
+    const int f = lane % CH, sub = lane / CH;
+    T s = 0;
+    for (int k0 = 0; k0 < a.k; k0 += CH) {
+        const T av = k0 + f < a.k ? Au[k0 + f] : (T)0;
+        for (int p0 = 0; p0 < np; p0 += 8 * RPI) {             // eight loads in flight per lane
+            T bv[8];
+            #pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int p = p0 + q * RPI + sub;
+                const int it = __shfl(item, p < np ? p : 0);
+                bv[q] = (p < np && k0 + f < a.k) ? a.B[(size_t)it * a.ldb + k0 + f] : (T)0;
+            }
+            #pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int p = p0 + q * RPI + sub;
+                rows[wv][p < np ? p : WAVE - 1][f] = bv[q];
+            }
+        }
+        const int kc = min(CH, a.k - k0);
+        for (int t = 0; t < kc; t++) s = fma_chain_step(lane_bcast<T>(av, t), rows[wv][mine ? lane : 0][t], s);
+    }
+    if (mine) a.pos_tmp[e] = masked ? (T)__int_as_float(0x7f800000) : s;
 }
 
 // One wavefront per SLOT (= up to 63 test entries of one user, by row position): rank of each of them among ALL the
