@@ -24,6 +24,7 @@ constexpr int GROUPS_PER_BLOCK = 4;
 constexpr int POS_CHUNK = 63;          // positives per slot = rows of a complete binary search tree of depth 6
 constexpr int MAX_J = 6;
 constexpr int IDX_EMPTY = 0x7fffffff;
+constexpr int HEAVY_NPOS = 256;        // test rows longer than this get wave-per-user treatment where one thread would crawl
 // where a sweep wave's top-K lists live: LM_LDS replace-the-minimum lists in LDS; LM_HBM the same scheme in HBM (lists that
 // do not fit LDS, K <= 32); LM_HBM_APPEND per-user append buffers in HBM with wave-cooperative compaction (K > 32)
 enum : int { LM_LDS = 0, LM_HBM = 1, LM_HBM_APPEND = 2 };
@@ -56,6 +57,7 @@ struct Plan {                                     // produced on device, read ba
     int class_offset[MAX_J + 2];
     int class_cursor[MAX_J + 1];
     int nonfinite;                      // some factor of A or B is NaN / Inf
+    int n_heavy;                        // evaluated users with more than HEAVY_NPOS test items (listed by k_classify)
     unsigned long long amax_a, amax_b;  // bit patterns of max|A|, max|B| as doubles (non-negative doubles order like u64)
 };
 

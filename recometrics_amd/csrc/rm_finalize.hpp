@@ -25,6 +25,9 @@ template <class T, class S> struct FinalArgs {     // T = real_t of inputs/outpu
     const int *gj; const long long *grow;
     const Entry<S> *pl; const PartialStat<S> *pst; const unsigned *hist; const S *pos_score;
     AucPart *auc_part;           // [n_slots]
+    T *heavy_topv;               // [m][min(K, FIN_TOPV)] largest test values (descending) of users with more than
+    unsigned char *heavy_nan;    // [m]    ... HEAVY_NPOS test items, and whether any of their values is NaN (k_top_values)
+    const int *heavy_users; int n_heavy;     // those users (k_classify)
     const double *log2tab;
     T *p, *tp, *r, *ap, *tap, *ndcg, *hit, *rr, *roc, *pr;
     Entry<S> *merged;            // [m][K]   final ordered top-K (also the rm_rank_* output)
@@ -94,6 +97,56 @@ __global__ void k_auc_slots(FinalArgs<T, S> a)
     }
     AucPart r; r.sum_ranks = sum_ranks; r.s1 = s1; r.s2 = s2; r.nvalid = nvalid; r.pad = 0;
     a.auc_part[slot] = r;
+}
+
+// The L = min(K, npos) largest test VALUES of a user, descending (ideal DCG, reference :868-961), for users whose row is too
+// long to walk on k_finalize's single thread: one wavefront per user, L rounds of "largest value after the previous pick in
+// (value desc, position asc) order" with the row strided over the lanes.
+template <class T, class S>
+__global__ void k_top_values(FinalArgs<T, S> a)
+{
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (w >= a.n_heavy) return;
+    const int u = a.heavy_users[w];
+    const int te0 = a.test_p[u], npos = a.test_p[u + 1] - te0;
+    const int L = a.K < npos ? a.K : npos;
+    if (L > FIN_TOPV) return;
+    const T *tv = a.test_v + te0;
+    T *out = a.heavy_topv + (size_t)u * (a.K < FIN_TOPV ? a.K : FIN_TOPV);
+    bool any_nan = false;
+    T pv = 0; int pi = -1;
+    // rows up to 64 * CACHE entries are read once into registers (all loads in flight together); longer ones are
+    // re-read from L2 in every round
+    constexpr int CACHE = 32;
+    const bool cached = npos <= WAVE * CACHE;
+    T xv[CACHE];
+    if (cached) {
+        #pragma unroll
+        for (int i = 0; i < CACHE; i++) xv[i] = lane + WAVE * i < npos ? tv[lane + WAVE * i] : (T)0;
+    }
+    for (int r = 0; r < L; r++) {
+        bool found = false; T bv = 0; int bi = 0x7fffffff;
+        auto consider = [&](T x, int t) {
+            if (r == 0) any_nan |= x != x;
+            if (r > 0 && !(x < pv || (x == pv && t > pi))) return;
+            if (!found || x > bv) { found = true; bv = x; bi = t; }          // ascending t: the first of equal values stays
+        };
+        if (cached) {
+            #pragma unroll
+            for (int i = 0; i < CACHE; i++) if (lane + WAVE * i < npos) consider(xv[i], lane + WAVE * i);
+        } else {
+            for (int t = lane; t < npos; t += WAVE) consider(tv[t], t);
+        }
+        #pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const T ov = __shfl_xor(bv, d); const int oi = __shfl_xor(bi, d); const bool of = __shfl_xor((int)found, d) != 0;
+            if (of && (!found || ov > bv || (ov == bv && oi < bi))) { found = true; bv = ov; bi = oi; }
+        }
+        pv = bv; pi = bi;
+        if (lane == 0) out[r] = bv;
+    }
+    const unsigned long long nm = __ballot(any_nan);
+    if (lane == 0) a.heavy_nan[u] = nm ? 1 : 0;
 }
 
 // users that are not evaluated (reference :450-476): NaN in every requested output, empty ranking
@@ -287,7 +340,11 @@ __global__ void k_finalize(FinalArgs<T, S> a)
             }
             ov = bv; oi = bi; return found;
         };
-        if (buffered) {
+        if (buffered && npos > HEAVY_NPOS) {                      // computed by k_top_values, one wave per such user
+            const T *hv = a.heavy_topv + (size_t)u * (K < FIN_TOPV ? K : FIN_TOPV);
+            for (int i = 0; i < L; i++) topv[i * FIN_THREADS] = hv[i];
+            has_nan_val = a.heavy_nan[u] != 0;
+        } else if (buffered) {
             int cnt = 0;
             T kth = 0;                                               // topv[L - 1] once the buffer is full
             for (int t0 = 0; t0 < npos; t0 += 8) {                 // eight loads in flight: a heavy user's row is thousands long

@@ -213,8 +213,9 @@ void run(const Call<T> &c, hipStream_t stream)
     int *uslot_base = (int *)ws.get("uslot_base", sizeof(int) * (size_t)m);
     Plan *plan = (Plan *)ws.get("plan", sizeof(Plan));
     HIP_CHECK(hipMemsetAsync(plan, 0, sizeof(Plan), stream));
+    int *heavy_users = (int *)ws.get("heavy_users", sizeof(int) * (size_t)m);
     ClassifyArgs ca{m, n, K, c.train_p, c.test_p, req, c.cold ? 1 : 0, min_items_pool, min_pos_test, want_auc ? 1 : 0,
-                    flags, user_nslots, plan};
+                    flags, user_nslots, heavy_users, plan};
     hipLaunchKernelGGL(k_classify, dim3(cdiv(m, 1024)), dim3(1024), 0, stream, ca);
     if (m > 8192) {                                          // one block walking the whole array costs ~0.5 us per 1024 entries
         const int n_tiles = (int)cdiv(m, 1024);
@@ -422,6 +423,12 @@ void run(const Call<T> &c, hipStream_t stream)
     fa.merged = merged; fa.rank_sorted = rank_sorted; fa.status = c.status;
     fa.n_slots = n_slots; fa.slot_user = slot_user; fa.slot_chunk = slot_chunk;
     hipLaunchKernelGGL((k_finalize_skipped<T, T>), dim3(cdiv(m, 256)), dim3(256), 0, stream, fa);
+    if (fa.ndcg && hp.n_heavy > 0) {                            // ideal-DCG values of the users with very long test rows
+        fa.heavy_topv = (T *)ws.get("heavy_topv", sizeof(T) * (size_t)m * std::min(K, FIN_TOPV));
+        fa.heavy_nan = (unsigned char *)ws.get("heavy_nan", (size_t)m);
+        fa.heavy_users = heavy_users; fa.n_heavy = hp.n_heavy;
+        hipLaunchKernelGGL((k_top_values<T, T>), dim3(cdiv((long long)hp.n_heavy * WAVE, 256)), dim3(256), 0, stream, fa);
+    }
     if (n_slots > 0) {
         if (want_auc) {
             fa.auc_part = (AucPart *)ws.get("auc_part", sizeof(AucPart) * (size_t)n_slots);

@@ -16,6 +16,7 @@ struct ClassifyArgs {
     int want_auc;            // ROC or PR requested
     int *flags;              // [m]
     int *user_nslots;        // [m]
+    int *heavy_users;        // [m] list of the evaluated users with more than HEAVY_NPOS test items (plan->n_heavy of them)
     Plan *plan;
 };
 
@@ -64,6 +65,7 @@ __global__ void k_classify(ClassifyArgs a)
     }
     if (nfull) atomicAdd(&blk_count[MAX_J], nfull);
     if (live) { a.flags[u] = f; a.user_nslots[u] = nsl; }
+    if (live && !isnan_user && npos > HEAVY_NPOS) a.heavy_users[atomicAdd(&a.plan->n_heavy, 1)] = u;      // rare
     __syncthreads();
     if (threadIdx.x <= MAX_J && blk_count[threadIdx.x]) atomicAdd(&a.plan->class_count[threadIdx.x], blk_count[threadIdx.x]);
     if (threadIdx.x == MAX_J + 1 && blk_count[MAX_J + 1]) atomicAdd(&a.plan->n_active, blk_count[MAX_J + 1]);
