@@ -229,6 +229,9 @@ __global__ void k_finalize(FinalArgs<T, S> a)
         fill_user_nan(a, u); return;
     }
     if (a.status) a.status[u] = 0;
+#if defined(RM_ABL_FIN_STOP) && RM_ABL_FIN_STOP == 1
+    return;
+#endif
 
     const int *ti = a.test_i + te0;
     const T *tv = a.test_v ? a.test_v + te0 : nullptr;
@@ -284,6 +287,9 @@ __global__ void k_finalize(FinalArgs<T, S> a)
         }
     }
 
+#if defined(RM_ABL_FIN_STOP) && RM_ABL_FIN_STOP == 2
+    return;
+#endif
     // ---- NaN overrides (:750-788) ----
     if (kleqn) {
         if (!cum) {
@@ -321,6 +327,9 @@ __global__ void k_finalize(FinalArgs<T, S> a)
         if (a.pr) a.pr[u] = (T)(ap_full / (double)npos);
     }
 
+#if defined(RM_ABL_FIN_STOP) && RM_ABL_FIN_STOP == 3
+    return;
+#endif
     // ---- NDCG normalisation (:868-961) ----
     if (a.ndcg) {
         const int L = K < npos ? K : npos;
