@@ -36,7 +36,25 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the north-star-shape extra measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = every GPU evaluates a full-size shard; strong = the workload's users are split over the GPUs")
+    ap.add_argument("--parity-users", type=int, default=64, help="users of the timed outputs compared with the oracle (0 = skip)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-pointer (PCIe-inclusive) measurement")
     return ap.parse_args()
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start torch.distributed.run as a CHILD before anything in
+    this process touches the GPU, and leave with its exit code (never exec from a GPU-initialised process)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 class DeviceProblem:
@@ -75,6 +93,51 @@ def load_traffic(workload, users):
         return None
 
 
+def parity_check(prob, torch, n_users):
+    """verify parity on the same inputs in the same run before accepting a number -- the first `n_users`
+    users of the timed outputs against the oracle (metrics within 1e-5, identical NaN pattern)."""
+    from oracle import oracle as orc
+    nu = int(min(n_users, prob.m))
+    host = prob.host
+    trp, tri = host["train"]
+    tep, tei, tev = host["test"]
+    sub_tr = (trp[:nu + 1], tri[:trp[nu]] if trp[nu] else np.zeros(1, np.int32))
+    sub_te = (tep[:nu + 1], tei[:tep[nu]], tev[:tep[nu]])
+    want = orc.Oracle().calc(host["A"][:nu], host["B"], sub_tr, sub_te, prob.K, nthreads=min(64, os.cpu_count() or 1),
+                             noise=False, dtype=prob.dtype)
+    got = prob.out[:, :nu].cpu().numpy()
+    worst = 0.0
+    for i, name in enumerate(orc.METRICS):
+        w, g = want[orc.NAMES[name]], got[i]
+        if not (np.isnan(w) == np.isnan(g)).all():
+            return {"users": nu, "ok": False, "what": "NaN pattern of %s" % name}
+        d = float(np.nanmax(np.abs(w.astype(np.float64) - g.astype(np.float64)), initial=0.0))
+        worst = max(worst, d)
+        if d > 1e-5:
+            return {"users": nu, "ok": False, "what": "%s differs by %g" % (name, d)}
+    return {"users": nu, "ok": True, "max_abs_diff": worst}
+
+
+def e2e_host(binding, prob, reps=3):
+    """host arrays in -> host arrays out through rm_calc_metrics_* (H2D of A/B/CSR, device work, D2H
+    of the metric block), first call (workspace allocation) and steady state (median)."""
+    h = prob.host
+    trp, tri = h["train"]
+    tep, tei, tev = h["test"]
+    want = {name: True for name in binding.METRIC_ORDER}
+
+    def call():
+        t0 = time.perf_counter()
+        binding.calc_metrics(h["A"], prob.k, h["B"], prob.k, trp, tri if tri.size else np.zeros(1, np.int32), tep, tei, tev,
+                             prob.K, want, False, False, True, 2, 1, 1, 1)
+        return (time.perf_counter() - t0) * 1e3
+    first = call()
+    rest = sorted(call() for _ in range(reps))
+    steady = rest[len(rest) // 2]
+    return {"first_call_ms": first, "steady_ms": steady, "users_per_s": prob.m / (steady * 1e-3),
+            "what": "rm_calc_metrics_%s: host pointers in, host pointers out (PCIe-inclusive); never `value`" % ("f32" if prob.dtype == np.float32 else "f64")}
+
+
 def cpu_baseline(host, K, n_users_total, budget_s, dtype=np.float32):
     """The CPU path on this host's cores over a bounded sample of the same workload."""
     from oracle import oracle as orc
@@ -99,8 +162,9 @@ def cpu_baseline(host, K, n_users_total, budget_s, dtype=np.float32):
     t_probe = run(probe)
     nu = int(min(n_users_total, max(probe, probe * budget_s / max(t_probe, 1e-6))))
     t = run(nu) if nu > probe else t_probe
+    how = "the reference built by oracle/Makefile with -march=x86-64-v3 (its default user build is -march=native)" if kind == "reference" else "oracle/ restatement"
     return {"value": nu / t, "unit": "users/s", "cores": ncores, "kind": kind,
-            "sample": "%d of %d users of the same workload, all metrics, K=%d, %d threads, %.1f s" % (nu, n_users_total, K, ncores, t)}
+            "sample": "%d of %d users of the same workload, all metrics, K=%d, %d threads, %.1f s; %s" % (nu, n_users_total, K, ncores, t, how)}
 
 
 def measure(torch, dist, binding, prob, steps, warmup, world, gather_buf):
@@ -136,6 +200,8 @@ def measure(torch, dist, binding, prob, steps, warmup, world, gather_buf):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)
     import torch
     import torch.distributed as dist
     from recometrics_amd import _binding as binding
@@ -158,20 +224,31 @@ def main():
         m = m // 8                                           # C3 is quoted user-sharded over 8 GPUs
     if args.users:
         m = args.users
+    m_total = m
+    if world > 1 and args.scaling == "strong":                # the workload's users split over the ranks (contiguous ranges)
+        from recometrics_amd.sharding import user_range
+        if args.workload == "C3" and not args.users:
+            m_total = CONFIGS["C3"][0]
+        lo, hi = user_range(m_total, world, rank)
+        m = hi - lo
     prob = DeviceProblem(torch, dev, m, n, k, mean_c, seed, K, dtype, shard=rank)
-    gather_buf = torch.empty((world * 10, m), dtype=prob.out.dtype, device=dev) if world > 1 else None
+    m_cap = m if args.scaling == "weak" else -(-m_total // world)       # all_gather_into_tensor wants equal shards: pad
+    if world > 1 and m_cap != m:
+        prob.out = torch.zeros((10, m_cap), dtype=prob.out.dtype, device=dev)
+    gather_buf = torch.empty((world * 10, m_cap), dtype=prob.out.dtype, device=dev) if world > 1 else None
     peak = PEAK_FP32_MFMA_TFLOPS if dtype == np.float32 else PEAK_FP64_MFMA_TFLOPS
     esize = 4.0 if dtype == np.float32 else 8.0
     dname = "f32" if dtype == np.float32 else "f64"
 
     dt, sweep_ms, prep_ms, fin_ms, tm = measure(torch, dist, binding, prob, args.steps, args.warmup, world, gather_buf)
-    users_per_s = world * m * args.steps / dt
+    users_done = (world * m) if args.scaling == "weak" else m_total
+    users_per_s = users_done * args.steps / dt
     flops_per_launch = 2.0 * n * k * m                       # 2*n*k per user x users of one launch
     achieved_tf = flops_per_launch / (sweep_ms * 1e-3) / 1e12
     line = {
         "metric": "users/sec evaluated (all metrics, K=%d)" % K, "value": users_per_s, "unit": "users/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dname, "data": "synthetic",
+        "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": dname, "data": "synthetic",
         "config": {"workload": "%s: %d users/GPU x %d items, %d factors %s, K=%d, all 10 metrics, noise off"
                                % (args.workload, m, n, k, dname, K),
                    "users_per_gpu": m, "n_items": n, "n_factors": k, "k_metrics": K,
@@ -184,6 +261,21 @@ def main():
         "stage_ms": {"prep": prep_ms, "sweep": sweep_ms, "finalize": fin_ms, "item_splits": tm.get("item_splits"),
                      "sweep_blocks": tm.get("sweep_blocks"), "lds_bytes": tm.get("lds_bytes")},
     }
+
+    failed = False
+    if rank == 0 and args.parity_users > 0:
+        try:
+            pc = parity_check(prob, torch, args.parity_users)
+        except Exception as e:      # noqa: BLE001
+            pc = {"users": 0, "ok": False, "what": repr(e)}
+        line["parity_checked"] = pc["users"] if pc["ok"] else 0
+        line["parity"] = pc
+        failed = not pc["ok"]
+    if rank == 0 and world == 1 and not args.no_e2e:
+        try:
+            line["e2e_host"] = e2e_host(binding, prob)
+        except Exception as e:      # noqa: BLE001
+            line["e2e_host"] = {"error": repr(e)}
 
     if rank == 0 and world == 1 and not args.no_extra and args.workload != "NS":
         # the north-star shape (n = 1M items, 128 factors): B = 512 MB does not fit the Infinity Cache
@@ -216,6 +308,8 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+    if failed:
+        sys.exit("bench.py: the timed outputs do NOT match the oracle -- the number above is invalid")
 
 
 if __name__ == "__main__":

@@ -4,6 +4,8 @@ Bar (BASELINE.json north_star): scores, top-K index lists, hit counts and positi
 fp32/fp64 metric values within 1e-5 of the CPU reference (they are in fact bit-identical except where the
 reference forms ROC-AUC in x87 long double).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -11,6 +13,7 @@ from _util import assert_close, assert_same_bits, golden_cases, load_golden
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
+NT = max(1, min(64, os.cpu_count() or 1))      # host threads for the oracle (the GPU box has many cores)
 
 
 @pytest.fixture(scope="module")
@@ -96,7 +99,7 @@ def test_golden_fixtures(hip, case):
 
 # ---------------------------------------------------------------------------------------------------------------------
 def _check_against_oracle(hip, oracle, pr, k, dtype=np.float32, **kw):
-    want_rank = oracle.rank(pr["A"], pr["B"], pr["train"], pr["test"], k, dtype=dtype, nthreads=8)
+    want_rank = oracle.rank(pr["A"], pr["B"], pr["train"], pr["test"], k, dtype=dtype, nthreads=NT)
     trp, tri = pr["train"]
     tep, tei = pr["test"][:2]
     got_rank = hip.rank(np.ascontiguousarray(pr["A"], dtype), np.ascontiguousarray(pr["B"], dtype), trp, tri, tep, tei, k)
@@ -105,7 +108,7 @@ def _check_against_oracle(hip, oracle, pr, k, dtype=np.float32, **kw):
     assert_same_bits(got_rank["topk_score"], want_rank["topk_score"], "top-K scores")
     assert (got_rank["pos_rank"] == want_rank["pos_rank"]).all(), "positive ranks differ"
     for cumulative in (False, True):
-        want = oracle.calc(pr["A"], pr["B"], pr["train"], pr["test"], k, cumulative=cumulative, dtype=dtype, nthreads=8, **kw)
+        want = oracle.calc(pr["A"], pr["B"], pr["train"], pr["test"], k, cumulative=cumulative, dtype=dtype, nthreads=NT, **kw)
         got = hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], k, cumulative=cumulative, dtype=dtype, **kw)
         # PR_AUC of a user with more than 63 test items is assembled from per-chunk partial sums (finalize):
         # same terms, different association than the reference's single running sum -> a few ulp(fp64), checked at 1e-12
@@ -195,7 +198,7 @@ def test_random_shapes_and_options(hip, oracle):
         kw = dict(cold=bool(rng.random() < 0.7), min_items_pool=int(rng.choice([1, 2, 10])), min_pos_test=int(rng.choice([1, 1, 3])))
         pr = make_problem(m, n, k, dtype, mean_c=mean_c, seed=int(rng.integers(1 << 30)))
         for cumulative in (False, True):
-            want = oracle.calc(pr["A"], pr["B"], pr["train"], pr["test"], K, cumulative=cumulative, dtype=dtype, nthreads=8, **kw)
+            want = oracle.calc(pr["A"], pr["B"], pr["train"], pr["test"], K, cumulative=cumulative, dtype=dtype, nthreads=NT, **kw)
             got = hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], K, cumulative=cumulative, dtype=dtype, **kw)
             for name in want:
                 assert_close(got[name], want[name], TOL, "%s %s m=%d n=%d k=%d K=%d %s" % (name, dtype.__name__, m, n, k, K, kw))
@@ -333,7 +336,7 @@ def test_full_size_properties(hip, oracle):
     single = hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], 10)
     sub_tr = slice_csr(pr["train"][0], pr["train"][1], None, 0, 384)[:2]
     sub_te = slice_csr(pr["test"][0], pr["test"][1], pr["test"][2], 0, 384)
-    want = oracle.calc(pr["A"][:384], pr["B"], sub_tr, sub_te, 10, nthreads=8)
+    want = oracle.calc(pr["A"][:384], pr["B"], sub_tr, sub_te, 10, nthreads=NT)
     for name in want:
         assert_close(single[name][:384], want[name], TOL, "sub-sample " + name)
     cum = hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], 10, cumulative=True)
@@ -349,3 +352,55 @@ def test_full_size_properties(hip, oracle):
     trp, tri = pr["train"]
     for u in range(0, 4096, 97):
         assert not set(rk["topk_idx"][u]).intersection(tri[trp[u]:trp[u + 1]])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE shapes at their full ITEM counts (user-sliced: users are independent, so a slice of the users exercises
+# exactly the n-driven machinery -- item splits and the merge of partial lists, > 2^32-byte offsets into the packed
+# item image, append buffers compacted across splits, histogram counts in the millions -- at a size the oracle
+# finishes in seconds).  Reference src/recometrics.hpp:501-512 switches to size_t addressing for exactly these sizes.
+def _big_problem(m, n, k, dtype, mean_c, seed, heavy=()):
+    """make_problem with the item factors drawn in row chunks (bounded host memory at n = 10M) and, optionally, the
+    test rows of the first len(heavy) users replaced by rows of the given lengths (users with > 63 / > 256 positives)."""
+    from recometrics_amd.synth import make_interactions
+    rng = np.random.default_rng(seed)
+    scale = dtype(1.0 / np.sqrt(k))
+    A = (rng.standard_normal((m, k), dtype=np.float32)).astype(dtype) * scale
+    B = np.empty((n, k), dtype=dtype)
+    step = 1 << 20
+    for r0 in range(0, n, step):
+        r1 = min(n, r0 + step)
+        B[r0:r1] = rng.standard_normal((r1 - r0, k), dtype=np.float32).astype(dtype) * scale
+    trp, tri, tep, tei, tev = make_interactions(m, n, mean_c, dtype, seed)
+    if heavy:
+        rows_i = [tei[tep[u]:tep[u + 1]] for u in range(m)]
+        rows_v = [tev[tep[u]:tep[u + 1]] for u in range(m)]
+        for u, cnt in enumerate(heavy):
+            taken = set(tri[trp[u]:trp[u + 1]].tolist())
+            pick = np.array(sorted(set(rng.integers(0, n, size=cnt + 64).tolist()) - taken)[:cnt], dtype=np.int32)
+            rows_i[u] = pick
+            rows_v[u] = rng.integers(1, 21, size=pick.shape[0]).astype(dtype)
+        tep = np.concatenate([[0], np.cumsum([r.shape[0] for r in rows_i])]).astype(np.int32)
+        tei = np.concatenate(rows_i).astype(np.int32)
+        tev = np.concatenate(rows_v).astype(dtype)
+    return {"A": A, "B": B, "train": (trp, tri), "test": (tep, tei, tev)}
+
+
+def test_baseline_c3_item_count(hip, oracle):
+    """C3: 380,000 items x 128 factors fp32, K = 20 single and cumulative (HBM replace-the-minimum lists, depth split,
+    item splits), 640 users incl. two with more than 63 test items"""
+    pr = _big_problem(640, 380_000, 128, np.float32, 48, 103, heavy=(100, 300))
+    _check_against_oracle(hip, oracle, pr, 20)
+
+
+def test_baseline_c4_item_count(hip, oracle):
+    """C4: 10,000,000 items x 128 factors fp32, K = 100, all metrics (append buffers + compaction, a 5.12 GB packed item
+    image, histogram counts in the millions), 64 users incl. one with > 63 and one with > 256 test items"""
+    pr = _big_problem(64, 10_000_000, 128, np.float32, 10, 104, heavy=(90, 300))
+    _check_against_oracle(hip, oracle, pr, 100)
+
+
+def test_baseline_c5_item_count(hip, oracle):
+    """C5: 500,000 items x 256 factors fp64, K = 50 (streamed factor axis, fp64 append buffers), 96 users"""
+    pr = _big_problem(96, 500_000, 256, np.float64, 50, 105, heavy=(70,))
+    _check_against_oracle(hip, oracle, pr, 50, dtype=np.float64)
