@@ -23,6 +23,11 @@ constexpr int SWEEP_THREADS = 512;     // 8 wavefronts: 4 groups x 2 sub-tiles
 constexpr int GROUPS_PER_BLOCK = 4;
 constexpr int POS_CHUNK = 63;          // positives per slot = rows of a complete binary search tree of depth 6
 constexpr int MAX_J = 6;
+// Depth class MAX_J + 1 = "streamed" users: users with more than POS_CHUNK test items whose candidate scores the sweep
+// writes to HBM instead of counting ranks in LDS; their ranks come from k_rank_streamed (rm_finalize.hpp).  One sweep
+// slot per such user whatever the length of its test row -- no lane recomputes a contraction for an extra chunk.
+constexpr int STREAM_CLASS = MAX_J + 1;
+constexpr int N_CLASSES = MAX_J + 2;
 constexpr int IDX_EMPTY = 0x7fffffff;
 constexpr int HEAVY_NPOS = 256;        // test rows longer than this get wave-per-user treatment where one thread would crawl
 // where a sweep wave's top-K lists live: LM_LDS replace-the-minimum lists in LDS; LM_HBM the same scheme in HBM (lists that
@@ -53,9 +58,13 @@ struct Plan {                                     // produced on device, read ba
     int n_groups;
     int jmax;          // deepest positive tree over all groups (0 when no AUC is requested)
     long long total_rows;   // sum over groups of (2^j - 1)
-    int class_count[MAX_J + 1];
-    int class_offset[MAX_J + 2];
-    int class_cursor[MAX_J + 1];
+    int class_count[N_CLASSES];
+    int class_offset[N_CLASSES + 1];
+    int class_cursor[N_CLASSES];
+    int n_long;             // users with more than POS_CHUNK test items (k_count_long: an upper bound of the streamed class)
+    int stream_enable;      // 1 = those users are streamed (their score rows fit the HBM budget), 0 = they get one slot per chunk
+    int max_npos;           // longest test row (k_count_long)
+    int n_stream_chunks;    // chunks of POS_CHUNK test entries over all streamed users (work items of the positives kernels)
     int nonfinite;                      // some factor of A or B is NaN / Inf
     int n_heavy;                        // evaluated users with more than HEAVY_NPOS test items (listed by k_classify)
     unsigned long long amax_a, amax_b;  // bit patterns of max|A|, max|B| as doubles (non-negative doubles order like u64)

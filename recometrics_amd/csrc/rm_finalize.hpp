@@ -33,6 +33,11 @@ template <class T, class S> struct FinalArgs {     // T = real_t of inputs/outpu
     Entry<S> *merged;            // [m][K]   final ordered top-K (also the rm_rank_* output)
     long long *rank_sorted;      // [nnz_test] 1-based full-ranking position per SORTED positive (0 = masked), optional
     int *status;                 // [m] optional: 0 ranked, 1 skipped
+    // streamed users (slots [stream_slot0, n_slots), rm_device.hpp STREAM_CLASS)
+    int stream_slot0;
+    const S *stream_scores; long long stream_ld;     // [n_stream][stream_ld] masked candidate scores written by the sweep
+    const S *spos_score; const int *spos_item;       // [nnz_test] sorted positives of those users at test_p[u] + rank
+    unsigned *shist;             // [nnz_test] at test_p[u] + j: candidates ranking above positive j but not above positive j + 1
 };
 
 template <class T> __device__ __forceinline__ T qnan();
@@ -70,7 +75,7 @@ template <class T, class S>
 __global__ void k_auc_slots(FinalArgs<T, S> a)
 {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= a.n_slots) return;
+    if (slot >= a.stream_slot0) return;                              // streamed users: k_rank_streamed / k_auc_streamed
     const int u = a.slot_user[slot], c = a.slot_chunk[slot];
     if (a.flags[u] & UF_ONLY_NDCG) return;
     const int te0 = a.test_p[u], npos = a.test_p[u + 1] - te0;
@@ -97,6 +102,160 @@ __global__ void k_auc_slots(FinalArgs<T, S> a)
     }
     AucPart r; r.sum_ranks = sum_ranks; r.s1 = s1; r.s2 = s2; r.nvalid = nvalid; r.pad = 0;
     a.auc_part[slot] = r;
+}
+
+// ---- streamed users: ranks of the positives from the score row the sweep stored --------------------------------------
+// Block = (streamed user, range of its items).  The user's sorted positives sit in LDS (global memory when the row is
+// longer than the LDS holds), every stored score is binary-searched among them with the sweep's tie rule (score desc,
+// item asc: a candidate outranks the equal-scored positives with a LARGER item id), and bin b = "exactly b positives rank
+// below the candidate" is counted at shist[test_p[u] + b - 1] (bin 0, below every positive, is never needed).
+constexpr int STREAM_RANK_THREADS = 256;
+constexpr int STREAM_RANK_ITEMS = 64;                    // items per thread and block
+constexpr int STREAM_RANK_LDS = 20 * 1024;               // LDS per block: eight blocks per CU
+// The LDS copy of the sorted positives is padded with +inf to a power of two (no bounds test in the search) and
+// REPLICATED R times ([entry][R copies], lane l reads copy l mod R): with R = 32 lane l always hits bank l whatever it
+// indexes, so the dependent reads of the search run at the conflict-free LDS rate (a single copy serves 64 random addresses
+// per read at 3-5 bank cycles).  R = the largest power of two that fits next to the counters; rows too long even for one
+// copy are searched in global memory.  ILP independent searches per thread advance level by level, all reads of a level
+// in flight together.
+template <class S, int ILP>
+__device__ __forceinline__ void rank_streamed_lds(const S *row, long long i0, int n, const int *pit, int P, int top, int lgsb,
+                                                  unsigned tab_addr, unsigned hist_addr)
+{
+    typedef __attribute__((address_space(3))) const S *LdsS;
+    typedef __attribute__((address_space(3))) unsigned *LdsU;
+    const unsigned sb = 1u << lgsb;                               // bytes between consecutive entries of the lane's copy
+    auto load_batch = [&](int it, S (&x)[ILP]) {
+        #pragma unroll
+        for (int q = 0; q < ILP; q++) {
+            // coalesced; UNCONDITIONAL (index clamped, validity applied at use): a predicated load would hide the number
+            // of loads in flight from the compiler and turn the wait for this batch into a wait for the prefetch too
+            const long long item = i0 + (long long)(it + q) * STREAM_RANK_THREADS + threadIdx.x;
+            x[q] = row[item < n ? item : n - 1];
+        }
+    };
+    S nxt[ILP];
+    load_batch(0, nxt);
+    for (int it = 0; it < STREAM_RANK_ITEMS; it += ILP) {
+        S v[ILP]; unsigned o[ILP];                                // o = (number of positives below the candidate) * sb
+        #pragma unroll
+        for (int q = 0; q < ILP; q++) {                           // masked / NaN / beyond the row: bin 0
+            const long long item = i0 + (long long)(it + q) * STREAM_RANK_THREADS + threadIdx.x;
+            v[q] = (nxt[q] == nxt[q] && item < n) ? nxt[q] : -(S)INFINITY; o[q] = 0;
+        }
+        load_batch(it + ILP, nxt);                                // the next batch's HBM latency hides behind this batch's searches
+        for (unsigned st = ((unsigned)top >> 1) << lgsb; st >= sb; st >>= 1) {
+            S pv[ILP];
+            #pragma unroll
+            for (int q = 0; q < ILP; q++) pv[q] = *(LdsS)(tab_addr + o[q] + st - sb);
+            #pragma unroll
+            for (int q = 0; q < ILP; q++) o[q] = (pv[q] < v[q]) ? o[q] + st : o[q];
+        }
+        S nx[ILP];
+        #pragma unroll
+        for (int q = 0; q < ILP; q++) nx[q] = *(LdsS)(tab_addr + o[q]);          // entry `top - 1` is +inf: always in range
+        #pragma unroll
+        for (int q = 0; q < ILP; q++) {
+            int l = (int)(o[q] >> lgsb);
+            if (nx[q] == v[q]) {                                  // exact tie with a positive (rare)
+                const int item = (int)(i0 + (long long)(it + q) * STREAM_RANK_THREADS + threadIdx.x);
+                while (l < P && *(LdsS)(tab_addr + ((unsigned)l << lgsb)) == v[q] && pit[l] > item) l++;
+            }
+            if (l >= 1) __hip_atomic_fetch_add((LdsU)(hist_addr + 4u * (unsigned)(l - 1)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
+template <class T, class S>
+__global__ __launch_bounds__(STREAM_RANK_THREADS) void k_rank_streamed(FinalArgs<T, S> a, int parts)
+{
+    __shared__ __attribute__((aligned(16))) char rk_smem[STREAM_RANK_LDS];
+    const int d = blockIdx.x / parts, part = blockIdx.x % parts;
+    const int slot = a.stream_slot0 + d;
+    const int u = a.slot_user[slot];
+    const int te0 = a.test_p[u], P = a.test_p[u + 1] - te0;
+    constexpr int WORDS = STREAM_RANK_LDS / 4;
+    constexpr int per = (int)sizeof(S) / 4;                       // LDS words per score
+    int top = 1;
+    while (top <= P) top <<= 1;                                   // table = top entries: P positives, then +inf
+    int R = 0;
+    if ((long long)top * per + P <= WORDS) { R = 1; while (R < 32 && (long long)top * 2 * R * per + P <= WORDS) R *= 2; }
+    const int *pit = a.spos_item + te0;
+    const S *row = a.stream_scores + (size_t)d * (size_t)a.stream_ld;
+    const long long i0 = (long long)part * STREAM_RANK_THREADS * STREAM_RANK_ITEMS;
+    if (R > 0) {
+        S *lds_s = (S *)rk_smem;                                  // [top][R]
+        unsigned *lds_h = (unsigned *)(rk_smem + sizeof(S) * (size_t)top * (size_t)R);
+        for (int i = threadIdx.x; i < top * R; i += STREAM_RANK_THREADS) { const int e = i / R; lds_s[i] = e < P ? a.spos_score[te0 + e] : (S)INFINITY; }
+        for (int i = threadIdx.x; i < P; i += STREAM_RANK_THREADS) lds_h[i] = 0u;
+        __syncthreads();
+        int lgsb = sizeof(S) == 4 ? 2 : 3;
+        for (int r = R; r > 1; r >>= 1) lgsb++;
+        const unsigned tab_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char *)rk_smem + (unsigned)((threadIdx.x & (R - 1)) * sizeof(S));
+        const unsigned hist_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds_h;
+        rank_streamed_lds<S, 8>(row, i0, a.n, pit, P, top, lgsb, tab_addr, hist_addr);
+        __syncthreads();
+        for (int i = threadIdx.x; i < P; i += STREAM_RANK_THREADS) { const unsigned c = lds_h[i]; if (c) atomicAdd(&a.shist[te0 + i], c); }
+    } else {                                                      // very long row: search in global memory
+        const S *tab = a.spos_score + te0;
+        unsigned *hist = a.shist + te0;
+        for (int it = 0; it < STREAM_RANK_ITEMS; it++) {
+            const long long item = i0 + (long long)it * STREAM_RANK_THREADS + threadIdx.x;
+            if (item >= a.n) break;
+            const S v = row[item];
+            if (v != v) continue;
+            int lo = 0;
+            for (int st = top >> 1; st >= 1; st >>= 1) { const int idx = lo + st; if (idx <= P && tab[idx - 1] < v) lo = idx; }
+            while (lo < P && tab[lo] == v && pit[lo] > (int)item) lo++;
+            if (lo >= 1) atomicAdd(&hist[lo - 1], 1u);
+        }
+    }
+}
+
+// One wavefront per streamed user: ranks of its positives from the counts above (descending walk), the ROC ingredients,
+// and the PR-AUC sum in the reference's own order -- left to right over the positives by descending score (:795-865) --
+// so that PR-AUC is bit-identical for these users whatever the length of the row.
+template <class T, class S>
+__global__ void k_auc_streamed(FinalArgs<T, S> a, int n_stream)
+{
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (w >= n_stream) return;
+    const int slot = a.stream_slot0 + w;
+    const int u = a.slot_user[slot];
+    const int te0 = a.test_p[u], P = a.test_p[u + 1] - te0;
+    unsigned long long above = 0, sum_ranks = 0;
+    double s2 = 0;
+    int nvalid = 0;
+    for (int base = P; base > 0; base -= WAVE) {
+        const int j = base - 1 - lane;                            // lane 0 holds the best remaining positive
+        const bool live = j >= 0;
+        const unsigned long long h = live ? (unsigned long long)a.shist[te0 + j] : 0ull;
+        unsigned long long incl = h;
+        #pragma unroll
+        for (int dd = 1; dd < WAVE; dd <<= 1) {
+            const unsigned lo32 = (unsigned)__shfl_up((int)(unsigned)incl, dd), hi32 = (unsigned)__shfl_up((int)(unsigned)(incl >> 32), dd);
+            if (lane >= dd) incl += ((unsigned long long)hi32 << 32) | lo32;
+        }
+        const S ps = live ? a.spos_score[te0 + j] : (S)0;
+        const bool valid = live && !(isinf(ps) && ps > 0);        // +inf = masked by the train row
+        const unsigned long long vm = __ballot(valid);
+        const unsigned long long rank = above + incl + 1;
+        const int myidx = nvalid + __popcll(vm & ((1ull << lane) - 1ull)) + 1;
+        const double term = valid ? (double)myidx / (double)rank : 0.;
+        unsigned long long rs = valid ? rank : 0ull;
+        #pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) {
+            const unsigned lo32 = (unsigned)__shfl_xor((int)(unsigned)rs, dd), hi32 = (unsigned)__shfl_xor((int)(unsigned)(rs >> 32), dd);
+            rs += ((unsigned long long)hi32 << 32) | lo32;
+        }
+        sum_ranks += rs;
+        for (unsigned long long mm = vm; mm; mm &= mm - 1) s2 += lane_bcast<double>(term, __ffsll((long long)mm) - 1);
+        if (a.rank_sorted && valid) a.rank_sorted[te0 + j] = (long long)rank;
+        const int last = (base < WAVE ? base : WAVE) - 1;         // lane of the lowest positive of this step
+        above += ((unsigned long long)(unsigned)__shfl((int)(unsigned)(incl >> 32), last) << 32) | (unsigned)__shfl((int)(unsigned)incl, last);
+        nvalid += __popcll(vm);
+    }
+    if (lane == 0) { AucPart r; r.sum_ranks = sum_ranks; r.s1 = 0; r.s2 = s2; r.nvalid = nvalid; r.pad = 0; a.auc_part[slot] = r; }
 }
 
 // The L = min(K, npos) largest test VALUES of a user, descending (ideal DCG, reference :868-961), for users whose row is too

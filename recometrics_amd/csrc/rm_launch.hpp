@@ -32,6 +32,10 @@ struct SweepArgs {
     ListEntry *pl;                        // partial lists [slot][n_part][K]
     PartialStat<float> *pst;              // [slot][n_part]
     float *dump;                          // DUMP mode: dense [n_slots][n] scores
+    // streamed users = slots [stream_slot0, n_slots): their masked candidate scores go to stream_scores[slot - stream_slot0][item]
+    int stream_slot0;
+    long long stream_ld;                  // row stride in elements (= tiles_total * items per tile)
+    float *stream_scores;
 };
 
 struct Sweep64Args {
@@ -56,6 +60,9 @@ struct Sweep64Args {
     Entry<double> *pl;                    // [slot][n_part][K]
     PartialStat<double> *pst;             // [slot][n_part]
     double *dump;
+    int stream_slot0;                     // streamed users: see SweepArgs
+    long long stream_ld;
+    double *stream_scores;
 };
 
 // return 0 = launched, -1 = unsupported factor-group count, otherwise a hipError_t

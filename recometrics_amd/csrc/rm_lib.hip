@@ -216,6 +216,20 @@ void run(const Call<T> &c, hipStream_t stream)
     int *heavy_users = (int *)ws.get("heavy_users", sizeof(int) * (size_t)m);
     ClassifyArgs ca{m, n, K, c.train_p, c.test_p, req, c.cold ? 1 : 0, min_items_pool, min_pos_test, want_auc ? 1 : 0,
                     flags, user_nslots, heavy_users, plan};
+    // Users with more than POS_CHUNK test items are "streamed" (rm_device.hpp STREAM_CLASS) when a score row for each of
+    // them fits the HBM budget: a third of the free memory unless RM_STREAM_BUDGET_MB says otherwise (0 = never; such
+    // users then take one sweep slot per chunk of their test row -- same results, the contraction repeated per chunk).
+    const long long stream_ld_max = ((long long)n + 191) / 192 * 192;             // row stride for either tile size (64 / 96 items)
+    if (want_auc) {
+        long long budget;
+        if (const char *e = getenv("RM_STREAM_BUDGET_MB")) budget = atoll(e) << 20;
+        else { size_t fr = 0, tot = 0; HIP_CHECK(hipMemGetInfo(&fr, &tot)); budget = (long long)(fr / 3); }
+        const long long cap = budget / (stream_ld_max * (long long)sizeof(T));
+        if (cap > 0) {
+            hipLaunchKernelGGL(k_count_long, dim3(cdiv(m, 1024)), dim3(1024), 0, stream, m, c.test_p, plan);
+            hipLaunchKernelGGL(k_decide_stream, dim3(1), dim3(1), 0, stream, plan, cap);
+        }
+    }
     hipLaunchKernelGGL(k_classify, dim3(cdiv(m, 1024)), dim3(1024), 0, stream, ca);
     if (m > 8192) {                                          // one block walking the whole array costs ~0.5 us per 1024 entries
         const int n_tiles = (int)cdiv(m, 1024);
@@ -236,7 +250,9 @@ void run(const Call<T> &c, hipStream_t stream)
     unsigned char *slot_j = (unsigned char *)ws.get("slot_j", (size_t)slot_bound);
     int *gj = (int *)ws.get("gj", sizeof(int) * (size_t)group_bound);
     long long *grow = (long long *)ws.get("grow", sizeof(long long) * (size_t)group_bound);
-    AssignArgs aa{m, c.test_p, flags, user_nslots, uslot_base, want_auc ? 1 : 0, plan, slot_user, slot_chunk, slot_index, slot_j};
+    int *sc_user = (int *)ws.get("sc_user", sizeof(int) * (size_t)slot_bound);
+    int *sc_chunk = (int *)ws.get("sc_chunk", sizeof(int) * (size_t)slot_bound);
+    AssignArgs aa{m, c.test_p, flags, user_nslots, uslot_base, want_auc ? 1 : 0, plan, slot_user, slot_chunk, slot_index, slot_j, sc_user, sc_chunk};
     hipLaunchKernelGGL(k_assign_slots, dim3(cdiv(m, ASSIGN_THREADS)), dim3(ASSIGN_THREADS), 0, stream, aa);
     const long long block_bound = group_bound / GROUPS_PER_BLOCK + 2;
     int *blk_j = (int *)ws.get("blk_j", sizeof(int) * (size_t)block_bound);
@@ -260,6 +276,9 @@ void run(const Call<T> &c, hipStream_t stream)
 
     const int n_slots = hp.n_slots, n_groups = hp.n_groups;
     const int jmax = want_auc ? hp.jmax : 0;
+    // streamed users own the last slots; the tables and their kernels cover slots [0, stream_slot0)
+    const int n_stream = want_auc ? hp.class_count[STREAM_CLASS] : 0;
+    const int stream_slot0 = n_stream > 0 ? hp.class_offset[STREAM_CLASS] : n_slots;
     // |any partial sum| <= k * max|A| * max|B|: if that is comfortably finite in T, no score is NaN / Inf
     double amax_a, amax_b;
     std::memcpy(&amax_a, &hp.amax_a, 8); std::memcpy(&amax_b, &hp.amax_b, 8);
@@ -324,6 +343,8 @@ void run(const Call<T> &c, hipStream_t stream)
     Entry<T> *merged = (Entry<T> *)ws.get("merged", sizeof(Entry<T>) * (size_t)m * K);
     T *pos_score = nullptr; unsigned *hist = nullptr; int *pos_order = nullptr, *pos_item = nullptr;
     Entry<T> *pl = nullptr; PartialStat<T> *pst = nullptr;
+    T *stream_scores = nullptr, *spos_score = nullptr; int *spos_item = nullptr; unsigned *shist = nullptr;
+    const long long stream_ld = (long long)tiles_total * tile_items;
 
     if (n_slots > 0) {
         // ---- pack operands into the MFMA images ----
@@ -344,8 +365,22 @@ void run(const Call<T> &c, hipStream_t stream)
             HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(unsigned) * (size_t)rows * GU, stream));
             PosArgs<T> pa{m, n, k, c.A, c.lda, c.B, c.ldb, c.train_p, c.train_i, c.test_p, c.test_i,
                           flags, user_nslots, uslot_base, slot_index, grow, pos_tmp, pos_order, pos_score, pos_item, GU};
-            hipLaunchKernelGGL(k_pos_scores<T>, dim3(cdiv(n_slots, POSS_WAVES)), dim3(POSS_WAVES * WAVE), 0, stream, pa, slot_user, slot_chunk, n_slots);
-            hipLaunchKernelGGL(k_pos_place<T>, dim3(cdiv((long long)n_slots * WAVE, 256)), dim3(256), 0, stream, pa, slot_user, slot_chunk, n_slots);
+            if (stream_slot0 > 0) {
+                hipLaunchKernelGGL(k_pos_scores<T>, dim3(cdiv(stream_slot0, POSS_WAVES)), dim3(POSS_WAVES * WAVE), 0, stream, pa, slot_user, slot_chunk, stream_slot0);
+                hipLaunchKernelGGL(k_pos_place<T>, dim3(cdiv((long long)stream_slot0 * WAVE, 256)), dim3(256), 0, stream, pa, slot_user, slot_chunk, stream_slot0);
+            }
+            if (n_stream > 0) {
+                const size_t nz = (size_t)std::max<long long>(c.nnz_test, 1);
+                stream_scores = (T *)ws.get("stream_scores", sizeof(T) * (size_t)n_stream * (size_t)stream_ld);
+                spos_score = (T *)ws.get("spos_score", sizeof(T) * nz);
+                spos_item = (int *)ws.get("spos_item", sizeof(int) * nz);
+                shist = (unsigned *)ws.get("shist", sizeof(unsigned) * nz);
+                HIP_CHECK(hipMemsetAsync(shist, 0, sizeof(unsigned) * nz, stream));
+                pa.stream = 1; pa.spos_score = spos_score; pa.spos_item = spos_item;
+                const int nsc = hp.n_stream_chunks;
+                hipLaunchKernelGGL(k_pos_scores<T>, dim3(cdiv(nsc, POSS_WAVES)), dim3(POSS_WAVES * WAVE), 0, stream, pa, sc_user, sc_chunk, nsc);
+                hipLaunchKernelGGL(k_pos_place<T>, dim3(cdiv((long long)nsc * WAVE, 256)), dim3(256), 0, stream, pa, sc_user, sc_chunk, nsc);
+            }
         }
 
         pl = (Entry<T> *)ws.get("pl", sizeof(Entry<T>) * (size_t)n_slots * n_part * K);
@@ -369,6 +404,7 @@ void run(const Call<T> &c, hipStream_t stream)
         sa.pos_score = pos_score; sa.pos_item = pos_item; sa.hist = hist; sa.glists = glists; sa.pl = pl; sa.pst = pst; sa.dump = nullptr;
         P::set_pending(sa, pend_cap, (int)pend_off);
         P::set_sync(sa, (int)sync_off);
+        sa.stream_slot0 = stream_slot0; sa.stream_ld = stream_ld; sa.stream_scores = stream_scores;
 
         HIP_CHECK(hipEventRecord(g_ev[1], stream));
         // Depth split: when only the deepest user blocks force the lists out of LDS (the allocation is sized per launch,
@@ -432,7 +468,14 @@ void run(const Call<T> &c, hipStream_t stream)
     if (n_slots > 0) {
         if (want_auc) {
             fa.auc_part = (AucPart *)ws.get("auc_part", sizeof(AucPart) * (size_t)n_slots);
-            hipLaunchKernelGGL((k_auc_slots<T, T>), dim3(cdiv(n_slots, 256)), dim3(256), 0, stream, fa);
+            fa.stream_slot0 = stream_slot0; fa.stream_scores = stream_scores; fa.stream_ld = stream_ld;
+            fa.spos_score = spos_score; fa.spos_item = spos_item; fa.shist = shist;
+            if (n_stream > 0) {
+                const int parts = (int)cdiv(n, STREAM_RANK_THREADS * STREAM_RANK_ITEMS);
+                hipLaunchKernelGGL((k_rank_streamed<T, T>), dim3((unsigned)((long long)n_stream * parts)), dim3(STREAM_RANK_THREADS), 0, stream, fa, parts);
+                hipLaunchKernelGGL((k_auc_streamed<T, T>), dim3(cdiv((long long)n_stream * WAVE, 256)), dim3(256), 0, stream, fa, n_stream);
+            }
+            if (stream_slot0 > 0) hipLaunchKernelGGL((k_auc_slots<T, T>), dim3(cdiv(stream_slot0, 256)), dim3(256), 0, stream, fa);
         }
         const size_t fin_lds = finalize_lds_bytes<T>(K, n_part);
         HIP_CHECK(hipFuncSetAttribute((const void *)k_finalize<T, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));

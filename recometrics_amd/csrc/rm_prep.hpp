@@ -25,6 +25,19 @@ __device__ __forceinline__ int chunk_depth(int pc)      // smallest j with 2^j -
     return 32 - __clz(pc);
 }
 
+// users with more than POS_CHUNK test items (an upper bound of the streamed class: eligibility is not looked at), and the
+// decision whether their score rows fit the HBM budget (`cap` rows)
+__global__ void k_count_long(int m, const int *test_p, Plan *plan)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    const int npos = u < m ? test_p[u + 1] - test_p[u] : 0;
+    const bool lng = npos > POS_CHUNK;
+    const unsigned long long mk = __ballot(lng);
+    if (mk && (threadIdx.x & 63) == __ffsll((long long)mk) - 1) atomicAdd(&plan->n_long, __popcll(mk));
+    if (lng) atomicMax(&plan->max_npos, npos);
+}
+__global__ void k_decide_stream(Plan *plan, long long cap) { plan->stream_enable = plan->n_long > 0 && plan->n_long <= cap; }
+
 // reference recometrics.hpp:439-448, :479-486  (one thread per user)
 __global__ void k_classify(ClassifyArgs a)
 {
@@ -42,7 +55,10 @@ __global__ void k_classify(ClassifyArgs a)
     if (isnan_user) f = UF_NAN;
     else {
         f = UF_ACTIVE | (only_ndcg ? UF_ONLY_NDCG : 0) | (kleqn ? UF_KLEQN : 0);
-        if (a.want_auc && !only_ndcg) {
+        if (a.want_auc && !only_ndcg && npos > POS_CHUNK && a.plan->stream_enable) {
+            nsl = 1;                                            // streamed user: one slot, ranks from its stored score row
+            myclass = STREAM_CLASS;
+        } else if (a.want_auc && !only_ndcg) {
             nfull = npos / POS_CHUNK;
             const int rem = npos % POS_CHUNK;
             nsl = nfull + (rem ? 1 : 0);
@@ -53,13 +69,13 @@ __global__ void k_classify(ClassifyArgs a)
         }
     }
     // counts are aggregated per block in LDS, then one global atomic per block and class (the counters share a line)
-    __shared__ int blk_count[MAX_J + 2];                          // [MAX_J + 1] = evaluated users
-    if (threadIdx.x <= MAX_J + 1) blk_count[threadIdx.x] = 0;
+    __shared__ int blk_count[N_CLASSES + 1];                      // [N_CLASSES] = evaluated users
+    if (threadIdx.x <= N_CLASSES) blk_count[threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const unsigned long long act = __ballot(!isnan_user);
-    if (act && lane == __ffsll((long long)act) - 1) atomicAdd(&blk_count[MAX_J + 1], __popcll(act));
-    for (int j = 0; j <= MAX_J; j++) {
+    if (act && lane == __ffsll((long long)act) - 1) atomicAdd(&blk_count[N_CLASSES], __popcll(act));
+    for (int j = 0; j < N_CLASSES; j++) {
         const unsigned long long mk = __ballot(myclass == j);
         if (mk && lane == __ffsll((long long)mk) - 1) atomicAdd(&blk_count[j], __popcll(mk));
     }
@@ -67,8 +83,8 @@ __global__ void k_classify(ClassifyArgs a)
     if (live) { a.flags[u] = f; a.user_nslots[u] = nsl; }
     if (live && !isnan_user && npos > HEAVY_NPOS) a.heavy_users[atomicAdd(&a.plan->n_heavy, 1)] = u;      // rare
     __syncthreads();
-    if (threadIdx.x <= MAX_J && blk_count[threadIdx.x]) atomicAdd(&a.plan->class_count[threadIdx.x], blk_count[threadIdx.x]);
-    if (threadIdx.x == MAX_J + 1 && blk_count[MAX_J + 1]) atomicAdd(&a.plan->n_active, blk_count[MAX_J + 1]);
+    if (threadIdx.x < N_CLASSES && blk_count[threadIdx.x]) atomicAdd(&a.plan->class_count[threadIdx.x], blk_count[threadIdx.x]);
+    if (threadIdx.x == N_CLASSES && blk_count[N_CLASSES]) atomicAdd(&a.plan->n_active, blk_count[N_CLASSES]);
 }
 
 // Long arrays are scanned in three launches: k_scan_tiles (every block scans its own 1024 entries and reports its total),
@@ -125,13 +141,13 @@ __global__ void k_scan_exclusive(const int *in, int *out, int count, int *total_
 __global__ void k_plan_classes(Plan *p, int gu)      // one thread; gu = users per group (32 fp32, 16 fp64)
 {
     int off = 0, jmax = 0;
-    for (int j = 0; j <= MAX_J; j++) {
+    for (int j = 0; j < N_CLASSES; j++) {
         p->class_offset[j] = off;
         off += p->class_count[j];
-        if (p->class_count[j]) jmax = j;
+        if (p->class_count[j] && j <= MAX_J) jmax = j;         // deepest TABLE: streamed users have none
         p->class_cursor[j] = 0;
     }
-    p->class_offset[MAX_J + 1] = off;
+    p->class_offset[N_CLASSES] = off;
     p->n_groups = (p->n_slots + gu - 1) / gu;
     p->jmax = jmax;
 }
@@ -143,6 +159,7 @@ struct AssignArgs {
     Plan *plan;
     int *slot_user, *slot_chunk, *slot_index;
     unsigned char *slot_j;
+    int *sc_user, *sc_chunk;     // work list of the streamed users' chunks of POS_CHUNK test entries (plan->n_stream_chunks of them)
 };
 
 // scatter every (user, chunk) into its depth class; order inside a class is arbitrary (results do not depend on it).
@@ -151,18 +168,19 @@ struct AssignArgs {
 constexpr int ASSIGN_THREADS = 1024;
 __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign_slots(AssignArgs a)
 {
-    __shared__ int blk_count[MAX_J + 1], blk_base[MAX_J + 1];
+    __shared__ int blk_count[N_CLASSES], blk_base[N_CLASSES];
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    if (threadIdx.x <= MAX_J) blk_count[threadIdx.x] = 0;
+    if (threadIdx.x < N_CLASSES) blk_count[threadIdx.x] = 0;
     __syncthreads();
     const int nsl = u < a.m ? a.user_nslots[u] : 0;
     const int npos = nsl ? a.test_p[u + 1] - a.test_p[u] : 0;
     const bool auc_user = nsl && a.want_auc && !(a.flags[u] & UF_ONLY_NDCG);
     // last (or only) chunk of every user: position inside the block's share of its class
     int jlast = -1, in_blk = 0;
-    if (nsl) jlast = auc_user ? chunk_depth(min(POS_CHUNK, npos - (nsl - 1) * POS_CHUNK)) : 0;
-    for (int j = 0; j <= MAX_J; j++) {
+    const bool streamed = auc_user && nsl == 1 && npos > POS_CHUNK;
+    if (nsl) jlast = streamed ? STREAM_CLASS : auc_user ? chunk_depth(min(POS_CHUNK, npos - (nsl - 1) * POS_CHUNK)) : 0;
+    for (int j = 0; j < N_CLASSES; j++) {
         const unsigned long long mk = __ballot(jlast == j);
         if (!mk) continue;
         const int leader = __ffsll((long long)mk) - 1;
@@ -175,8 +193,13 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign_slots(AssignArgs a)
     int full_at = 0;
     if (nsl > 1) full_at = atomicAdd(&blk_count[MAX_J], nsl - 1);
     __syncthreads();
-    if (threadIdx.x <= MAX_J && blk_count[threadIdx.x]) blk_base[threadIdx.x] = atomicAdd(&a.plan->class_cursor[threadIdx.x], blk_count[threadIdx.x]);
+    if (threadIdx.x < N_CLASSES && blk_count[threadIdx.x]) blk_base[threadIdx.x] = atomicAdd(&a.plan->class_cursor[threadIdx.x], blk_count[threadIdx.x]);
     __syncthreads();
+    if (streamed) {                                              // rare: the order of the work list does not matter
+        const int nch = (npos + POS_CHUNK - 1) / POS_CHUNK;
+        const int at = atomicAdd(&a.plan->n_stream_chunks, nch);
+        for (int c = 0; c < nch; c++) { a.sc_user[at + c] = u; a.sc_chunk[at + c] = c; }
+    }
     if (nsl) {
         const int pos = a.plan->class_offset[jlast] + blk_base[jlast] + in_blk;
         a.slot_user[pos] = u;
@@ -202,7 +225,13 @@ __global__ void k_block_rows(const Plan *p, const unsigned char *slot_j, int *bl
     if (b * GROUPS_PER_BLOCK >= ng) return;
     const int glast = min(ng, (b + 1) * GROUPS_PER_BLOCK) - 1;
     const int slast = min(ns, (glast + 1) * gu) - 1;
-    const int jb = slot_j[slast];
+    int jb = slot_j[slast];
+    if (jb == STREAM_CLASS) {
+        // streamed slots are the last class: a block of nothing else has no tables at all, the one block that straddles
+        // the boundary sizes its tables for the deepest of its other slots
+        const int first_stream = p->class_offset[STREAM_CLASS];
+        jb = first_stream > b * GROUPS_PER_BLOCK * gu ? slot_j[first_stream - 1] : 0;
+    }
     blk_j[b] = jb;
     blk_rows[b] = (glast - b * GROUPS_PER_BLOCK + 1) * ((1 << jb) - 1);
 }
@@ -376,6 +405,10 @@ template <class T> struct PosArgs {
     T *pos_score;        // [(total_rows + n_groups)][32]: group g owns rows (grow[g] + g) .. + 2^j - 1, last row = +inf pad
     int *pos_item;       // same shape: item id of each sorted positive (tie resolution)
     int gu;              // users per group
+    // streamed users (work list = their chunks): the sorted positives go to contiguous rows instead of group tables
+    int stream;          // 1 = the work list is the streamed users' chunk list
+    T *spos_score;       // [nnz_test] at test_p[u] + rank: scores ascending, order (score asc, item desc)
+    int *spos_item;      // [nnz_test] their item ids
 };
 
 __device__ __forceinline__ bool in_sorted_row(const int *row, int len, int item)
@@ -482,7 +515,11 @@ __global__ void k_pos_place(PosArgs<T> a, const int *slot_user, const int *slot_
             }
         }
     }
-    if (mine) {
+    if (mine && a.stream) {
+        a.pos_order[e] = rank;
+        a.spos_score[te0 + rank] = s;
+        a.spos_item[te0 + rank] = item;
+    } else if (mine) {
         a.pos_order[e] = rank;
         const int c = rank / POS_CHUNK, r = rank % POS_CHUNK;
         const int slot = a.slot_index[a.uslot_base[u] + c];

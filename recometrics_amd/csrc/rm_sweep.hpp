@@ -273,6 +273,12 @@ void k_sweep(SweepArgs a)
         piv_hi = *(LdsF32Ptr)(pos_addr + (r0 + d) * 128);
     }
     const int *pos_item_g = (AUC && group_ok) ? a.pos_item + (a.grow[group] + group) * GROUP_USERS + ul : nullptr;
+    // streamed users (more than POS_CHUNK test items; the last slots): no table, no rank counting here -- the lane writes
+    // its masked scores to the user's row in HBM and k_rank_streamed counts from there.  Wave-uniform flag: a wave with
+    // none of them (all but the last few user blocks) pays one scalar branch per tile.
+    const bool stream_lane = AUC && slot_ok && slot >= a.stream_slot0;
+    const bool wave_streams = AUC && __any(stream_lane);
+    float *stream_row = stream_lane ? a.stream_scores + (size_t)(slot - a.stream_slot0) * (size_t)a.stream_ld : nullptr;
 
     // ---- staging: packed tile (BUF_F4 float4, contiguous) HBM -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging
     // registers, the wave never waits for the bytes before the end-of-step barrier.  One wave-instruction moves 1 KiB
@@ -473,6 +479,13 @@ void k_sweep(SweepArgs a)
 #endif
 #ifndef RM_ABL_NO_AUC
         // (4) AUC rank counting (replaces the full sort of :552 + the walk of :795-865)
+        if (AUC && wave_streams) {
+            if (stream_lane) {                                  // registers 4q .. 4q+3 are four consecutive items
+                #pragma unroll
+                for (int q4 = 0; q4 < 4; q4++)
+                    *(float4 *)(stream_row + sb + 8 * q4 + 4 * h) = make_float4(v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
+            }
+        }
         if (AUC) {
             switch (jb) {
                 case 1: auc_pass<1>(v, pos_addr, pos_item_g, sb, h, piv_root, piv_lo, piv_hi); break;

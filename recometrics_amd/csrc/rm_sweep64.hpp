@@ -211,6 +211,10 @@ void k_sweep64(Sweep64Args a)
     const char *posb = (const char *)(posL + gi * (PLmax + 1) * GU + ul);
     char *histb = (char *)(histL + gi * (PLmax + 1) * GU + ul);
     const int *pos_item_g = (AUC && group_ok) ? a.pos_item + (a.grow[group] + group) * GU + ul : nullptr;
+    // streamed users (see the fp32 sweep): the lane writes its masked scores to the user's row in HBM
+    const bool stream_lane = AUC && slot_ok && slot >= a.stream_slot0;
+    const bool wave_streams = AUC && __any(stream_lane);
+    double *stream_row = stream_lane ? a.stream_scores + (size_t)(slot - a.stream_slot0) * (size_t)a.stream_ld : nullptr;
 
     // unit u = (tile, chunk): contiguous BUF_D2 double2 of the packed image [tile][g][q][row][2]
     auto stage = [&](int tile, int chunk, int buf) {
@@ -336,6 +340,12 @@ void k_sweep64(Sweep64Args a)
                 const unsigned long long kk = ord_key(t2);
                 if (q == 0 && kk > thr_pub) atomicMax(a.thr_shared + slot, kk);
                 thr_pub = kk > thr_pub ? kk : thr_pub;
+            }
+        }
+        if (AUC && wave_streams) {
+            if (stream_lane) {
+                #pragma unroll
+                for (int r = 0; r < 8; r++) stream_row[sb + (r >> 2) * 16 + q + 4 * (r & 3)] = v[r];
             }
         }
         if (AUC) {

@@ -112,7 +112,9 @@ def _check_against_oracle(hip, oracle, pr, k, dtype=np.float32, **kw):
         got = hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], k, cumulative=cumulative, dtype=dtype, **kw)
         # PR_AUC of a user with more than 63 test items is assembled from per-chunk partial sums (finalize):
         # same terms, different association than the reference's single running sum -> a few ulp(fp64), checked at 1e-12
-        one_chunk = (np.diff(tep) <= 63)
+        # (only when such users take one sweep slot per chunk, RM_STREAM_BUDGET_MB=0; by default their ranks come from
+        # their stored score rows and the sum is the reference's own left-to-right one: bitwise for every user)
+        one_chunk = (np.diff(tep) <= 63) if os.environ.get("RM_STREAM_BUDGET_MB") == "0" else np.ones(len(tep) - 1, bool)
         for name in want:
             assert_close(got[name], want[name], TOL, "%s cumulative=%s" % (name, cumulative))
             if name == "PR_AUC":
@@ -172,6 +174,28 @@ def test_list_schemes_agree(hip, oracle, env, dtype, monkeypatch):
         monkeypatch.setenv(key, val)
     pr = make_problem(150, 9000, 48, dtype, mean_c=60, seed=5)
     _check_against_oracle(hip, oracle, pr, 12, dtype=dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("budget", ["0", "1", None])
+def test_long_test_rows_streamed_or_chunked(hip, oracle, dtype, budget, monkeypatch):
+    """users with more than 63 test items: streamed through HBM (default), one sweep slot per chunk of 63 when the
+    score rows do not fit the budget (forced here: 0 = never stream, 1 MB = too small for these rows)"""
+    from recometrics_amd.synth import make_problem
+    if budget is not None:
+        monkeypatch.setenv("RM_STREAM_BUDGET_MB", budget)
+    pr = make_problem(700, 7000, 40, dtype, mean_c=260, seed=31)         # about half of the users have long rows
+    if budget == "1":
+        monkeypatch.setenv("RM_STREAM_BUDGET_MB", "0")                       # the bitwise rule of the checker: chunked sums
+        _check_against_oracle(hip, oracle, pr, 10, dtype=dtype)
+        monkeypatch.setenv("RM_STREAM_BUDGET_MB", "1")
+        got = hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], 10, dtype=dtype)
+        monkeypatch.setenv("RM_STREAM_BUDGET_MB", "0")
+        ref = hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], 10, dtype=dtype)
+        for name in ref:
+            assert_same_bits(got[name], ref[name], "budget too small == never stream: " + name)
+    else:
+        _check_against_oracle(hip, oracle, pr, 10, dtype=dtype)
 
 
 def test_rank_outputs_do_not_depend_on_the_previous_call(hip, oracle):
