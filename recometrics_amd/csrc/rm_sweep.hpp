@@ -30,6 +30,13 @@ namespace rm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// NaN-ignoring hardware min / max (the masked-score sentinel is a NaN and must stay invisible).  Through inline asm: the
+// generic fmaxf / fminf lower to the same instructions PLUS one canonicalising v_max_f32 x, x, x per MFMA result (the
+// compiler cannot prove an accumulator is not a signalling NaN), which doubled the instruction count of the scan.
+__device__ __forceinline__ float hw_max(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float hw_max3(float a, float b, float c) { float d; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ float hw_min3(float a, float b, float c) { float d; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+
 
 typedef __attribute__((address_space(3))) unsigned long long *LdsListPtr;
 typedef u32x2 *GblListPtr;
@@ -42,27 +49,48 @@ typedef __attribute__((address_space(3))) unsigned *LdsU32Ptr;
 // `pos_addr` = LDS byte address of row 0 of the lane's user in its group's table.  The table of a group is 2^J rows
 // of 128 B and is ALIGNED to its own size, so "address of row r" = pos_addr | (r << 7): each level of the branchless
 // lower_bound is one OR (candidate address), one compare, one select -- no add.
+// One wavefront alone issues ONE instruction of any kind per ~4 cycles, and while its SIMD partners are inside their MFMA
+// chains this pass runs alone: its cost is its instruction COUNT, s_nop and s_waitcnt included.  The compiler's version
+// of a search level spends 6 issue slots per score -- v_or, s_waitcnt, v_cmp, s_nop (VALU-writes-SGPR hazard in front of
+// the select), v_cndmask -- so the compare / select pairs are written as inline asm in a software-pipelined order: the
+// select of score i issues after the compares of scores i+1 and i+2, which are the two wait states the hazard asks for
+// (three mask registers in rotation), and the LDS reads of a level are waited for in four groups instead of one by one.
+#define RM_CMP_LT(m, p, x) asm volatile("v_cmp_lt_f32 %0, %1, %2" : "=s"(m) : "v"(p), "v"(x))
+#define RM_SEL(d, a, b, m) asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(m))
+__device__ __forceinline__ float hw_absmin3(float a, float b, float c) { float d; asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+
 template <int J>
 __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr,
                                          const int *pos_item_g, int sb, int h, float piv_root, float piv_lo, float piv_hi)
 {
     // The 16 searches are independent: run them level by level (16 LDS reads in flight per level) instead of one
-    // dependent 6-deep chain after another, and keep the histogram atomics out of the way until all reads are done
-    // (an LDS atomic may alias the table for the compiler and would serialise the chains).  The pivots of the two
-    // top levels of the lane's user (root, and the roots of its two subtrees) are per-sweep constants held in
-    // registers: two of the dependent LDS round trips disappear.
+    // dependent 6-deep chain after another, and keep the histogram atomics out of the way until all reads are done.
+    // The pivots of the two top levels of the lane's user (root, and the roots of its two subtrees) are per-sweep
+    // constants held in registers: two of the dependent LDS round trips disappear.  They are sorted (lo <= root <= hi, the
+    // table is padded with +inf at its end), so the subtree a score falls into is simply the NUMBER of them below it:
+    // three independent compares, each selecting over the previous one, instead of a dependent compare-select-compare.
     // the block's histogram tables follow its four positives tables of 2^J rows each (k_sweep's carve): a compile-time
     // distance, so the LDS atomic below takes it as its immediate offset instead of an address add per score
     constexpr unsigned HIST_DELTA = (unsigned)GROUPS_PER_BLOCK * (1u << J) * GROUP_USERS * 4u;
     unsigned at[16];                                           // address of row `base`
     constexpr int TOP = J >= 2 ? 2 : 0;                        // levels resolved from registers
+    unsigned long long mk0, mk1, mk2;                          // lane masks in SGPR pairs, in rotation
     if (TOP == 2) {
+        constexpr unsigned Q = 128u << (J >= 2 ? J - 2 : 0);   // a quarter of the table
+        const unsigned a1 = pos_addr | Q, a2 = pos_addr | (2 * Q), a3 = pos_addr | (3 * Q);
         #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const bool c1 = piv_root < v[r];
-            const float p2 = c1 ? piv_hi : piv_lo;
-            const bool c2 = p2 < v[r];
-            at[r] = pos_addr | (c1 ? (128u << (J - 1)) : 0u) | (c2 ? (128u << (J - 2)) : 0u);
+        for (int r = 0; r < 16; r++) at[r] = pos_addr;
+        #pragma unroll
+        for (int i = 0; i < 48 + 2; i++) {                     // i = pivot * 16 + score
+            if (i < 48) {
+                const float pv = i < 16 ? piv_lo : (i < 32 ? piv_root : piv_hi);
+                if (i % 3 == 0) RM_CMP_LT(mk0, pv, v[i % 16]); else if (i % 3 == 1) RM_CMP_LT(mk1, pv, v[i % 16]); else RM_CMP_LT(mk2, pv, v[i % 16]);
+            }
+            if (i >= 2) {
+                const int j = i - 2;
+                const unsigned tgt = j < 16 ? a1 : (j < 32 ? a2 : a3);
+                if (j % 3 == 0) RM_SEL(at[j % 16], at[j % 16], tgt, mk0); else if (j % 3 == 1) RM_SEL(at[j % 16], at[j % 16], tgt, mk1); else RM_SEL(at[j % 16], at[j % 16], tgt, mk2);
+            }
         }
     } else {
         #pragma unroll
@@ -74,18 +102,31 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
         #pragma unroll
         for (int r = 0; r < 16; r++) pv[r] = *(LdsF32Ptr)(at[r] + (st - 1) * 128);
         #pragma unroll
-        for (int r = 0; r < 16; r++) at[r] = (pv[r] < v[r]) ? (at[r] | (st * 128)) : at[r];
+        for (int i = 0; i < 16 + 2; i++) {
+            // s_waitcnt lgkmcnt(12 / 8 / 4 / 0) with the other counters left alone (gfx9 encoding, see WAIT_VMCNT0)
+            if (i == 0) __builtin_amdgcn_s_waitcnt(0xCC7F); else if (i == 4) __builtin_amdgcn_s_waitcnt(0xC87F);
+            else if (i == 8) __builtin_amdgcn_s_waitcnt(0xC47F); else if (i == 12) __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (i < 16) { if (i % 3 == 0) RM_CMP_LT(mk0, pv[i], v[i]); else if (i % 3 == 1) RM_CMP_LT(mk1, pv[i], v[i]); else RM_CMP_LT(mk2, pv[i], v[i]); }
+            if (i >= 2) {
+                const int j = i - 2;
+                const unsigned cand = at[j] | (unsigned)(st * 128);
+                if (j % 3 == 0) RM_SEL(at[j], at[j], cand, mk0); else if (j % 3 == 1) RM_SEL(at[j], at[j], cand, mk1); else RM_SEL(at[j], at[j], cand, mk2);
+            }
+        }
     }
     // exact score tie with a positive (row `base` is the first positive not below s; the table has one +inf pad
     // row, so the read is always in range): the total order is (score desc, item asc), i.e. the candidate also
-    // outranks the equal-scored positives with a LARGER item id.  Rare; positives' item ids stay in HBM.
+    // outranks the equal-scored positives with a LARGER item id.  Rare; positives' item ids stay in HBM.  Detection: the
+    // smallest |next positive - score| of the 16 (a masked score gives NaN, which v_min3 ignores) is zero.
     float nx[16];
     #pragma unroll
     for (int r = 0; r < 16; r++) nx[r] = *(LdsF32Ptr)(at[r]);
-    unsigned long long tie = 0;
+    float df[16];
     #pragma unroll
-    for (int r = 0; r < 16; r++) tie |= __ballot(nx[r] == v[r]);
-    if (tie) {
+    for (int r = 0; r < 16; r++) df[r] = nx[r] - v[r];
+    const float dmin = hw_absmin3(hw_absmin3(hw_absmin3(df[0], df[1], df[2]), hw_absmin3(df[3], df[4], df[5]), hw_absmin3(df[6], df[7], df[8])),
+                                  hw_absmin3(hw_absmin3(df[9], df[10], df[11]), hw_absmin3(df[12], df[13], df[14]), df[15]), df[15]);
+    if (__any(dmin == 0.f)) {
         #pragma unroll
         for (int r = 0; r < 16; r++) {
             if (nx[r] == v[r]) {
@@ -96,9 +137,12 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
             }
         }
     }
+    // (inline asm: the six instantiations of this pass share one tail after the compiler's merge of the switch, which turned
+    // the compile-time distance into a register and an address add per score)
+    const unsigned one = 1u;
     #pragma unroll
     for (int r = 0; r < 16; r++)
-        __hip_atomic_fetch_add((LdsU32Ptr)at[r] + HIST_DELTA / 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("ds_add_u32 %0, %1 offset:%2" :: "v"(at[r]), "v"(one), "n"(HIST_DELTA) : "memory");
 }
 
 #ifdef RM_STATS
@@ -373,6 +417,8 @@ void k_sweep(SweepArgs a)
             }
             if (sb + 32 > n) mbits |= (n > sb) ? (0xffffffffu << (n - sb)) : 0xffffffffu;
             // the sentinel is all ones: OR-ing the sign-extended mask bit into the score masks it (2 VALU per register)
+            // (skipping the registers no lane masks, by a scalar union of the lanes' patterns, was measured 2-4 % SLOWER:
+            // the scalar loop and 16 branches are more issue slots than the 25 vector instructions they save)
             const int mb = (int)(mbits >> (4 * h));
             #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -387,16 +433,12 @@ void k_sweep(SweepArgs a)
 #ifndef RM_ABL_NO_STATS
         // (2) min / max over candidates (NaN-ignoring, so the sentinel is invisible) (:519-524): v_max3 / v_min3 trees
         // (the maxima of the four register quads are kept: the top-K path below skips a whole quad with one test)
-        const float qmax[4] = {__builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), __builtin_fmaxf(v[2], v[3])),
-                               __builtin_fmaxf(__builtin_fmaxf(v[4], v[5]), __builtin_fmaxf(v[6], v[7])),
-                               __builtin_fmaxf(__builtin_fmaxf(v[8], v[9]), __builtin_fmaxf(v[10], v[11])),
-                               __builtin_fmaxf(__builtin_fmaxf(v[12], v[13]), __builtin_fmaxf(v[14], v[15]))};
-        const float tmax = __builtin_fmaxf(__builtin_fmaxf(qmax[0], qmax[1]), __builtin_fmaxf(qmax[2], qmax[3]));
-        const float tmin = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fminf(v[0], v[1]), __builtin_fminf(v[2], v[3])),
-                                                           __builtin_fminf(__builtin_fminf(v[4], v[5]), __builtin_fminf(v[6], v[7]))),
-                                           __builtin_fminf(__builtin_fminf(__builtin_fminf(v[8], v[9]), __builtin_fminf(v[10], v[11])),
-                                                           __builtin_fminf(__builtin_fminf(v[12], v[13]), __builtin_fminf(v[14], v[15]))));
-        vmax = __builtin_fmaxf(vmax, tmax); vmin = __builtin_fminf(vmin, tmin);
+        const float qmax[4] = {hw_max3(v[0], v[1], hw_max(v[2], v[3])), hw_max3(v[4], v[5], hw_max(v[6], v[7])),
+                               hw_max3(v[8], v[9], hw_max(v[10], v[11])), hw_max3(v[12], v[13], hw_max(v[14], v[15]))};
+        const float tmax = hw_max3(qmax[0], qmax[1], hw_max(qmax[2], qmax[3]));
+        const float tmin = hw_min3(hw_min3(v[0], v[1], v[2]), hw_min3(v[3], v[4], v[5]), hw_min3(v[6], v[7], v[8]));
+        const float tmin2 = hw_min3(hw_min3(v[9], v[10], v[11]), hw_min3(v[12], v[13], v[14]), v[15]);
+        vmax = hw_max(vmax, tmax); vmin = hw_min3(vmin, tmin, tmin2);
 #endif
 #ifndef RM_ABL_NO_TOPK
         // (3) streaming top-K: anything at or above the user's current K-th best is offered to the list (:537-540).
@@ -597,6 +639,7 @@ void k_sweep(SweepArgs a)
         }
     }
     if (AUC) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): the asm histogram atomics are invisible to the compiler
         __syncthreads();
         for (int i = tid; i < GROUPS_PER_BLOCK * (PLb + 1) * GROUP_USERS; i += THREADS) {
             const int g4 = i / ((PLb + 1) * GROUP_USERS), rem = i % ((PLb + 1) * GROUP_USERS);
