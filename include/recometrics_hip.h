@@ -36,6 +36,9 @@ extern "C" {
 #define RM_ERR_HIP 2         /* HIP runtime failure (message has the hipError string) */
 #define RM_ERR_NOMEM 3       /* device or host allocation failed (the reference throws std::bad_alloc) */
 #define RM_ERR_UNSUPPORTED 4 /* shape outside what the kernels are built for (message says which) */
+#define RM_ERR_INTERRUPTED 5 /* SIGINT (or rm_request_interrupt) during a host-pointer call: "Error: procedure was interrupted."
+                              * -- the std::runtime_error of src/recometrics.hpp:171.  Users of finished batches have their
+                              * results; the rest of the output arrays is untouched, as in the reference (:488-489) */
 
 /* replaces calc_metrics_float  (src/recometrics_signatures.hpp:74-98).  ALL pointers are HOST pointers. */
 int rm_calc_metrics_f32(
@@ -121,6 +124,18 @@ int rm_has_openmp(void);
 const char *rm_last_error(void);       /* message of the last failing call on this thread ("" if none) */
 int rm_device_count(void);             /* visible HIP devices (0 when there is no GPU / driver) */
 int rm_set_device(int device);         /* device used by subsequent calls on this thread */
+
+/* Devices of the HOST-pointer calls (rm_calc_metrics_f32/f64, rm_rank_*) of this process: with n > 1 a call shards its users
+ * inside the library -- contiguous ranges [m g / n, m (g + 1) / n), one host thread + stream + workspace per entry, the item
+ * factors uploaded once and copied device-to-device, every shard's results written straight into the caller's arrays; no
+ * exchange between shards (reference: the OpenMP loop over users, src/recometrics.hpp:428-437).  The same device may be
+ * listed more than once.  n = 0 restores "the calling thread's current device".  Results do not depend on the list. */
+int rm_set_devices(const int32_t *devices, int32_t n);
+int rm_get_devices(int32_t *devices, int32_t cap);      /* returns the length of the list */
+
+/* Asks the host-pointer calls in flight to stop at their next batch boundary (what SIGINT does during such a call,
+ * src/recometrics.hpp:114-174); they return RM_ERR_INTERRUPTED. */
+void rm_request_interrupt(void);
 
 /* Timings of the most recent successful call on this thread, milliseconds measured with HIP events on the call's
  * stream: out[0] plan+pack+positives, out[1] sweep kernel, out[2] finalize, out[3] whole device section;

@@ -35,9 +35,10 @@ def _row_major_with_ld(X):
     (reference __init__.py:11-16)."""
     if X.flags["C_CONTIGUOUS"]:
         return X, X.shape[1]
-    if X.strides[1] == X.dtype.itemsize:
-        return X, X.strides[0] // X.itemsize
-    return np.ascontiguousarray(X), X.shape[1]
+    st0 = X.strides[0]
+    if X.strides[1] == X.dtype.itemsize and st0 > 0 and st0 % X.itemsize == 0 and st0 // X.itemsize >= X.shape[1]:
+        return X, st0 // X.itemsize
+    return np.ascontiguousarray(X), X.shape[1]          # reversed / overlapping / unaligned rows: a size_t cannot express them
 
 
 def _sorted_csr_int32(X):

@@ -18,7 +18,8 @@ METRIC_ORDER = ("p", "tp", "r", "ap", "tap", "ndcg", "hit", "rr", "roc", "pr")
 EXPORTS = (
     "rm_calc_metrics_f32", "rm_calc_metrics_f64", "rm_calc_metrics_dev_f32", "rm_calc_metrics_dev_f64",
     "rm_rank_f32", "rm_rank_f64", "rm_debug_scores_f32", "rm_debug_scores_f64", "rm_has_openmp",
-    "rm_last_error", "rm_device_count", "rm_set_device", "rm_get_timings", "rm_release_workspace",
+    "rm_last_error", "rm_device_count", "rm_set_device", "rm_set_devices", "rm_get_devices", "rm_request_interrupt",
+    "rm_get_timings", "rm_release_workspace",
     "rm_split_f32", "rm_split_f64", "rm_split_size", "rm_split_copy", "rm_split_free", "rm_split_last_error",
 )
 
@@ -66,6 +67,9 @@ def load():
     lib.rm_last_error.restype = C.c_char_p
     lib.rm_get_timings.argtypes = [C.POINTER(C.c_double), ci]
     lib.rm_set_device.argtypes = [ci]
+    lib.rm_set_devices.argtypes = [C.POINTER(i32), i32]
+    lib.rm_get_devices.argtypes = [C.POINTER(i32), i32]
+    lib.rm_request_interrupt.restype = None
     _lib = lib
     return lib
 
@@ -76,6 +80,11 @@ def _raise(lib, rc):
         raise ValueError(msg)
     if rc == 3:
         raise MemoryError(msg)
+    if rc == 5:
+        # the reference throws std::runtime_error("Error: procedure was interrupted.") after re-raising SIGINT
+        # (src/recometrics.hpp:166-173); Cython's `except +` turns it into this RuntimeError, and Python's own handler
+        # raises KeyboardInterrupt for the re-raised signal
+        raise RuntimeError(msg.strip())
     raise RuntimeError("recometrics_amd (status %d): %s" % (rc, msg))
 
 
@@ -98,6 +107,27 @@ def set_device(i):
         _raise(lib, rc)
 
 
+def set_devices(devices):
+    """Devices of the host-pointer calls of this process (rm_set_devices): a list of device ids, the same id may repeat;
+    an empty list restores "the current device"."""
+    lib = load()
+    arr = (C.c_int32 * max(len(devices), 1))(*devices)
+    rc = lib.rm_set_devices(arr, len(devices))
+    if rc:
+        _raise(lib, rc)
+
+
+def get_devices():
+    lib = load()
+    buf = (C.c_int32 * 64)()
+    n = lib.rm_get_devices(buf, 64)
+    return [int(buf[i]) for i in range(min(n, 64))]
+
+
+def request_interrupt():
+    load().rm_request_interrupt()
+
+
 def timings():
     lib = load()
     buf = (C.c_double * 8)()
@@ -111,7 +141,7 @@ def _suffix(dtype):
 
 
 def calc_metrics(A, lda, B, ldb, train_p, train_i, test_p, test_i, test_v, k_metrics, want, cumulative,
-                 break_ties_with_noise, consider_cold_start, min_items_pool, min_pos_test, nthreads, seed):
+                 break_ties_with_noise, consider_cold_start, min_items_pool, min_pos_test, nthreads, seed, outs=None):
     """Host-array entry.  `want`: dict metric-name -> bool in METRIC_ORDER.  Returns the 10-tuple of arrays the
     reference's cpp_funs.calc_reco_metrics returns (wrapper.pyx:306-323): size-0 arrays for metrics not requested,
     (m, k) arrays for cumulative top-K metrics."""
@@ -120,10 +150,11 @@ def calc_metrics(A, lda, B, ldb, train_p, train_i, test_p, test_i, test_v, k_met
     m, k = A.shape
     n = B.shape[0]
     size_arr = m * k_metrics if cumulative else m
-    outs = []
-    for name in METRIC_ORDER:
-        cnt = (m if name in ("roc", "pr") else size_arr) if want.get(name) else 0
-        outs.append(np.empty(cnt, dtype=dtype))
+    if outs is None:                                   # `outs`: ten caller-owned flat arrays (size 0 = not requested)
+        outs = []
+        for name in METRIC_ORDER:
+            cnt = (m if name in ("roc", "pr") else size_arr) if want.get(name) else 0
+            outs.append(np.empty(cnt, dtype=dtype))
     fn = getattr(lib, "rm_calc_metrics_" + _suffix(dtype))
     rc = fn(_p(A), lda, _p(B), ldb, m, n, k, _p(train_p), _p(train_i), _p(test_p), _p(test_i), _p(test_v),
             k_metrics, int(bool(cumulative)), int(bool(break_ties_with_noise)), *[_p(o) for o in outs],
@@ -163,6 +194,8 @@ def rank(A, B, train_p, train_i, test_p, test_i, k_metrics, break_ties_with_nois
     pr = np.zeros(max(int(test_i.shape[0]), 1), dtype=np.int64)
     st = np.empty(m, dtype=np.int32)
     fn = getattr(lib, "rm_rank_" + _suffix(dtype))
+    A = np.ascontiguousarray(A)                  # the raw pointer is passed with lda = k: rows must be dense
+    B = np.ascontiguousarray(B)
     rc = fn(_p(A), A.shape[1], _p(B), B.shape[1], m, n, k, _p(train_p), _p(train_i), _p(test_p), _p(test_i),
             k_metrics, int(bool(break_ties_with_noise)), int(bool(consider_cold_start)), min_items_pool, min_pos_test, seed,
             _p(idx), _p(sc), _p(pr), _p(st))

@@ -65,7 +65,8 @@ struct Plan {                                     // produced on device, read ba
     int stream_enable;      // 1 = those users are streamed (their score rows fit the HBM budget), 0 = they get one slot per chunk
     int max_npos;           // longest test row (k_count_long)
     int n_stream_chunks;    // chunks of POS_CHUNK test entries over all streamed users (work items of the positives kernels)
-    int nonfinite;                      // some factor of A or B is NaN / Inf
+    int nonfinite;                      // some factor of A is NaN / Inf
+    int nonfinite_b;                    // some factor of B is NaN / Inf
     int n_heavy;                        // evaluated users with more than HEAVY_NPOS test items (listed by k_classify)
     unsigned long long amax_a, amax_b;  // bit patterns of max|A|, max|B| as doubles (non-negative doubles order like u64)
 };

@@ -11,9 +11,14 @@
 #include <cstring>
 #include <cstdlib>
 #include <type_traits>
+#include <atomic>
+#include <condition_variable>
+#include <csignal>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/recometrics_hip.h"
@@ -27,14 +32,6 @@ namespace {
 using namespace rm;
 
 thread_local std::string g_err;
-thread_local double g_timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-thread_local hipEvent_t g_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-thread_local bool g_ev_valid = false;
-thread_local hipStream_t g_ev_stream = nullptr;
-thread_local hipStream_t g_side_stream = nullptr;      // second sweep launch of a depth-split call runs beside the first
-thread_local hipEvent_t g_side_ev[2] = {nullptr, nullptr};
-std::mutex g_mu;
-
 struct RmError { int code; std::string msg; };
 
 #define HIP_CHECK(expr)                                                                                   \
@@ -67,13 +64,40 @@ struct Workspace {
         bufs.clear();
     }
 };
-std::map<int, Workspace> g_ws;
+// One context per (device, shard slot): the cached workspace plus the events / side stream that belong to that device.
+// Slot 0 serves ordinary calls; a call sharded inside the library (rm_set_devices) uses slot i for the i-th entry of the device
+// list, so that the same physical device can appear more than once ("virtual shards").  A context is used by ONE call at a
+// time (`mu` is held while that call enqueues its work), and a call whose stream differs from the previous call's waits for
+// that call's `done` event before it touches any workspace buffer: calls on different streams or threads serialise on the
+// device instead of corrupting each other's buffers.
+struct Ctx {
+    int device = 0, slot = 0;
+    std::mutex mu;
+    Workspace ws;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false, ev_recorded = false;
+    hipStream_t side_stream = nullptr;      // second sweep launch of a depth-split call runs beside the first
+    hipEvent_t side_ev[2] = {nullptr, nullptr};
+    hipEvent_t done = nullptr;               // end of the device work of the most recent call on this context
+    hipStream_t own_stream = nullptr;        // stream of a shard worker (multi-device calls)
+    double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double acc[4] = {0, 0, 0, 0};            // prep / sweep / finalize / total ms of the batches already read back (host entry)
+    // what the packed item image (workspace buffer "Bp") currently holds, for batches of one host call that share B
+    unsigned long long packed_tag = 0; int packed_tile = 0, packed_ng = 0; const void *packed_ptr = nullptr;
+    unsigned long long packed_amax_b = 0; int packed_nonfinite_b = 0;
+};
+std::mutex g_ctx_mu;
+std::map<std::pair<int, int>, std::unique_ptr<Ctx>> g_ctx;
+thread_local Ctx *g_last_ctx = nullptr;      // context of the most recent call on this thread (rm_get_timings)
 
-Workspace &workspace()
+Ctx &context(int slot)
 {
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
-    return g_ws[dev];
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    auto &p = g_ctx[std::make_pair(dev, slot)];
+    if (!p) { p.reset(new Ctx()); p->device = dev; p->slot = slot; }
+    return *p;
 }
 
 template <class T> struct Call {          // one calc_metrics call; every pointer is a DEVICE pointer
@@ -86,6 +110,9 @@ template <class T> struct Call {          // one calc_metrics call; every pointe
     bool cold; int min_items_pool, min_pos_test;
     // optional ranking outputs (device)
     int *topk_idx; T *topk_score; long long *pos_rank; int *status;
+    // batches of one host call share the item factors: a non-zero tag says "the packed image and the |B| bound made for this
+    // tag are still valid" (set by run_host_range; 0 = always repack)
+    unsigned long long items_tag;
 };
 
 inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
@@ -169,15 +196,15 @@ inline void dispatch_sweep(bool auc, bool dump, bool llds, int, int NG, dim3 gri
 }
 
 inline void pack_operands(const float *A, size_t lda, const float *B, size_t ldb, int n, int k, int NG, int tile_items, const int *slot_user,
-                          int n_slots, float4 *Ap, long long ap, float4 *Bp, long long bp, hipStream_t stream)
+                          int n_slots, float4 *Ap, long long ap, float4 *Bp, long long bp, hipStream_t stream, bool items = true)
 {
-    hipLaunchKernelGGL(k_pack_items<float>, dim3(cdiv(bp, 256)), dim3(256), 0, stream, B, ldb, n, k, NG, tile_items, Bp, bp);
+    if (items) hipLaunchKernelGGL(k_pack_items<float>, dim3(cdiv(bp, 256)), dim3(256), 0, stream, B, ldb, n, k, NG, tile_items, Bp, bp);
     hipLaunchKernelGGL(k_pack_users<float>, dim3(cdiv(ap, 256)), dim3(256), 0, stream, A, lda, k, NG, slot_user, n_slots, Ap, ap);
 }
 inline void pack_operands(const double *A, size_t lda, const double *B, size_t ldb, int n, int k, int NG, int, const int *slot_user,
-                          int n_slots, double2 *Ap, long long ap, double2 *Bp, long long bp, hipStream_t stream)
+                          int n_slots, double2 *Ap, long long ap, double2 *Bp, long long bp, hipStream_t stream, bool items = true)
 {
-    hipLaunchKernelGGL(k_pack_items64<double>, dim3(cdiv(bp, 256)), dim3(256), 0, stream, B, ldb, n, k, NG, Bp, bp);
+    if (items) hipLaunchKernelGGL(k_pack_items64<double>, dim3(cdiv(bp, 256)), dim3(256), 0, stream, B, ldb, n, k, NG, Bp, bp);
     hipLaunchKernelGGL(k_pack_users64<double>, dim3(cdiv(ap, 256)), dim3(256), 0, stream, A, lda, k, NG, slot_user, n_slots, Ap, ap);
 }
 
@@ -187,11 +214,13 @@ constexpr size_t LDS_LIMIT = 160 * 1024;
 // device pipeline (T = float: v_mfma_f32_32x32x2_f32 sweep; T = double: v_mfma_f64_16x16x4_f64 sweep)
 // ---------------------------------------------------------------------------------------------------------------------
 template <class T>
-void run(const Call<T> &c, hipStream_t stream)
+void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
 {
     typedef Prec<T> P;
     constexpr int GU = P::GU;
-    Workspace &ws = workspace();
+    Workspace &ws = cx.ws;
+    double *g_timings = cx.timings;
+    hipEvent_t *g_ev = cx.ev;
     const int m = c.m, n = c.n, k = c.k, K = c.K;
     // reference recometrics.hpp:390-393
     const int min_items_pool = std::max(std::max(c.min_items_pool, K), 2);
@@ -203,8 +232,14 @@ void run(const Call<T> &c, hipStream_t stream)
     const int NG = P::supported_ng(k);
     if (NG < 0) throw RmError{RM_ERR_UNSUPPORTED, std::string(P::limit()) + " (got " + std::to_string(k) + ")"};
 
-    if (!g_ev_valid) { for (auto &e : g_ev) HIP_CHECK(hipEventCreate(&e)); g_ev_valid = true; }
-    g_ev_stream = stream;
+    if (!cx.ev_valid) {
+        for (int i = 0; i < 5; i++) HIP_CHECK(hipEventCreate(&cx.ev[i]));
+        HIP_CHECK(hipEventCreateWithFlags(&cx.done, hipEventDisableTiming));
+        cx.ev_valid = true;
+    } else {
+        HIP_CHECK(hipStreamWaitEvent(stream, cx.done, 0));          // the previous call on this context may still be running on another stream
+    }
+    g_last_ctx = &cx;
     HIP_CHECK(hipEventRecord(g_ev[0], stream));
 
     // ---- plan ----
@@ -263,7 +298,8 @@ void run(const Call<T> &c, hipStream_t stream)
     hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, blk_rows, blk_base, (int)block_bound, blk_base + block_bound);
     hipLaunchKernelGGL(k_group_rows, dim3(cdiv(group_bound, 256)), dim3(256), 0, stream, plan, blk_j, blk_base, blk_base + block_bound, gj, grow);
     hipLaunchKernelGGL(k_absmax<T>, dim3(512), dim3(256), 0, stream, c.A, c.lda, (long long)m, k, &plan->amax_a, &plan->nonfinite);
-    hipLaunchKernelGGL(k_absmax<T>, dim3(1024), dim3(256), 0, stream, c.B, c.ldb, (long long)n, k, &plan->amax_b, &plan->nonfinite);
+    const bool items_known = c.items_tag != 0 && c.items_tag == cx.packed_tag;       // a later batch of the same host call
+    if (!items_known) hipLaunchKernelGGL(k_absmax<T>, dim3(1024), dim3(256), 0, stream, c.B, c.ldb, (long long)n, k, &plan->amax_b, &plan->nonfinite_b);
     // log2(i + 2) for the DCG discounts, from the host's libm like the reference's (:620,:902, int -> double log2); staged
     // here so that the one synchronisation of the call (the plan read-back below) also covers this stack-owned buffer
     std::vector<double> lt((size_t)K);
@@ -280,10 +316,12 @@ void run(const Call<T> &c, hipStream_t stream)
     const int n_stream = want_auc ? hp.class_count[STREAM_CLASS] : 0;
     const int stream_slot0 = n_stream > 0 ? hp.class_offset[STREAM_CLASS] : n_slots;
     // |any partial sum| <= k * max|A| * max|B|: if that is comfortably finite in T, no score is NaN / Inf
+    if (items_known) { hp.amax_b = cx.packed_amax_b; hp.nonfinite_b = cx.packed_nonfinite_b; }
+    else { cx.packed_amax_b = hp.amax_b; cx.packed_nonfinite_b = hp.nonfinite_b; }
     double amax_a, amax_b;
     std::memcpy(&amax_a, &hp.amax_a, 8); std::memcpy(&amax_b, &hp.amax_b, 8);
     const double tmax = std::is_same<T, float>::value ? 3.0e38 : 1.0e308;
-    const bool check_nan = hp.nonfinite || !((double)k * amax_a * 1.001 < tmax / std::max(amax_b, 1e-300));
+    const bool check_nan = hp.nonfinite || hp.nonfinite_b || !((double)k * amax_a * 1.001 < tmax / std::max(amax_b, 1e-300));
     const int n_ublocks = (n_groups + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK;
 
     // ---- sweep geometry ----
@@ -315,6 +353,7 @@ void run(const Call<T> &c, hipStream_t stream)
             if (score > best + 1e-9) { best = score; n_splits = sct; }
         }
     }
+    if (const char *e = getenv("RM_DEBUG_SPLITS")) n_splits = std::max(1, std::min(atoi(e), std::max(1, MAX_PARTS / nsub)));   // A/B timing only
     const int n_part = nsub * n_splits;
     auto lds_need = [&](bool with_lists) { return lds_need_n(with_lists, nsub); };
     const bool list_in_lds = lds_need(true) + 16 <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS");
@@ -351,7 +390,10 @@ void run(const Call<T> &c, hipStream_t stream)
         const long long bp_units = P::items_units(tiles_total, NG, tile_items), ap_units = P::users_units(n_groups, NG);
         typename P::PackT *Bp = (typename P::PackT *)ws.get("Bp", 16 * (size_t)bp_units);
         typename P::PackT *Ap = (typename P::PackT *)ws.get("Ap", 16 * (size_t)ap_units);
-        pack_operands(c.A, c.lda, c.B, c.ldb, n, k, NG, tile_items, slot_user, n_slots, Ap, ap_units, Bp, bp_units, stream);
+        // the packed item image survives between the batches of one host call (same B, same geometry)
+        const bool items_packed = items_known && cx.packed_tile == tile_items && cx.packed_ng == NG && cx.packed_ptr == (const void *)Bp;
+        pack_operands(c.A, c.lda, c.B, c.ldb, n, k, NG, tile_items, slot_user, n_slots, Ap, ap_units, Bp, bp_units, stream, !items_packed);
+        cx.packed_tag = c.items_tag; cx.packed_tile = tile_items; cx.packed_ng = NG; cx.packed_ptr = (const void *)Bp;
 
         // ---- positives ----
         if (want_auc) {
@@ -417,10 +459,12 @@ void run(const Call<T> &c, hipStream_t stream)
             if (j_shallow >= 0) u_split = hp.class_offset[j_shallow + 1] / (GROUPS_PER_BLOCK * GU);
         }
         if (u_split > 0) {
-            if (!g_side_stream) {
-                HIP_CHECK(hipStreamCreateWithFlags(&g_side_stream, hipStreamNonBlocking));
-                for (auto &e : g_side_ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            if (!cx.side_stream) {
+                HIP_CHECK(hipStreamCreateWithFlags(&cx.side_stream, hipStreamNonBlocking));
+                for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&cx.side_ev[i], hipEventDisableTiming));
             }
+            hipStream_t g_side_stream = cx.side_stream;
+            hipEvent_t *g_side_ev = cx.side_ev;
             typename P::Args sb = sa;                              // the deep blocks: lists in HBM, as computed above
             P::set_ublocks(sb, u_split, n_ublocks - u_split);
             typename P::Args sl = sa;                              // the shallow blocks: lists in LDS
@@ -491,7 +535,187 @@ void run(const Call<T> &c, hipStream_t stream)
             HIP_CHECK(hipMemsetAsync(c.pos_rank, 0, sizeof(long long) * (size_t)c.nnz_test, stream));
     }
     HIP_CHECK(hipEventRecord(g_ev[3], stream));
+    HIP_CHECK(hipEventRecord(cx.done, stream));
+    cx.ev_recorded = true;
     HIP_CHECK(hipGetLastError());
+}
+
+
+template <class F> int guarded(F &&f)
+{
+    g_err.clear();
+    try { f(); return RM_OK; }
+    catch (const RmError &e) { g_err = e.msg; return e.code; }
+    catch (const std::bad_alloc &) { g_err = "host allocation failed"; return RM_ERR_NOMEM; }
+    catch (const std::exception &e) { g_err = e.what(); return RM_ERR_HIP; }
+}
+
+// ---- interruption (reference src/recometrics.hpp:114-174: SignalSwitcher) ---------------------------------------------
+// While a host-pointer call runs, SIGINT sets a flag instead of killing the process; the call looks at the flag between its
+// user batches, stops, restores the previous handler, re-raises the signal (so that the caller's own handler -- Python's
+// KeyboardInterrupt -- sees it) and reports the reference's message.  As in the reference only the first of several
+// concurrent calls owns the handler (:141-143).  rm_request_interrupt() sets the same flag without a signal.
+volatile std::sig_atomic_t g_interrupt = 0, g_interrupt_by_signal = 0;
+std::atomic<bool> g_handler_locked{false};
+extern "C" void rm_on_sigint(int) { g_interrupt = 1; g_interrupt_by_signal = 1; }
+struct SignalGuard {
+    void (*old_handler)(int) = nullptr;
+    bool active = false;
+    SignalGuard()
+    {
+        bool expected = false;
+        if (g_handler_locked.compare_exchange_strong(expected, true)) {
+            g_interrupt = 0; g_interrupt_by_signal = 0;
+            old_handler = std::signal(SIGINT, rm_on_sigint);
+            active = true;
+        }
+    }
+    void restore()
+    {
+        if (active) { std::signal(SIGINT, old_handler); active = false; g_handler_locked.store(false); }
+    }
+    ~SignalGuard() { const bool mine = active; restore(); if (mine) { g_interrupt = 0; g_interrupt_by_signal = 0; } }
+    void check()                                  // reference :166-173
+    {
+        if (!g_interrupt) return;
+        const bool by_signal = g_interrupt_by_signal != 0;
+        const bool mine = active;
+        restore();
+        if (mine) { g_interrupt = 0; g_interrupt_by_signal = 0; }
+        if (by_signal && mine) std::raise(SIGINT);
+        throw RmError{RM_ERR_INTERRUPTED, "Error: procedure was interrupted.\n"};
+    }
+};
+
+// devices of the calls sharded inside the library (rm_set_devices); empty = the calling thread's current device only
+std::mutex g_dev_mu;
+std::vector<int> g_devices;
+
+template <class T> struct HostCall {              // one host-pointer call (reference signature, src/recometrics_signatures.hpp:48-98)
+    const T *A; size_t lda; const T *B; size_t ldb; int m, n, k;
+    const int *trp, *tri, *tep, *tei; const T *tev;
+    int K; bool cumulative, noise; T *outs[10]; bool cold; int mip, mpt;
+    int *topk_idx; T *topk_score; long long *pos_rank; int *status;
+};
+
+// item factors of a sharded call: uploaded from the host by shard 0, copied device-to-device (xGMI) by the others
+struct SharedItems {
+    std::mutex mu; std::condition_variable cv;
+    bool ready = false, failed = false;
+    const void *src = nullptr; int src_device = 0;
+};
+
+std::atomic<unsigned long long> g_call_counter{1};
+
+// Users [u0, u1) of a host call on the current device: stage the inputs of the range into HBM, evaluate them in batches
+// small enough to look at the interrupt flag a few times per second, copy each batch's outputs straight into the caller's
+// arrays.  `shared` (sharded calls) says where the item factors come from.
+template <class T>
+void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t stream, SharedItems *shared, int shard, unsigned long long tag)
+{
+    std::lock_guard<std::mutex> lk(cx.mu);
+    Workspace &ws = cx.ws;
+    const int m = u1 - u0, n = h.n, k = h.k, K = h.K;
+    cx.acc[0] = cx.acc[1] = cx.acc[2] = cx.acc[3] = 0; cx.ev_recorded = false;
+    g_last_ctx = &cx;
+    // item factors, dense rows of k
+    T *dB = (T *)ws.get("in_B", sizeof(T) * (size_t)n * k);
+    if (!shared || shard == 0) {
+        hipError_t e = hipMemcpy2DAsync(dB, sizeof(T) * k, h.B, sizeof(T) * h.ldb, sizeof(T) * k, n, hipMemcpyHostToDevice, stream);
+        if (shared) {
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            std::lock_guard<std::mutex> sl(shared->mu);
+            shared->ready = true; shared->failed = e != hipSuccess; shared->src = dB; shared->src_device = cx.device;
+            shared->cv.notify_all();
+        }
+        HIP_CHECK(e);
+    } else {
+        std::unique_lock<std::mutex> sl(shared->mu);
+        shared->cv.wait(sl, [&] { return shared->ready; });
+        if (shared->failed) throw RmError{RM_ERR_HIP, "upload of the item factors failed on the first device"};
+        HIP_CHECK(hipMemcpyPeerAsync(dB, cx.device, shared->src, shared->src_device, sizeof(T) * (size_t)n * k, stream));
+    }
+    if (m <= 0) { HIP_CHECK(hipStreamSynchronize(stream)); return; }
+    // this range's users: factors, CSR rows with the index pointers rebased to the range
+    const long long tr0 = h.trp[u0], te0 = h.tep[u0];
+    const long long nnz_tr = (long long)h.trp[u1] - tr0, nnz_te = (long long)h.tep[u1] - te0;
+    T *dA = (T *)ws.get("in_A", sizeof(T) * (size_t)m * k);
+    HIP_CHECK(hipMemcpy2DAsync(dA, sizeof(T) * k, h.A + (size_t)u0 * h.lda, sizeof(T) * h.lda, sizeof(T) * k, m, hipMemcpyHostToDevice, stream));
+    int *dtrp = (int *)ws.get("in_trp", sizeof(int) * (size_t)(m + 1));
+    int *dtep = (int *)ws.get("in_tep", sizeof(int) * (size_t)(m + 1));
+    int *dtri = (int *)ws.get("in_tri", sizeof(int) * (size_t)std::max<long long>(nnz_tr, 1));
+    int *dtei = (int *)ws.get("in_tei", sizeof(int) * (size_t)std::max<long long>(nnz_te, 1));
+    std::vector<int> rb;                                              // rebased index pointers (only when the range does not start at 0)
+    const int *trp = h.trp + u0, *tep = h.tep + u0;
+    if (tr0 || te0) {
+        rb.resize(2 * (size_t)(m + 1));
+        for (int i = 0; i <= m; i++) { rb[i] = h.trp[u0 + i] - (int)tr0; rb[m + 1 + i] = h.tep[u0 + i] - (int)te0; }
+        trp = rb.data(); tep = rb.data() + m + 1;
+    }
+    HIP_CHECK(hipMemcpyAsync(dtrp, trp, sizeof(int) * (size_t)(m + 1), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(dtep, tep, sizeof(int) * (size_t)(m + 1), hipMemcpyHostToDevice, stream));
+    if (nnz_tr > 0) HIP_CHECK(hipMemcpyAsync(dtri, h.tri + tr0, sizeof(int) * (size_t)nnz_tr, hipMemcpyHostToDevice, stream));
+    if (nnz_te > 0) HIP_CHECK(hipMemcpyAsync(dtei, h.tei + te0, sizeof(int) * (size_t)nnz_te, hipMemcpyHostToDevice, stream));
+    T *dtev = nullptr;
+    if (h.tev) {
+        dtev = (T *)ws.get("in_tev", sizeof(T) * (size_t)std::max<long long>(nnz_te, 1));
+        if (nnz_te > 0) HIP_CHECK(hipMemcpyAsync(dtev, h.tev + te0, sizeof(T) * (size_t)nnz_te, hipMemcpyHostToDevice, stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(stream));                         // `rb` goes out of use; uploads are complete
+    const size_t per = h.cumulative ? (size_t)K : 1;                 // values per user of the eight top-K metrics
+    static const char *onames[10] = {"o_p", "o_tp", "o_r", "o_ap", "o_tap", "o_ndcg", "o_hit", "o_rr", "o_roc", "o_pr"};
+    T *dout[10];
+    for (int i = 0; i < 10; i++) dout[i] = h.outs[i] ? (T *)ws.get(onames[i], sizeof(T) * (size_t)m * (i >= 8 ? 1 : per)) : nullptr;
+    int *d_topk_idx = nullptr, *d_status = nullptr; T *d_topk_score = nullptr; long long *d_pos_rank = nullptr;
+    if (h.topk_idx) {
+        d_topk_idx = (int *)ws.get("o_topk_idx", sizeof(int) * (size_t)m * K);
+        d_topk_score = (T *)ws.get("o_topk_score", sizeof(T) * (size_t)m * K);
+        d_pos_rank = (long long *)ws.get("o_pos_rank", sizeof(long long) * (size_t)std::max<long long>(nnz_te, 1));
+        d_status = (int *)ws.get("o_status", sizeof(int) * (size_t)m);
+    }
+    // batch size: ~0.4 s of device work at the rate the sweep sustains (2 n k flop per user), whole user blocks
+    const double rate = std::is_same<T, float>::value ? 6.0e13 : 2.5e13;
+    double bu = 0.4 * rate / (2.0 * (double)n * (double)k);
+    if (const char *e = getenv("RM_BATCH_USERS")) bu = atof(e);      // tests
+    long long batch = (long long)std::min<double>(std::max(bu, 1024.0), 2.0e9);
+    batch = (batch + 1023) / 1024 * 1024;
+    SignalGuard *sg = nullptr;                                       // the caller's guard polls; here only the flag is read
+    (void)sg;
+    for (long long b0 = 0; b0 < m; b0 += batch) {
+        const int b1 = (int)std::min<long long>(m, b0 + batch), mb = b1 - (int)b0;
+        if (g_interrupt) break;                                      // reference :488-489: the remaining users are skipped
+        Call<T> c{};
+        c.A = dA + (size_t)b0 * k; c.lda = k; c.B = dB; c.ldb = k; c.m = mb; c.n = n; c.k = k;
+        c.train_p = dtrp + b0; c.train_i = dtri; c.nnz_train = nnz_tr;
+        c.test_p = dtep + b0; c.test_i = dtei; c.test_v = dtev; c.nnz_test = nnz_te;
+        c.K = K; c.cumulative = h.cumulative; c.noise = h.noise; c.cold = h.cold; c.min_items_pool = h.mip; c.min_pos_test = h.mpt;
+        for (int i = 0; i < 10; i++) c.out[i] = dout[i] ? dout[i] + (size_t)b0 * (i >= 8 ? 1 : per) : nullptr;
+        if (h.topk_idx) {
+            c.topk_idx = d_topk_idx + (size_t)b0 * K; c.topk_score = d_topk_score + (size_t)b0 * K;
+            c.pos_rank = d_pos_rank; c.status = d_status + b0;
+        }
+        c.items_tag = tag;
+        run<T>(c, stream, cx);
+        for (int i = 0; i < 10; i++) {
+            const size_t w = i >= 8 ? 1 : per;
+            if (h.outs[i]) HIP_CHECK(hipMemcpyAsync(h.outs[i] + ((size_t)u0 + b0) * w, c.out[i], sizeof(T) * (size_t)mb * w, hipMemcpyDeviceToHost, stream));
+        }
+        if (h.topk_idx) {
+            HIP_CHECK(hipMemcpyAsync(h.topk_idx + ((size_t)u0 + b0) * K, c.topk_idx, sizeof(int) * (size_t)mb * K, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(h.topk_score + ((size_t)u0 + b0) * K, c.topk_score, sizeof(T) * (size_t)mb * K, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(h.status + u0 + b0, c.status, sizeof(int) * (size_t)mb, hipMemcpyDeviceToHost, stream));
+            const long long e0 = tep[b0], e1 = tep[b1];             // this batch's test entries (range-relative)
+            if (e1 > e0) HIP_CHECK(hipMemcpyAsync(h.pos_rank + te0 + e0, c.pos_rank + e0, sizeof(long long) * (size_t)(e1 - e0), hipMemcpyDeviceToHost, stream));
+        }
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (b1 < m || b0 > 0) {                                       // more than one batch: add up the stage timings
+            float ta = 0, tb = 0, tc = 0, td = 0;
+            (void)hipEventElapsedTime(&ta, cx.ev[0], cx.ev[1]); (void)hipEventElapsedTime(&tb, cx.ev[1], cx.ev[2]);
+            (void)hipEventElapsedTime(&tc, cx.ev[2], cx.ev[3]); (void)hipEventElapsedTime(&td, cx.ev[0], cx.ev[3]);
+            cx.acc[0] += ta; cx.acc[1] += tb; cx.acc[2] += tc; cx.acc[3] += td;
+            cx.ev_recorded = false;
+        }
+    }
 }
 
 template <class T>
@@ -503,75 +727,55 @@ void validate(const T *A, const T *B, int m, int n, int k, const int *trp, const
     if (lda < (size_t)k || ldb < (size_t)k) throw RmError{RM_ERR_INVALID, "leading dimension smaller than k"};
 }
 
-template <class F> int guarded(F &&f)
-{
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_err.clear();
-    try { f(); return RM_OK; }
-    catch (const RmError &e) { g_err = e.msg; return e.code; }
-    catch (const std::bad_alloc &) { g_err = "host allocation failed"; return RM_ERR_NOMEM; }
-    catch (const std::exception &e) { g_err = e.what(); return RM_ERR_HIP; }
-}
-
-// host-pointer entry: stage inputs into HBM, run, copy the requested outputs back
+// host-pointer entry: one device (the calling thread's current one), or the devices of rm_set_devices with contiguous user
+// ranges [m g / G, m (g + 1) / G), one host thread + stream + workspace per shard, no exchange between the shards
 template <class T>
-void run_host(const T *A, size_t lda, const T *B, size_t ldb, int m, int n, int k,
-              const int *trp, const int *tri, const int *tep, const int *tei, const T *tev,
-              int K, bool cumulative, bool noise, T *const outs[10], bool cold, int mip, int mpt,
-              int *topk_idx, T *topk_score, long long *pos_rank, int *status)
+void run_host(const HostCall<T> &h)
 {
-    validate(A, B, m, n, k, trp, tep, tei, K, lda, ldb);
-    Workspace &ws = workspace();
-    hipStream_t stream = nullptr;
-    const long long nnz_tr = trp[m], nnz_te = tep[m];
-    if (nnz_tr > 0 && !tri) throw RmError{RM_ERR_INVALID, "null train indices"};
-    Call<T> c{};
-    // A and B are copied densely (rows of k), so the device leading dimension is k
-    T *dA = (T *)ws.get("in_A", sizeof(T) * (size_t)m * k);
-    T *dB = (T *)ws.get("in_B", sizeof(T) * (size_t)n * k);
-    HIP_CHECK(hipMemcpy2DAsync(dA, sizeof(T) * k, A, sizeof(T) * lda, sizeof(T) * k, m, hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipMemcpy2DAsync(dB, sizeof(T) * k, B, sizeof(T) * ldb, sizeof(T) * k, n, hipMemcpyHostToDevice, stream));
-    int *dtrp = (int *)ws.get("in_trp", sizeof(int) * (size_t)(m + 1));
-    int *dtep = (int *)ws.get("in_tep", sizeof(int) * (size_t)(m + 1));
-    int *dtri = (int *)ws.get("in_tri", sizeof(int) * (size_t)std::max<long long>(nnz_tr, 1));
-    int *dtei = (int *)ws.get("in_tei", sizeof(int) * (size_t)std::max<long long>(nnz_te, 1));
-    T *dtev = nullptr;
-    HIP_CHECK(hipMemcpyAsync(dtrp, trp, sizeof(int) * (size_t)(m + 1), hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipMemcpyAsync(dtep, tep, sizeof(int) * (size_t)(m + 1), hipMemcpyHostToDevice, stream));
-    if (nnz_tr > 0) HIP_CHECK(hipMemcpyAsync(dtri, tri, sizeof(int) * (size_t)nnz_tr, hipMemcpyHostToDevice, stream));
-    if (nnz_te > 0) HIP_CHECK(hipMemcpyAsync(dtei, tei, sizeof(int) * (size_t)nnz_te, hipMemcpyHostToDevice, stream));
-    if (tev) {
-        dtev = (T *)ws.get("in_tev", sizeof(T) * (size_t)std::max<long long>(nnz_te, 1));
-        if (nnz_te > 0) HIP_CHECK(hipMemcpyAsync(dtev, tev, sizeof(T) * (size_t)nnz_te, hipMemcpyHostToDevice, stream));
+    validate(h.A, h.B, h.m, h.n, h.k, h.trp, h.tep, h.tei, h.K, h.lda, h.ldb);
+    if (h.trp[h.m] > 0 && !h.tri) throw RmError{RM_ERR_INVALID, "null train indices"};
+    if (h.outs[5] && !h.tev) throw RmError{RM_ERR_INVALID, "NDCG requested without test values"};
+    std::vector<int> devs;
+    { std::lock_guard<std::mutex> lk(g_dev_mu); devs = g_devices; }
+    const unsigned long long tag = g_call_counter.fetch_add(1);
+    SignalGuard guard;
+    if (devs.size() <= 1) {
+        int prev = -1;
+        if (devs.size() == 1) { HIP_CHECK(hipGetDevice(&prev)); HIP_CHECK(hipSetDevice(devs[0])); }
+        try { run_host_range<T>(h, 0, h.m, context(0), nullptr, nullptr, 0, tag); }
+        catch (...) { if (prev >= 0) (void)hipSetDevice(prev); throw; }
+        if (prev >= 0) HIP_CHECK(hipSetDevice(prev));
+        guard.check();
+        return;
     }
-    if (outs[5] && !tev) throw RmError{RM_ERR_INVALID, "NDCG requested without test values"};
-    c.A = dA; c.lda = k; c.B = dB; c.ldb = k; c.m = m; c.n = n; c.k = k;
-    c.train_p = dtrp; c.train_i = dtri; c.nnz_train = nnz_tr; c.test_p = dtep; c.test_i = dtei; c.test_v = dtev; c.nnz_test = nnz_te;
-    c.K = K; c.cumulative = cumulative; c.noise = noise; c.cold = cold; c.min_items_pool = mip; c.min_pos_test = mpt;
-    const size_t per = cumulative ? (size_t)m * K : (size_t)m;
-    static const char *onames[10] = {"o_p", "o_tp", "o_r", "o_ap", "o_tap", "o_ndcg", "o_hit", "o_rr", "o_roc", "o_pr"};
-    for (int i = 0; i < 10; i++) {
-        const size_t cnt = i >= 8 ? (size_t)m : per;
-        c.out[i] = outs[i] ? (T *)ws.get(onames[i], sizeof(T) * cnt) : nullptr;
+    const int G = (int)devs.size();
+    SharedItems shared;
+    std::vector<RmError> errs((size_t)G, RmError{RM_OK, ""});
+    std::vector<std::thread> workers;
+    Ctx *first = nullptr;
+    std::mutex first_mu;
+    for (int g = 0; g < G; g++) {
+        workers.emplace_back([&, g] {
+            try {
+                HIP_CHECK(hipSetDevice(devs[g]));
+                Ctx &cx = context(g);
+                if (g == 0) { std::lock_guard<std::mutex> lk(first_mu); first = &cx; }
+                if (!cx.own_stream) HIP_CHECK(hipStreamCreateWithFlags(&cx.own_stream, hipStreamNonBlocking));
+                const int u0 = (int)((long long)h.m * g / G), u1 = (int)((long long)h.m * (g + 1) / G);
+                run_host_range<T>(h, u0, u1, cx, cx.own_stream, &shared, g, tag);
+            } catch (const RmError &e) { errs[g] = e; }
+            catch (const std::bad_alloc &) { errs[g] = RmError{RM_ERR_NOMEM, "host allocation failed"}; }
+            catch (const std::exception &e) { errs[g] = RmError{RM_ERR_HIP, e.what()}; }
+            if (g == 0 && errs[g].code != RM_OK) {                    // never leave the other shards waiting for the item factors
+                std::lock_guard<std::mutex> sl(shared.mu);
+                if (!shared.ready) { shared.ready = true; shared.failed = true; shared.cv.notify_all(); }
+            }
+        });
     }
-    if (topk_idx) {
-        c.topk_idx = (int *)ws.get("o_topk_idx", sizeof(int) * (size_t)m * K);
-        c.topk_score = (T *)ws.get("o_topk_score", sizeof(T) * (size_t)m * K);
-        c.pos_rank = (long long *)ws.get("o_pos_rank", sizeof(long long) * (size_t)std::max<long long>(nnz_te, 1));
-        c.status = (int *)ws.get("o_status", sizeof(int) * (size_t)m);
-    }
-    run<T>(c, stream);
-    for (int i = 0; i < 10; i++) {
-        const size_t cnt = i >= 8 ? (size_t)m : per;
-        if (outs[i]) HIP_CHECK(hipMemcpyAsync(outs[i], c.out[i], sizeof(T) * cnt, hipMemcpyDeviceToHost, stream));
-    }
-    if (topk_idx) {
-        HIP_CHECK(hipMemcpyAsync(topk_idx, c.topk_idx, sizeof(int) * (size_t)m * K, hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipMemcpyAsync(topk_score, c.topk_score, sizeof(T) * (size_t)m * K, hipMemcpyDeviceToHost, stream));
-        if (nnz_te > 0) HIP_CHECK(hipMemcpyAsync(pos_rank, c.pos_rank, sizeof(long long) * (size_t)nnz_te, hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipMemcpyAsync(status, c.status, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, stream));
-    }
-    HIP_CHECK(hipStreamSynchronize(stream));
+    for (auto &w : workers) w.join();
+    g_last_ctx = first;
+    for (int g = 0; g < G; g++) if (errs[g].code != RM_OK) throw RmError{errs[g].code, "device " + std::to_string(devs[g]) + ": " + errs[g].msg};
+    guard.check();
 }
 
 template <class T>
@@ -582,7 +786,10 @@ void debug_scores(const T *A, size_t lda, const T *B, size_t ldb, int m, int n, 
     if (!A || !B || !out || m <= 0 || n <= 0 || k <= 0) throw RmError{RM_ERR_INVALID, "bad argument"};
     const int NG = P::supported_ng(k);
     if (NG < 0) throw RmError{RM_ERR_UNSUPPORTED, P::limit()};
-    Workspace &ws = workspace();
+    Ctx &cx = context(0);
+    std::lock_guard<std::mutex> lk(cx.mu);
+    Workspace &ws = cx.ws;
+    cx.packed_tag = 0;                                       // the packed item image is overwritten below
     hipStream_t stream = nullptr;
     T *dA = (T *)ws.get("in_A", sizeof(T) * (size_t)m * k);
     T *dB = (T *)ws.get("in_B", sizeof(T) * (size_t)n * k);
@@ -631,10 +838,11 @@ extern "C" int rm_calc_metrics_##SUFFIX(                                        
 {                                                                                                                       \
     (void)nthreads; (void)seed;                                                                                         \
     return guarded([&] {                                                                                                \
-        T *outs[10] = {p_at_k, tp_at_k, r_at_k, ap_at_k, tap_at_k, ndcg_at_k, hit_at_k, rr_at_k, roc_auc, pr_auc};      \
-        run_host<T>(A, lda, B, ldb, m, n, k, Xtrain_csr_p, Xtrain_csr_i, Xtest_csr_p, Xtest_csr_i, Xtest_csr,           \
-                    k_metrics, cumulative != 0, break_ties_with_noise != 0, outs, consider_cold_start != 0,             \
-                    min_items_pool, min_pos_test, nullptr, nullptr, nullptr, nullptr);                                  \
+        HostCall<T> h{A, lda, B, ldb, m, n, k, Xtrain_csr_p, Xtrain_csr_i, Xtest_csr_p, Xtest_csr_i, Xtest_csr,         \
+                      k_metrics, cumulative != 0, break_ties_with_noise != 0,                                           \
+                      {p_at_k, tp_at_k, r_at_k, ap_at_k, tap_at_k, ndcg_at_k, hit_at_k, rr_at_k, roc_auc, pr_auc},      \
+                      consider_cold_start != 0, min_items_pool, min_pos_test, nullptr, nullptr, nullptr, nullptr};      \
+        run_host<T>(h);                                                                                                 \
     });                                                                                                                 \
 }                                                                                                                       \
 extern "C" int rm_calc_metrics_dev_##SUFFIX(                                                                            \
@@ -658,7 +866,10 @@ extern "C" int rm_calc_metrics_dev_##SUFFIX(                                    
         T *outs[10] = {p_at_k, tp_at_k, r_at_k, ap_at_k, tap_at_k, ndcg_at_k, hit_at_k, rr_at_k, roc_auc, pr_auc};      \
         for (int i = 0; i < 10; i++) c.out[i] = outs[i];                                                                \
         c.cold = consider_cold_start != 0; c.min_items_pool = min_items_pool; c.min_pos_test = min_pos_test;            \
-        run<T>(c, (hipStream_t)stream);                                                                                 \
+        Ctx &cx = context(0);                                                                                           \
+        std::lock_guard<std::mutex> lk(cx.mu);                                                                          \
+        cx.acc[0] = cx.acc[1] = cx.acc[2] = cx.acc[3] = 0;                                                              \
+        run<T>(c, (hipStream_t)stream, cx);                                                                             \
     });                                                                                                                 \
 }                                                                                                                       \
 extern "C" int rm_rank_##SUFFIX(                                                                                        \
@@ -671,10 +882,12 @@ extern "C" int rm_rank_##SUFFIX(                                                
     return guarded([&] {                                                                                                \
         if (!topk_idx || !topk_score || !pos_rank || !status) throw RmError{RM_ERR_INVALID, "null output pointer"};     \
         std::vector<T> ap((size_t)std::max(m, 1)), roc((size_t)std::max(m, 1)), pr((size_t)std::max(m, 1));             \
-        T *outs[10] = {nullptr, nullptr, nullptr, ap.data(), nullptr, nullptr, nullptr, nullptr, roc.data(), pr.data()};\
-        run_host<T>(A, lda, B, ldb, m, n, k, Xtrain_csr_p, Xtrain_csr_i, Xtest_csr_p, Xtest_csr_i, (const T *)nullptr,  \
-                    k_metrics, false, break_ties_with_noise != 0, outs, consider_cold_start != 0,                       \
-                    min_items_pool, min_pos_test, topk_idx, topk_score, (long long *)pos_rank, status);                 \
+        HostCall<T> h{A, lda, B, ldb, m, n, k, Xtrain_csr_p, Xtrain_csr_i, Xtest_csr_p, Xtest_csr_i, (const T *)nullptr,\
+                      k_metrics, false, break_ties_with_noise != 0,                                                     \
+                      {nullptr, nullptr, nullptr, ap.data(), nullptr, nullptr, nullptr, nullptr, roc.data(), pr.data()},\
+                      consider_cold_start != 0, min_items_pool, min_pos_test,                                           \
+                      topk_idx, topk_score, (long long *)pos_rank, status};                                             \
+        run_host<T>(h);                                                                                                 \
     });                                                                                                                 \
 }
 
@@ -707,22 +920,59 @@ extern "C" int rm_set_device(int device)
     return guarded([&] { HIP_CHECK(hipSetDevice(device)); });
 }
 
+extern "C" int rm_set_devices(const int32_t *devices, int32_t n)
+{
+    return guarded([&] {
+        if (n < 0 || (n > 0 && !devices)) throw RmError{RM_ERR_INVALID, "bad device list"};
+        int count = 0;
+        HIP_CHECK(hipGetDeviceCount(&count));
+        std::vector<int> v;
+        for (int i = 0; i < n; i++) {
+            if (devices[i] < 0 || devices[i] >= count) throw RmError{RM_ERR_INVALID, "device " + std::to_string(devices[i]) + " does not exist (" + std::to_string(count) + " visible)"};
+            v.push_back(devices[i]);
+        }
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        g_devices = v;
+    });
+}
+
+extern "C" int rm_get_devices(int32_t *devices, int32_t cap)
+{
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    for (int i = 0; i < (int)g_devices.size() && i < cap; i++) devices[i] = g_devices[i];
+    return (int)g_devices.size();
+}
+
+extern "C" void rm_request_interrupt(void) { g_interrupt = 1; }
+
 extern "C" int rm_get_timings(double *out, int n)
 {
-    if (!out || n <= 0 || !g_ev_valid) return 0;
-    if (hipEventSynchronize(g_ev[3]) != hipSuccess) return 0;
+    Ctx *cx = g_last_ctx;
+    if (!out || n <= 0 || !cx || !cx->ev_valid) return 0;
     float a = 0, b = 0, c = 0, d = 0;
-    (void)hipEventElapsedTime(&a, g_ev[0], g_ev[1]);
-    (void)hipEventElapsedTime(&b, g_ev[1], g_ev[2]);
-    (void)hipEventElapsedTime(&c, g_ev[2], g_ev[3]);
-    (void)hipEventElapsedTime(&d, g_ev[0], g_ev[3]);
-    g_timings[0] = a; g_timings[1] = b; g_timings[2] = c; g_timings[3] = d;
+    if (cx->ev_recorded) {
+        if (hipEventSynchronize(cx->ev[3]) != hipSuccess) return 0;
+        (void)hipEventElapsedTime(&a, cx->ev[0], cx->ev[1]);
+        (void)hipEventElapsedTime(&b, cx->ev[1], cx->ev[2]);
+        (void)hipEventElapsedTime(&c, cx->ev[2], cx->ev[3]);
+        (void)hipEventElapsedTime(&d, cx->ev[0], cx->ev[3]);
+    }
+    cx->timings[0] = cx->acc[0] + a; cx->timings[1] = cx->acc[1] + b; cx->timings[2] = cx->acc[2] + c; cx->timings[3] = cx->acc[3] + d;
     const int cnt = n < 8 ? n : 8;
-    for (int i = 0; i < cnt; i++) out[i] = g_timings[i];
+    for (int i = 0; i < cnt; i++) out[i] = cx->timings[i];
     return cnt;
 }
 
 extern "C" int rm_release_workspace(void)
 {
-    return guarded([&] { workspace().release(); });
+    return guarded([&] {
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        for (auto &kv : g_ctx) if (kv.first.first == dev) {
+            std::lock_guard<std::mutex> cl(kv.second->mu);
+            kv.second->ws.release();
+            kv.second->packed_tag = 0;
+        }
+    });
 }

@@ -1,0 +1,203 @@
+"""GPU tests of what sits around the kernels: sharding inside the library (rm_set_devices), the torch.distributed helper
+with the HIP binding as its compute, interruption between user batches, calls from several threads.
+
+One MI355X is visible on the test box, so the in-library shards are VIRTUAL (the same device listed several times: every
+shard has its own host thread, stream and workspace, exactly as on distinct devices)."""
+import os
+import signal
+import subprocess
+import sys
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from _util import assert_same_bits
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ALL = {name: True for name in ("p", "tp", "r", "ap", "tap", "ndcg", "hit", "rr", "roc", "pr")}
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from recometrics_amd import _binding
+    _binding.load()
+    assert _binding.device_count() > 0, "no HIP device visible"
+    return _binding
+
+
+def _calc(hip, pr, K, cumulative=False, dtype=np.float32, outs=None):
+    trp, tri = pr["train"]
+    tep, tei, tev = pr["test"]
+    return hip.calc_metrics(np.ascontiguousarray(pr["A"], dtype), pr["A"].shape[1], np.ascontiguousarray(pr["B"], dtype), pr["B"].shape[1],
+                            trp, tri, tep, tei, tev.astype(dtype), K, ALL, cumulative, False, True, 2, 1, 1, 1, outs=outs)
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], [0]])
+@pytest.mark.parametrize("dtype,cumulative", [(np.float32, False), (np.float32, True), (np.float64, False)])
+def test_in_library_shards_equal_the_single_device_call(hip, devices, dtype, cumulative):
+    """rm_set_devices: users sharded inside one call (uneven ranges: 1,003 users over 2 and 3 shards), every output
+    bit-identical to the unsharded call; the ranking outputs of rm_rank_* too"""
+    from recometrics_amd.synth import make_problem
+    pr = make_problem(1003, 6000, 48, dtype, mean_c=70, seed=12)
+    hip.set_devices([])
+    want = _calc(hip, pr, 10, cumulative, dtype)
+    want_rank = hip.rank(pr["A"], pr["B"], pr["train"][0], pr["train"][1], pr["test"][0], pr["test"][1], 10)
+    try:
+        hip.set_devices(devices)
+        assert hip.get_devices() == devices
+        got = _calc(hip, pr, 10, cumulative, dtype)
+        got_rank = hip.rank(pr["A"], pr["B"], pr["train"][0], pr["train"][1], pr["test"][0], pr["test"][1], 10)
+    finally:
+        hip.set_devices([])
+    for name, g, w in zip(hip.METRIC_ORDER, got, want):
+        assert_same_bits(g, w, "%s over devices %s" % (name, devices))
+    for key in want_rank:
+        assert (got_rank[key] == want_rank[key]).all() or key == "topk_score", key
+    assert_same_bits(got_rank["topk_score"], want_rank["topk_score"], "top-K scores")
+
+
+def test_set_devices_rejects_unknown_devices(hip):
+    with pytest.raises(ValueError, match="does not exist"):
+        hip.set_devices([0, 99])
+    assert hip.get_devices() == []
+
+
+def test_user_batches_equal_one_batch(hip, monkeypatch):
+    """host-pointer calls evaluate their users in batches (so that an interrupt is seen within a fraction of a second);
+    the batch size must not change any result (RM_BATCH_USERS forces many small batches)"""
+    from recometrics_amd.synth import make_problem
+    pr = make_problem(5000, 3000, 32, np.float32, mean_c=120, seed=4)
+    want = _calc(hip, pr, 7, True)
+    monkeypatch.setenv("RM_BATCH_USERS", "1024")
+    got = _calc(hip, pr, 7, True)
+    for name, g, w in zip(hip.METRIC_ORDER, got, want):
+        assert_same_bits(g, w, name + " in batches of 1024 users")
+    rk = hip.rank(pr["A"], pr["B"], pr["train"][0], pr["train"][1], pr["test"][0], pr["test"][1], 7)
+    monkeypatch.delenv("RM_BATCH_USERS")
+    rk1 = hip.rank(pr["A"], pr["B"], pr["train"][0], pr["train"][1], pr["test"][0], pr["test"][1], 7)
+    for key in rk:
+        assert (rk[key] == rk1[key]).all() or key == "topk_score", key
+
+
+def _interruptible_problem():
+    from recometrics_amd.synth import make_problem
+    return make_problem(40 * 1024, 20000, 64, np.float32, mean_c=40, seed=8)
+
+
+def test_interrupt_between_batches(hip, monkeypatch):
+    """reference src/recometrics.hpp:114-174,:488-489,:964: an interrupt stops the evaluation (the remaining users are
+    skipped), the call fails with "Error: procedure was interrupted.", what was finished is intact"""
+    pr = _interruptible_problem()
+    m = pr["A"].shape[0]
+    full = _calc(hip, pr, 10)
+    monkeypatch.setenv("RM_BATCH_USERS", "1024")
+    outs = [np.full(m, -7.0, np.float32) for _ in range(10)]
+    t = threading.Timer(0.05, hip.request_interrupt)
+    t.start()
+    with pytest.raises(RuntimeError, match="procedure was interrupted"):
+        _calc(hip, pr, 10, outs=outs)
+    t.join()
+    done = int((outs[0] != -7.0).sum() if not np.isnan(outs[0]).any() else (~(outs[0] == -7.0)).sum())
+    assert 1024 <= done < m and done % 1024 == 0, "finished users: %d of %d" % (done, m)
+    for name, g, w in zip(hip.METRIC_ORDER, outs, full):
+        assert_same_bits(g[:done], w[:done], name + " of the users finished before the interrupt")
+        assert (g[done:] == -7.0).all(), name + ": users after the interrupt must be untouched"
+    # the flag is cleared: the next call runs to the end
+    again = _calc(hip, pr, 10)
+    for name, g, w in zip(hip.METRIC_ORDER, again, full):
+        assert_same_bits(g, w, name + " after an interrupted call")
+
+
+def test_sigint_during_a_call_becomes_keyboard_interrupt(hip, monkeypatch):
+    """a real SIGINT: the library's handler takes it during the call, then restores Python's handler and re-raises the
+    signal, so that the caller sees KeyboardInterrupt (reference :166-173 + recometrics/wrapper.pyx `except +`)"""
+    pr = _interruptible_problem()
+    monkeypatch.setenv("RM_BATCH_USERS", "1024")
+    before = signal.getsignal(signal.SIGINT)
+    t = threading.Timer(0.05, lambda: os.kill(os.getpid(), signal.SIGINT))
+    t.start()
+    with pytest.raises((KeyboardInterrupt, RuntimeError)) as ei:
+        _calc(hip, pr, 10)
+        time.sleep(0.5)            # (the pending KeyboardInterrupt surfaces here if the call itself returned an error first)
+    t.join()
+    assert ei.type is KeyboardInterrupt or "interrupted" in str(ei.value)
+    assert signal.getsignal(signal.SIGINT) is before, "the caller's SIGINT handler must be back in place"
+
+
+def test_calls_from_two_threads_share_a_device(hip):
+    """two host threads calling at the same time on one device: each call has the context (workspace, events) to itself
+    while it runs -- results equal the sequential ones"""
+    from recometrics_amd.synth import make_problem
+    prs = [make_problem(3000, 4000, 24, np.float32, mean_c=60, seed=s) for s in (1, 2)]
+    want = [_calc(hip, pr, 10) for pr in prs]
+    got = [None, None]
+
+    def work(i):
+        for _ in range(3):
+            got[i] = _calc(hip, prs[i], 10)
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [th.start() for th in ths]
+    [th.join() for th in ths]
+    for i in range(2):
+        for name, g, w in zip(hip.METRIC_ORDER, got[i], want[i]):
+            assert_same_bits(g, w, "thread %d %s" % (i, name))
+
+
+def test_set_device_on_two_devices_from_one_thread(hip):
+    if hip.device_count() < 2:
+        pytest.skip("one device visible")
+    from recometrics_amd.synth import make_problem
+    pr = make_problem(500, 3000, 16, np.float32, mean_c=40, seed=3)
+    hip.set_device(0)
+    want = _calc(hip, pr, 5)
+    hip.set_device(1)
+    got = _calc(hip, pr, 5)
+    hip.set_device(0)
+    for name, g, w in zip(hip.METRIC_ORDER, got, want):
+        assert_same_bits(g, w, name + " on device 1")
+
+
+_RANK_SCRIPT = r"""
+import os, sys, numpy as np
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from recometrics_amd import _binding as hip
+from recometrics_amd.sharding import calc_metrics_sharded
+from recometrics_amd.synth import make_problem
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+hip.load(); hip.set_device(0)                      # both ranks share GPU 0 (one device on the test box)
+pr = make_problem(777, 5000, 32, np.float32, mean_c=50, seed=5)
+names = {"p": "P@K", "tp": "TP@K", "r": "R@K", "ap": "AP@K", "tap": "TAP@K", "ndcg": "NDCG@K", "hit": "Hit@K", "rr": "RR@K", "roc": "ROC_AUC", "pr": "PR_AUC"}
+def compute(A, B, train, test, k, want, **kw):
+    outs = hip.calc_metrics(np.ascontiguousarray(A), A.shape[1], B, B.shape[1], train[0], train[1], test[0], test[1], test[2], k,
+                            {n: True for n in hip.METRIC_ORDER}, False, False, True, 2, 1, 1, 1)
+    return {names[n]: o for n, o in zip(hip.METRIC_ORDER, outs)}
+full = calc_metrics_sharded(pr["A"], pr["B"], pr["train"], pr["test"], 10, None, compute, world, rank, dist=dist)
+if rank == 0:
+    np.savez(%(out)r, **full)
+dist.destroy_process_group()
+"""
+
+
+def test_torch_distributed_helper_with_the_hip_binding(hip, tmp_path):
+    """recometrics_amd.sharding.calc_metrics_sharded (one process per GPU, one all-gather of the metric block) with the
+    HIP binding as its compute: two gloo ranks sharing GPU 0 == the single-process call"""
+    from recometrics_amd.synth import make_problem
+    out = str(tmp_path / "sharded.npz")
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT % {"root": ROOT, "out": out})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    got = np.load(out)
+    pr = make_problem(777, 5000, 32, np.float32, mean_c=50, seed=5)
+    want = _calc(hip, pr, 10)
+    names = {"p": "P@K", "tp": "TP@K", "r": "R@K", "ap": "AP@K", "tap": "TAP@K", "ndcg": "NDCG@K", "hit": "Hit@K", "rr": "RR@K", "roc": "ROC_AUC", "pr": "PR_AUC"}
+    for n, w in zip(hip.METRIC_ORDER, want):
+        assert_same_bits(got[names[n]].astype(np.float32), w, "sharded over 2 ranks: " + names[n])
