@@ -38,7 +38,9 @@ enum : int { LM_LDS = 0, LM_HBM = 1, LM_HBM_APPEND = 2 };
 constexpr int WAIT_VMCNT0 = 0x0F70;
 
 // per-user flags written by k_classify
-enum : int { UF_NAN = 1, UF_ONLY_NDCG = 2, UF_KLEQN = 4, UF_ACTIVE = 8 };
+// UF_SKIP: the user is not part of this pass at all (second pass of a noise call: only the flagged users are re-evaluated);
+// nothing of it is read or written
+enum : int { UF_NAN = 1, UF_ONLY_NDCG = 2, UF_KLEQN = 4, UF_ACTIVE = 8, UF_SKIP = 16 };
 
 // which outputs the caller asked for (NULL pointer == not requested, reference recometrics.hpp:370-379)
 enum : int { RQ_P = 1, RQ_TP = 2, RQ_R = 4, RQ_AP = 8, RQ_TAP = 16, RQ_NDCG = 32, RQ_HIT = 64, RQ_RR = 128, RQ_ROC = 256, RQ_PR = 512 };
@@ -67,6 +69,7 @@ struct Plan {                                     // produced on device, read ba
     int n_stream_chunks;    // chunks of POS_CHUNK test entries over all streamed users (work items of the positives kernels)
     int nonfinite;                      // some factor of A is NaN / Inf
     int nonfinite_b;                    // some factor of B is NaN / Inf
+    int n_noise_flagged;                // fp32 + noise, first pass: users whose ranking the noise can change (rm_noise.hpp)
     int n_heavy;                        // evaluated users with more than HEAVY_NPOS test items (listed by k_classify)
     unsigned long long amax_a, amax_b;  // bit patterns of max|A|, max|B| as doubles (non-negative doubles order like u64)
 };

@@ -38,6 +38,7 @@ template <class T, class S> struct FinalArgs {     // T = real_t of inputs/outpu
     const S *stream_scores; long long stream_ld;     // [n_stream][stream_ld] masked candidate scores written by the sweep
     const S *spos_score; const int *spos_item;       // [nnz_test] sorted positives of those users at test_p[u] + rank
     unsigned *shist;             // [nnz_test] at test_p[u] + j: candidates ranking above positive j but not above positive j + 1
+    int *noise_flag; Plan *plan; // first pass of an fp32 noise call: flag the users with a top-K score the noise can change
 };
 
 template <class T> __device__ __forceinline__ T qnan();
@@ -388,6 +389,11 @@ __global__ void k_finalize(FinalArgs<T, S> a)
         fill_user_nan(a, u); return;
     }
     if (a.status) a.status[u] = 0;
+    if (a.noise_flag) {
+        bool zone = false;
+        for (int i = 0; i < W; i++) { const S x = M[i].s; zone |= (x < (S)0 ? -x : x) < (S)6.103515625e-05f; }
+        if (zone && atomicExch(&a.noise_flag[u], 1) == 0) atomicAdd(&a.plan->n_noise_flagged, 1);
+    }
 #if defined(RM_ABL_FIN_STOP) && RM_ABL_FIN_STOP == 1
     return;
 #endif

@@ -36,6 +36,8 @@ struct SweepArgs {
     int stream_slot0;
     long long stream_ld;                  // row stride in elements (= tiles_total * items per tile)
     float *stream_scores;
+    // tie noise (rm_noise.hpp): noise_E[row of the lane's user][item] is added to every score after the validity scan
+    const int *noise_row; int noise_row0; const float *noise_E; long long noise_ld;
 };
 
 struct Sweep64Args {
@@ -63,6 +65,7 @@ struct Sweep64Args {
     int stream_slot0;                     // streamed users: see SweepArgs
     long long stream_ld;
     double *stream_scores;
+    const int *noise_row; int noise_row0; const double *noise_E; long long noise_ld;     // tie noise: see SweepArgs
 };
 
 // return 0 = launched, -1 = unsupported factor-group count, otherwise a hipError_t

@@ -26,6 +26,7 @@
 #include "rm_prep.hpp"
 #include "rm_launch.hpp"
 #include "rm_finalize.hpp"
+#include "rm_noise.hpp"
 
 namespace {
 
@@ -113,6 +114,12 @@ template <class T> struct Call {          // one calc_metrics call; every pointe
     // batches of one host call share the item factors: a non-zero tag says "the packed image and the |B| bound made for this
     // tag are still valid" (set by run_host_range; 0 = always repack)
     unsigned long long items_tag;
+    // tie noise (rm_noise.hpp)
+    unsigned long long seed; long long user0;      // the engine of local user u is seeded with seed + user0 + u
+    const unsigned char *only_users;               // optional [m]: evaluate only these users, leave the others' outputs alone
+    const int *noise_row; int noise_row0;          // row of each user in noise_E (null: row = user)
+    const T *noise_E; long long noise_ld;          // per-item noise rows; null = scores as they are
+    int *noise_flag;                               // optional [m] out (fp32 first pass): users the noise can change
 };
 
 inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
@@ -124,22 +131,22 @@ template <class T> __global__ void k_iota(T *p, int count)
 }
 
 template <class S>
-__global__ void k_export_rank(int m, int K, const Entry<S> *merged, int *topk_idx, S *topk_score)
+__global__ void k_export_rank(int m, int K, const Entry<S> *merged, int *topk_idx, S *topk_score, const int *flags)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)m * K) return;
+    if (i >= (long long)m * K || (flags[i / K] & UF_SKIP)) return;
     topk_idx[i] = merged[i].idx;
     topk_score[i] = merged[i].s;
 }
 
 __global__ void k_export_pos_rank(long long nnz, int m, const int *test_p, const int *flags, const int *pos_order,
-                                  const long long *rank_sorted, long long *pos_rank)
+                                  const long long *rank_sorted, long long *pos_rank, int have_ranks)
 {
     // one thread per user row (rows are short).  Users that were never ranked (skipped, or NDCG-only) have no entry in
     // pos_order -- whatever the workspace held before -- and report rank 0.
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= m) return;
-    const bool ranked = (flags[u] & UF_ACTIVE) && !(flags[u] & UF_ONLY_NDCG);
+    if (u >= m || (flags[u] & UF_SKIP)) return;
+    const bool ranked = have_ranks && (flags[u] & UF_ACTIVE) && !(flags[u] & UF_ONLY_NDCG);
     for (int e = test_p[u]; e < test_p[u + 1]; e++) pos_rank[e] = ranked ? rank_sorted[test_p[u] + pos_order[e]] : 0;
 }
 
@@ -251,6 +258,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     int *heavy_users = (int *)ws.get("heavy_users", sizeof(int) * (size_t)m);
     ClassifyArgs ca{m, n, K, c.train_p, c.test_p, req, c.cold ? 1 : 0, min_items_pool, min_pos_test, want_auc ? 1 : 0,
                     flags, user_nslots, heavy_users, plan};
+    ca.only = c.only_users;
     // Users with more than POS_CHUNK test items are "streamed" (rm_device.hpp STREAM_CLASS) when a score row for each of
     // them fits the HBM budget: a third of the free memory unless RM_STREAM_BUDGET_MB says otherwise (0 = never; such
     // users then take one sweep slot per chunk of their test row -- same results, the contraction repeated per chunk).
@@ -261,7 +269,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         else { size_t fr = 0, tot = 0; HIP_CHECK(hipMemGetInfo(&fr, &tot)); budget = (long long)(fr / 3); }
         const long long cap = budget / (stream_ld_max * (long long)sizeof(T));
         if (cap > 0) {
-            hipLaunchKernelGGL(k_count_long, dim3(cdiv(m, 1024)), dim3(1024), 0, stream, m, c.test_p, plan);
+            hipLaunchKernelGGL(k_count_long, dim3(cdiv(m, 1024)), dim3(1024), 0, stream, m, c.test_p, plan, c.only_users);
             hipLaunchKernelGGL(k_decide_stream, dim3(1), dim3(1), 0, stream, plan, cap);
         }
     }
@@ -407,6 +415,8 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(unsigned) * (size_t)rows * GU, stream));
             PosArgs<T> pa{m, n, k, c.A, c.lda, c.B, c.ldb, c.train_p, c.train_i, c.test_p, c.test_i,
                           flags, user_nslots, uslot_base, slot_index, grow, pos_tmp, pos_order, pos_score, pos_item, GU};
+            pa.noise_row = c.noise_row; pa.noise_row0 = c.noise_row0; pa.noise_E = c.noise_E; pa.noise_ld = c.noise_ld;
+            pa.noise_flag = c.noise_flag; pa.plan = plan;
             if (stream_slot0 > 0) {
                 hipLaunchKernelGGL(k_pos_scores<T>, dim3(cdiv(stream_slot0, POSS_WAVES)), dim3(POSS_WAVES * WAVE), 0, stream, pa, slot_user, slot_chunk, stream_slot0);
                 hipLaunchKernelGGL(k_pos_place<T>, dim3(cdiv((long long)stream_slot0 * WAVE, 256)), dim3(256), 0, stream, pa, slot_user, slot_chunk, stream_slot0);
@@ -447,6 +457,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         P::set_pending(sa, pend_cap, (int)pend_off);
         P::set_sync(sa, (int)sync_off);
         sa.stream_slot0 = stream_slot0; sa.stream_ld = stream_ld; sa.stream_scores = stream_scores;
+        sa.noise_row = c.noise_row; sa.noise_row0 = c.noise_row0; sa.noise_E = c.noise_E; sa.noise_ld = c.noise_ld;
 
         HIP_CHECK(hipEventRecord(g_ev[1], stream));
         // Depth split: when only the deepest user blocks force the lists out of LDS (the allocation is sized per launch,
@@ -501,6 +512,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     fa.p = c.out[0]; fa.tp = c.out[1]; fa.r = c.out[2]; fa.ap = c.out[3]; fa.tap = c.out[4];
     fa.ndcg = c.out[5]; fa.hit = c.out[6]; fa.rr = c.out[7]; fa.roc = c.out[8]; fa.pr = c.out[9];
     fa.merged = merged; fa.rank_sorted = rank_sorted; fa.status = c.status;
+    fa.noise_flag = c.noise_flag; fa.plan = plan;
     fa.n_slots = n_slots; fa.slot_user = slot_user; fa.slot_chunk = slot_chunk;
     hipLaunchKernelGGL((k_finalize_skipped<T, T>), dim3(cdiv(m, 256)), dim3(256), 0, stream, fa);
     if (fa.ndcg && hp.n_heavy > 0) {                            // ideal-DCG values of the users with very long test rows
@@ -527,19 +539,88 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     }
     HIP_CHECK(hipGetLastError());
     if (c.topk_idx)
-        hipLaunchKernelGGL(k_export_rank<T>, dim3(cdiv((long long)m * K, 256)), dim3(256), 0, stream, m, K, merged, c.topk_idx, c.topk_score);
-    if (c.pos_rank) {
-        if (want_auc && n_slots > 0)
-            hipLaunchKernelGGL(k_export_pos_rank, dim3(cdiv(m, 128)), dim3(128), 0, stream, c.nnz_test, m, c.test_p, flags, pos_order, rank_sorted, c.pos_rank);
-        else
-            HIP_CHECK(hipMemsetAsync(c.pos_rank, 0, sizeof(long long) * (size_t)c.nnz_test, stream));
-    }
+        hipLaunchKernelGGL(k_export_rank<T>, dim3(cdiv((long long)m * K, 256)), dim3(256), 0, stream, m, K, merged, c.topk_idx, c.topk_score, flags);
+    if (c.pos_rank)           // (per user, never a memset of the whole array: a batch must not clear what other batches wrote)
+        hipLaunchKernelGGL(k_export_pos_rank, dim3(cdiv(m, 128)), dim3(128), 0, stream, c.nnz_test, m, c.test_p, flags, pos_order, rank_sorted, c.pos_rank,
+                           (want_auc && n_slots > 0) ? 1 : 0);
     HIP_CHECK(hipEventRecord(g_ev[3], stream));
     HIP_CHECK(hipEventRecord(cx.done, stream));
     cx.ev_recorded = true;
     HIP_CHECK(hipGetLastError());
 }
 
+
+// ---- tie noise on top of run() (rm_noise.hpp) ---------------------------------------------------------------------------
+// fp64: the noise (|e| <= 1e-12) is far above an ulp of any ordinary score, every score changes: every user is evaluated
+// with its noise row, in user batches whose rows (draws + noise values, 2 x 8 n bytes per user) fit the memory budget.
+// fp32: the noise only changes scores below 2^-15 in magnitude; a first pass evaluates everybody on the plain scores and
+// flags the users who have such a score among their test items or their top-K -- the only ones whose ranking the noise
+// can touch -- and only those are evaluated again, exactly.
+template <class T>
+void run_call(const Call<T> &c0, hipStream_t stream, Ctx &cx)
+{
+    if (!c0.noise || getenv("RM_NOISE_OFF")) { run<T>(c0, stream, cx); return; }     // RM_NOISE_OFF: A/B timing only
+    Workspace &ws = cx.ws;
+    const int m = c0.m, n = c0.n;
+    const int per = sizeof(T) == 4 ? 1 : 2;
+    const long long e_ld = ((long long)n + 191) / 192 * 192;                      // covers either tile size of the sweep
+    const long long d_ld = ((long long)n * per + MT_N - 1) / MT_N * MT_N;
+    const long long row_bytes = e_ld * (long long)sizeof(T) + d_ld * 4;
+    long long budget;
+    if (const char *e = getenv("RM_NOISE_BUDGET_MB")) budget = atoll(e) << 20;
+    else { size_t fr = 0, tot = 0; HIP_CHECK(hipMemGetInfo(&fr, &tot)); budget = (long long)(fr / 3); }
+    const long long cap = std::max<long long>(1, std::min<long long>(budget / row_bytes, 1 << 20));
+    auto make_rows = [&](const int *row_user, int rows, const int *train_p, long long user0, unsigned *&D, T *&E) {
+        D = (unsigned *)ws.get("noise_draws", sizeof(unsigned) * (size_t)rows * (size_t)d_ld);
+        E = (T *)ws.get("noise_rows", sizeof(T) * (size_t)rows * (size_t)e_ld);
+        hipLaunchKernelGGL(k_mt_draws, dim3(cdiv(rows, MT_WAVES)), dim3(MT_WAVES * WAVE), 0, stream, row_user, rows, c0.seed, user0,
+                           train_p, n, per, D, d_ld);
+        hipLaunchKernelGGL(k_noise_rows<T>, dim3(cdiv((long long)rows * e_ld, 256)), dim3(256), 0, stream, row_user, rows, train_p, c0.train_i, n,
+                           D, d_ld, E, e_ld);
+    };
+    if (sizeof(T) == 8) {
+        const long long width = c0.cumulative ? c0.K : 1;
+        for (long long b0 = 0; b0 < m; b0 += cap) {
+            const int mb = (int)std::min<long long>(cap, m - b0);
+            Call<T> c = c0;
+            c.A = c0.A + (size_t)b0 * c0.lda; c.m = mb; c.train_p = c0.train_p + b0; c.test_p = c0.test_p + b0; c.user0 = c0.user0 + b0;
+            for (int i = 0; i < 10; i++) if (c0.out[i]) c.out[i] = c0.out[i] + (size_t)b0 * (i >= 8 ? 1 : width);
+            if (c0.topk_idx) { c.topk_idx = c0.topk_idx + (size_t)b0 * c0.K; c.topk_score = c0.topk_score + (size_t)b0 * c0.K; c.status = c0.status + b0; }
+            if (c0.only_users) c.only_users = c0.only_users + b0;
+            unsigned *D; T *E;
+            make_rows(nullptr, mb, c.train_p, c.user0, D, E);
+            c.noise_E = E; c.noise_ld = e_ld; c.noise_row = nullptr; c.noise_row0 = 0;
+            run<T>(c, stream, cx);
+        }
+        return;
+    }
+    int *flag = (int *)ws.get("noise_flag", sizeof(int) * (size_t)m);
+    HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int) * (size_t)m, stream));
+    Call<T> c1 = c0;
+    c1.noise_flag = flag;
+    run<T>(c1, stream, cx);
+    Plan *plan = (Plan *)ws.get("plan", sizeof(Plan));
+    int n_flagged = 0;
+    HIP_CHECK(hipMemcpyAsync(&n_flagged, &plan->n_noise_flagged, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    cx.timings[4] = 0;                                              // (reported below: users evaluated exactly)
+    if (n_flagged <= 0) return;
+    int *noise_row = (int *)ws.get("noise_row", sizeof(int) * (size_t)m);
+    int *row_user = (int *)ws.get("noise_row_user", sizeof(int) * (size_t)n_flagged);
+    int *counter = (int *)ws.get("noise_counter", sizeof(int));
+    unsigned char *only = (unsigned char *)ws.get("noise_only", (size_t)m);
+    HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(k_noise_assign_rows, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, flag, noise_row, row_user, counter);
+    for (long long r0 = 0; r0 < n_flagged; r0 += cap) {
+        const int rows = (int)std::min<long long>(cap, n_flagged - r0);
+        hipLaunchKernelGGL(k_noise_select, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, noise_row, (int)r0, (int)r0 + rows, only);
+        unsigned *D; T *E;
+        make_rows(row_user + r0, rows, c0.train_p, c0.user0, D, E);
+        Call<T> c = c0;
+        c.only_users = only; c.noise_row = noise_row; c.noise_row0 = (int)r0; c.noise_E = E; c.noise_ld = e_ld; c.noise_flag = nullptr;
+        run<T>(c, stream, cx);
+    }
+}
 
 template <class F> int guarded(F &&f)
 {
@@ -596,6 +677,7 @@ template <class T> struct HostCall {              // one host-pointer call (refe
     const int *trp, *tri, *tep, *tei; const T *tev;
     int K; bool cumulative, noise; T *outs[10]; bool cold; int mip, mpt;
     int *topk_idx; T *topk_score; long long *pos_rank; int *status;
+    unsigned long long seed;
 };
 
 // item factors of a sharded call: uploaded from the host by shard 0, copied device-to-device (xGMI) by the others
@@ -695,7 +777,8 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
             c.pos_rank = d_pos_rank; c.status = d_status + b0;
         }
         c.items_tag = tag;
-        run<T>(c, stream, cx);
+        c.seed = h.seed; c.user0 = (long long)u0 + b0;
+        run_call<T>(c, stream, cx);
         for (int i = 0; i < 10; i++) {
             const size_t w = i >= 8 ? 1 : per;
             if (h.outs[i]) HIP_CHECK(hipMemcpyAsync(h.outs[i] + ((size_t)u0 + b0) * w, c.out[i], sizeof(T) * (size_t)mb * w, hipMemcpyDeviceToHost, stream));
@@ -836,12 +919,12 @@ extern "C" int rm_calc_metrics_##SUFFIX(                                        
     T *roc_auc, T *pr_auc, int consider_cold_start, int32_t min_items_pool, int32_t min_pos_test,                       \
     int32_t nthreads, uint64_t seed)                                                                                    \
 {                                                                                                                       \
-    (void)nthreads; (void)seed;                                                                                         \
+    (void)nthreads;                                                                                                     \
     return guarded([&] {                                                                                                \
         HostCall<T> h{A, lda, B, ldb, m, n, k, Xtrain_csr_p, Xtrain_csr_i, Xtest_csr_p, Xtest_csr_i, Xtest_csr,         \
                       k_metrics, cumulative != 0, break_ties_with_noise != 0,                                           \
                       {p_at_k, tp_at_k, r_at_k, ap_at_k, tap_at_k, ndcg_at_k, hit_at_k, rr_at_k, roc_auc, pr_auc},      \
-                      consider_cold_start != 0, min_items_pool, min_pos_test, nullptr, nullptr, nullptr, nullptr};      \
+                      consider_cold_start != 0, min_items_pool, min_pos_test, nullptr, nullptr, nullptr, nullptr, seed};\
         run_host<T>(h);                                                                                                 \
     });                                                                                                                 \
 }                                                                                                                       \
@@ -854,7 +937,6 @@ extern "C" int rm_calc_metrics_dev_##SUFFIX(                                    
     T *roc_auc, T *pr_auc, int consider_cold_start, int32_t min_items_pool, int32_t min_pos_test,                       \
     uint64_t seed, void *stream)                                                                                        \
 {                                                                                                                       \
-    (void)seed;                                                                                                         \
     return guarded([&] {                                                                                                \
         validate(A, B, m, n, k, Xtrain_csr_p, Xtest_csr_p, Xtest_csr_i, k_metrics, lda, ldb);                           \
         if (ndcg_at_k && !Xtest_csr) throw RmError{RM_ERR_INVALID, "NDCG requested without test values"};               \
@@ -869,7 +951,8 @@ extern "C" int rm_calc_metrics_dev_##SUFFIX(                                    
         Ctx &cx = context(0);                                                                                           \
         std::lock_guard<std::mutex> lk(cx.mu);                                                                          \
         cx.acc[0] = cx.acc[1] = cx.acc[2] = cx.acc[3] = 0;                                                              \
-        run<T>(c, (hipStream_t)stream, cx);                                                                             \
+        c.seed = seed; c.user0 = 0;                                                                                     \
+        run_call<T>(c, (hipStream_t)stream, cx);                                                                             \
     });                                                                                                                 \
 }                                                                                                                       \
 extern "C" int rm_rank_##SUFFIX(                                                                                        \
@@ -878,7 +961,6 @@ extern "C" int rm_rank_##SUFFIX(                                                
     int32_t k_metrics, int break_ties_with_noise, int consider_cold_start, int32_t min_items_pool,                      \
     int32_t min_pos_test, uint64_t seed, int32_t *topk_idx, T *topk_score, int64_t *pos_rank, int32_t *status)          \
 {                                                                                                                       \
-    (void)seed;                                                                                                         \
     return guarded([&] {                                                                                                \
         if (!topk_idx || !topk_score || !pos_rank || !status) throw RmError{RM_ERR_INVALID, "null output pointer"};     \
         std::vector<T> ap((size_t)std::max(m, 1)), roc((size_t)std::max(m, 1)), pr((size_t)std::max(m, 1));             \
@@ -886,7 +968,7 @@ extern "C" int rm_rank_##SUFFIX(                                                
                       k_metrics, false, break_ties_with_noise != 0,                                                     \
                       {nullptr, nullptr, nullptr, ap.data(), nullptr, nullptr, nullptr, nullptr, roc.data(), pr.data()},\
                       consider_cold_start != 0, min_items_pool, min_pos_test,                                           \
-                      topk_idx, topk_score, (long long *)pos_rank, status};                                             \
+                      topk_idx, topk_score, (long long *)pos_rank, status, seed};                                       \
         run_host<T>(h);                                                                                                 \
     });                                                                                                                 \
 }

@@ -18,6 +18,7 @@ struct ClassifyArgs {
     int *user_nslots;        // [m]
     int *heavy_users;        // [m] list of the evaluated users with more than HEAVY_NPOS test items (plan->n_heavy of them)
     Plan *plan;
+    const unsigned char *only;   // optional [m]: evaluate only the users with a non-zero entry (the others: UF_SKIP)
 };
 
 __device__ __forceinline__ int chunk_depth(int pc)      // smallest j with 2^j - 1 >= pc   (pc in 1..63)
@@ -27,10 +28,10 @@ __device__ __forceinline__ int chunk_depth(int pc)      // smallest j with 2^j -
 
 // users with more than POS_CHUNK test items (an upper bound of the streamed class: eligibility is not looked at), and the
 // decision whether their score rows fit the HBM budget (`cap` rows)
-__global__ void k_count_long(int m, const int *test_p, Plan *plan)
+__global__ void k_count_long(int m, const int *test_p, Plan *plan, const unsigned char *only)
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    const int npos = u < m ? test_p[u + 1] - test_p[u] : 0;
+    const int npos = (u < m && !(only && !only[u])) ? test_p[u + 1] - test_p[u] : 0;
     const bool lng = npos > POS_CHUNK;
     const unsigned long long mk = __ballot(lng);
     if (mk && (threadIdx.x & 63) == __ffsll((long long)mk) - 1) atomicAdd(&plan->n_long, __popcll(mk));
@@ -42,7 +43,9 @@ __global__ void k_decide_stream(Plan *plan, long long cap) { plan->stream_enable
 __global__ void k_classify(ClassifyArgs a)
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = u < a.m;
+    const bool skip = u < a.m && a.only && !a.only[u];
+    const bool live = u < a.m && !skip;
+    if (skip) { a.flags[u] = UF_SKIP; a.user_nslots[u] = 0; }
     const int ntr = live ? a.train_p[u + 1] - a.train_p[u] : 0;
     const int npos = live ? a.test_p[u + 1] - a.test_p[u] : 0;
     const int cand = a.n - ntr;
@@ -406,6 +409,10 @@ template <class T> struct PosArgs {
     int *pos_item;       // same shape: item id of each sorted positive (tie resolution)
     int gu;              // users per group
     // streamed users (work list = their chunks): the sorted positives go to contiguous rows instead of group tables
+    // tie noise (rm_noise.hpp): per-item noise rows added to the positives' scores; first pass of an fp32 noise call: flag
+    // the users with a test item inside the zone the noise can change
+    const int *noise_row; int noise_row0; const T *noise_E; long long noise_ld;
+    int *noise_flag; Plan *plan;
     int stream;          // 1 = the work list is the streamed users' chunk list
     T *spos_score;       // [nnz_test] at test_p[u] + rank: scores ascending, order (score asc, item desc)
     int *spos_item;      // [nnz_test] their item ids
@@ -467,6 +474,13 @@ __global__ __launch_bounds__(POSS_WAVES * WAVE) void k_pos_scores(PosArgs<T> a, 
         }
         const int kc = min(CH, a.k - k0);
         for (int t = 0; t < kc; t++) s = fma_chain_step(lane_bcast<T>(av, t), rows[wv][mine ? lane : 0][t], s);
+    }
+    if (mine && !masked && a.noise_E) {
+        const long long nr = a.noise_row ? a.noise_row[u] - a.noise_row0 : u;
+        s += a.noise_E[(size_t)nr * (size_t)a.noise_ld + item];
+    }
+    if (mine && !masked && a.noise_flag && (s < (T)0 ? -s : s) < (T)6.103515625e-05f) {
+        if (atomicExch(&a.noise_flag[u], 1) == 0) atomicAdd(&a.plan->n_noise_flagged, 1);
     }
     if (mine) a.pos_tmp[e] = masked ? (T)__int_as_float(0x7f800000) : s;
 }

@@ -323,6 +323,9 @@ void k_sweep(SweepArgs a)
     const bool stream_lane = AUC && slot_ok && slot >= a.stream_slot0;
     const bool wave_streams = AUC && __any(stream_lane);
     float *stream_row = stream_lane ? a.stream_scores + (size_t)(slot - a.stream_slot0) * (size_t)a.stream_ld : nullptr;
+    // tie noise (rm_noise.hpp), exact passes only: the lane's user's row of per-item noise values
+    const float *noise_lane = (a.noise_E && user >= 0)
+        ? a.noise_E + (size_t)(a.noise_row ? a.noise_row[user] - a.noise_row0 : user) * (size_t)a.noise_ld : nullptr;
 
     // ---- staging: packed tile (BUF_F4 float4, contiguous) HBM -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging
     // registers, the wave never waits for the bytes before the end-of-step barrier.  One wave-instruction moves 1 KiB
@@ -433,12 +436,25 @@ void k_sweep(SweepArgs a)
 #ifndef RM_ABL_NO_STATS
         // (2) min / max over candidates (NaN-ignoring, so the sentinel is invisible) (:519-524): v_max3 / v_min3 trees
         // (the maxima of the four register quads are kept: the top-K path below skips a whole quad with one test)
-        const float qmax[4] = {hw_max3(v[0], v[1], hw_max(v[2], v[3])), hw_max3(v[4], v[5], hw_max(v[6], v[7])),
-                               hw_max3(v[8], v[9], hw_max(v[10], v[11])), hw_max3(v[12], v[13], hw_max(v[14], v[15]))};
-        const float tmax = hw_max3(qmax[0], qmax[1], hw_max(qmax[2], qmax[3]));
+        float qmax[4] = {hw_max3(v[0], v[1], hw_max(v[2], v[3])), hw_max3(v[4], v[5], hw_max(v[6], v[7])),
+                         hw_max3(v[8], v[9], hw_max(v[10], v[11])), hw_max3(v[12], v[13], hw_max(v[14], v[15]))};
+        float tmax = hw_max3(qmax[0], qmax[1], hw_max(qmax[2], qmax[3]));
         const float tmin = hw_min3(hw_min3(v[0], v[1], v[2]), hw_min3(v[3], v[4], v[5]), hw_min3(v[6], v[7], v[8]));
         const float tmin2 = hw_min3(hw_min3(v[9], v[10], v[11]), hw_min3(v[12], v[13], v[14]), v[15]);
         vmax = hw_max(vmax, tmax); vmin = hw_min3(vmin, tmin, tmin2);
+        // tie noise (reference :531-534: added AFTER the validity scan, in real_t): wave-uniform branch, exact passes only
+        if (a.noise_E) {
+            if (noise_lane) {
+                #pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) {
+                    const float4 e = *(const float4 *)(noise_lane + sb + 8 * q4 + 4 * h);
+                    v[4 * q4] += e.x; v[4 * q4 + 1] += e.y; v[4 * q4 + 2] += e.z; v[4 * q4 + 3] += e.w;
+                }
+            }
+            #pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) qmax[q4] = hw_max3(v[4 * q4], v[4 * q4 + 1], hw_max(v[4 * q4 + 2], v[4 * q4 + 3]));
+            tmax = hw_max3(qmax[0], qmax[1], hw_max(qmax[2], qmax[3]));
+        }
 #endif
 #ifndef RM_ABL_NO_TOPK
         // (3) streaming top-K: anything at or above the user's current K-th best is offered to the list (:537-540).

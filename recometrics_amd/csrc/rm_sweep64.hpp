@@ -215,6 +215,9 @@ void k_sweep64(Sweep64Args a)
     const bool stream_lane = AUC && slot_ok && slot >= a.stream_slot0;
     const bool wave_streams = AUC && __any(stream_lane);
     double *stream_row = stream_lane ? a.stream_scores + (size_t)(slot - a.stream_slot0) * (size_t)a.stream_ld : nullptr;
+    // tie noise (rm_noise.hpp): the lane's user's row of per-item noise values
+    const double *noise_lane = (a.noise_E && user >= 0)
+        ? a.noise_E + (size_t)(a.noise_row ? a.noise_row[user] - a.noise_row0 : user) * (size_t)a.noise_ld : nullptr;
 
     // unit u = (tile, chunk): contiguous BUF_D2 double2 of the packed image [tile][g][q][row][2]
     auto stage = [&](int tile, int chunk, int buf) {
@@ -271,6 +274,11 @@ void k_sweep64(Sweep64Args a)
         }
         #pragma unroll
         for (int r = 0; r < 8; r++) { vmax = __builtin_fmax(vmax, v[r]); vmin = __builtin_fmin(vmin, v[r]); }
+        // tie noise (reference :531-534: added AFTER the validity scan, in real_t)
+        if (a.noise_E && noise_lane) {
+            #pragma unroll
+            for (int r = 0; r < 8; r++) v[r] += noise_lane[sb + (r >> 2) * 16 + q + 4 * (r & 3)];
+        }
         if (primary && thr_seen > thr_pub) { thr_pub = thr_seen; const double t = ord_unkey(thr_seen); thr = t > thr ? t : thr; }
         unsigned long long cm = 0;
         #pragma unroll

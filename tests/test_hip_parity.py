@@ -95,6 +95,11 @@ def test_golden_fixtures(hip, case):
         for name in expected:
             g, w = _skip_user_with_nan_test_value(case, name, got[name], expected[name], inp)
             assert_close(g, w, TOL, "%s v%d %s %s" % (case, vi, kw, name))
+            # break_ties_with_noise=True: the reference's mt19937(seed + user) noise is reproduced bit for bit, so what it
+            # decides -- top-K membership and order, the rank of every test item -- is the reference's (ROC-AUC apart:
+            # x87 long double there)
+            if kw.get("noise") and name != "ROC_AUC" and case.startswith(("g9_", "g6_", "g4_")):
+                assert_same_bits(g, w, "%s v%d %s %s (bitwise, noise on)" % (case, vi, kw, name))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -196,6 +201,38 @@ def test_long_test_rows_streamed_or_chunked(hip, oracle, dtype, budget, monkeypa
             assert_same_bits(got[name], ref[name], "budget too small == never stream: " + name)
     else:
         _check_against_oracle(hip, oracle, pr, 10, dtype=dtype)
+
+
+@pytest.mark.parametrize("dtype,budget", [(np.float32, None), (np.float64, None), (np.float32, "1"), (np.float64, "1")])
+def test_tie_noise_rankings_equal_the_oracle(hip, oracle, dtype, budget, monkeypatch):
+    """break_ties_with_noise=True (the API default): ordered top-K lists, the rank of every test item and all metrics equal
+    the oracle's, which draws from std::mt19937 / std::uniform_real_distribution themselves (and is pinned on the
+    reference's own noise-on outputs, tests/golden/g9_noise_*).  15 % cold items (all-zero factors): blocks of exactly tied
+    scores that only the noise orders.  budget = 1 MB: the noise rows are made in several batches."""
+    from recometrics_amd.synth import make_problem
+    if budget is not None:
+        monkeypatch.setenv("RM_NOISE_BUDGET_MB", budget)
+    pr = make_problem(300, 5000, 20, dtype, mean_c=80, seed=41)
+    rng = np.random.default_rng(5)
+    pr["B"] = pr["B"].copy()
+    pr["B"][rng.random(5000) < 0.15] = 0
+    seed = 2 ** 33 + 5
+    want_rank = oracle.rank(pr["A"], pr["B"], pr["train"], pr["test"], 10, dtype=dtype, nthreads=NT, noise=True, seed=seed)
+    trp, tri = pr["train"]
+    tep, tei = pr["test"][:2]
+    got_rank = hip.rank(np.ascontiguousarray(pr["A"], dtype), np.ascontiguousarray(pr["B"], dtype), trp, tri, tep, tei, 10,
+                        break_ties_with_noise=True, seed=seed)
+    assert (got_rank["status"] == want_rank["status"]).all()
+    assert (got_rank["topk_idx"] == want_rank["topk_idx"]).all(), "top-K index lists differ"
+    assert_same_bits(got_rank["topk_score"], want_rank["topk_score"], "top-K scores (with their noise)")
+    assert (got_rank["pos_rank"] == want_rank["pos_rank"]).all(), "positive ranks differ"
+    for cumulative in (False, True):
+        want = oracle.calc(pr["A"], pr["B"], pr["train"], pr["test"], 10, cumulative=cumulative, dtype=dtype, nthreads=NT, noise=True, seed=seed)
+        got = hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], 10, cumulative=cumulative, dtype=dtype, noise=True, seed=seed)
+        for name in want:
+            assert_close(got[name], want[name], TOL, name)
+            if name != "ROC_AUC":
+                assert_same_bits(got[name], want[name], "%s cumulative=%s (bitwise, noise on)" % (name, cumulative))
 
 
 def test_rank_outputs_do_not_depend_on_the_previous_call(hip, oracle):
