@@ -38,6 +38,9 @@ template <class T, class S> struct FinalArgs {     // T = real_t of inputs/outpu
     const S *stream_scores; long long stream_ld;     // [n_stream][stream_ld] masked candidate scores written by the sweep
     const S *spos_score; const int *spos_item;       // [nnz_test] sorted positives of those users at test_p[u] + rank
     unsigned *shist;             // [nnz_test] at test_p[u] + j: candidates ranking above positive j but not above positive j + 1
+    // top-K lists longer than the sweep keeps (k_metrics > 256): EVERY user is streamed and k_select_topk picks its top-K
+    // from the stored row straight into `merged`
+    int ext_topk; unsigned long long *sel_hi; unsigned *sel_lo; int sel_ld;      // scratch [n_slots][sel_ld] (sel_ld = power of two >= K)
     int *noise_flag; Plan *plan; // first pass of an fp32 noise call: flag the users with a top-K score the noise can change
 };
 
@@ -174,6 +177,7 @@ __global__ __launch_bounds__(STREAM_RANK_THREADS) void k_rank_streamed(FinalArgs
     const int d = blockIdx.x / parts, part = blockIdx.x % parts;
     const int slot = a.stream_slot0 + d;
     const int u = a.slot_user[slot];
+    if (a.flags[u] & UF_ONLY_NDCG) return;                            // (only when every user is streamed: no ranks wanted)
     const int te0 = a.test_p[u], P = a.test_p[u + 1] - te0;
     constexpr int WORDS = STREAM_RANK_LDS / 4;
     constexpr int per = (int)sizeof(S) / 4;                       // LDS words per score
@@ -213,6 +217,112 @@ __global__ __launch_bounds__(STREAM_RANK_THREADS) void k_rank_streamed(FinalArgs
     }
 }
 
+// ---- top-K of a stored score row (k_metrics beyond what the sweep's lists hold) ---------------------------------------------
+// Block per user.  Order everywhere: (score desc, item asc).  The K-th best score is found by a radix select over the
+// order-preserving integer keys of the row (8 bits per pass, most significant first), the entries above it are gathered in any
+// order, those EQUAL to it in item order until K are together, and the K entries are sorted by a block-wide bitonic network
+// (in global scratch: K is unbounded; padded to a power of two with keys below every real one).
+template <class S> struct SelKey;
+template <> struct SelKey<float> { typedef unsigned T; static constexpr int BITS = 32; };
+template <> struct SelKey<double> { typedef unsigned long long T; static constexpr int BITS = 64; };
+constexpr int SELECT_THREADS = 256;
+
+template <class T, class S>
+__global__ __launch_bounds__(SELECT_THREADS) void k_select_topk(FinalArgs<T, S> a)
+{
+    typedef typename SelKey<S>::T KeyT;
+    constexpr int BITS = SelKey<S>::BITS;
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long sh_prefix;
+    __shared__ int sh_remaining, sh_gt, sh_wsum[SELECT_THREADS / WAVE], sh_taken;
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = a.stream_slot0 + row;
+    const int u = a.slot_user[slot];
+    const int n = a.n, K = a.K;
+    const int C = n - (a.train_p[u + 1] - a.train_p[u]);
+    const int W = K < C ? K : C;                                   // entries to produce (the row may hold NaN scores: then fewer exist)
+    const S *sc = a.stream_scores + (size_t)row * (size_t)a.stream_ld;
+    Entry<S> *M = a.merged + (size_t)u * K;
+    unsigned long long *hi = a.sel_hi + (size_t)row * a.sel_ld;
+    unsigned *lo = a.sel_lo + (size_t)row * a.sel_ld;
+    if (tid == 0) { sh_prefix = 0ull; sh_remaining = W; }
+    // ---- radix select: key of the W-th best score ----
+    for (int pass = 0; pass < BITS / 8; pass++) {
+        const int shift = BITS - 8 * (pass + 1);
+        hist[tid] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = sh_prefix;
+        for (int i = tid; i < n; i += SELECT_THREADS) {
+            const S x = sc[i];
+            if (x != x) continue;                                    // masked by the train row / NaN score
+            const KeyT key = ord_key(x);
+            if (pass == 0 || (unsigned long long)(key >> (shift + 8)) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int rem = sh_remaining, b = 255;
+            unsigned long long total = 0;
+            for (int q = 0; q < 256; q++) total += hist[q];
+            if (total < (unsigned long long)rem) rem = (int)total;  // fewer real scores than W (only at the first pass)
+            for (; b > 0; b--) { if ((int)hist[b] >= rem) break; rem -= (int)hist[b]; }
+            sh_remaining = rem; sh_prefix = (prefix << 8) | (unsigned long long)b;
+        }
+        __syncthreads();
+    }
+    const KeyT T0 = (KeyT)sh_prefix;
+    const int need_eq = sh_remaining;                                 // entries wanted among the scores equal to the W-th best
+    // (how many exist in all: recount -- cheap, and it makes W_real exact when the row has fewer real scores than W)
+    if (tid == 0) { sh_gt = 0; sh_taken = 0; }
+    __syncthreads();
+    // ---- gather: key > T0 anywhere, key == T0 in item order ----
+    for (int base = 0; base < n; base += SELECT_THREADS) {
+        const int i = base + tid;
+        const S x = i < n ? sc[i] : (S)NAN;
+        const bool real = x == x;
+        const KeyT key = real ? ord_key(x) : (KeyT)0;
+        const bool gt = real && key > T0, eq = real && key == T0;
+        if (gt) { const int at = atomicAdd(&sh_gt, 1); hi[need_eq + at] = (unsigned long long)key; lo[need_eq + at] = ~(unsigned)i; }
+        const unsigned long long em = __ballot(eq);
+        if (lane == 0) sh_wsum[wave] = __popcll(em);
+        __syncthreads();
+        int before = sh_taken;
+        for (int w = 0; w < wave; w++) before += sh_wsum[w];
+        const int my = before + __popcll(em & ((1ull << lane) - 1ull));
+        if (eq && my < need_eq) { hi[my] = (unsigned long long)key; lo[my] = ~(unsigned)i; }
+        __syncthreads();
+        if (tid == 0) { int t = sh_taken; for (int w = 0; w < SELECT_THREADS / WAVE; w++) t += sh_wsum[w]; sh_taken = t; }
+        __syncthreads();
+    }
+    const int got = min(need_eq, sh_taken) + sh_gt;                   // == W unless the row has fewer real scores
+    // the equal-keyed entries sit at [0, need_eq) and the larger ones behind them: close the gap when fewer equals exist
+    // (cannot happen: need_eq <= number of equals by construction), pad to the power of two, sort
+    for (int i = got + tid; i < a.sel_ld; i += SELECT_THREADS) { hi[i] = 0ull; lo[i] = 0u; }
+    __syncthreads();
+    int Kp = 2;
+    while (Kp < got) Kp <<= 1;
+    for (int k2 = 2; k2 <= Kp; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int idx = tid; idx < Kp; idx += SELECT_THREADS) {
+                const int l = idx ^ j;
+                if (l > idx) {
+                    const unsigned long long ha = hi[idx], hb = hi[l];
+                    const unsigned la = lo[idx], lb = lo[l];
+                    const bool a_lt_b = ha < hb || (ha == hb && la < lb);
+                    const bool desc = (idx & k2) == 0;
+                    if (desc ? a_lt_b : !a_lt_b && !(ha == hb && la == lb)) { hi[idx] = hb; hi[l] = ha; lo[idx] = lb; lo[l] = la; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < K; i += SELECT_THREADS) {
+        Entry<S> e;
+        if (i < got) { e.s = ord_unkey((KeyT)hi[i]); e.idx = (int)~lo[i]; }
+        else { e.s = (S)qnan<float>(); e.idx = -1; }
+        M[i] = e;
+    }
+}
+
 // One wavefront per streamed user: ranks of its positives from the counts above (descending walk), the ROC ingredients,
 // and the PR-AUC sum in the reference's own order -- left to right over the positives by descending score (:795-865) --
 // so that PR-AUC is bit-identical for these users whatever the length of the row.
@@ -223,6 +333,7 @@ __global__ void k_auc_streamed(FinalArgs<T, S> a, int n_stream)
     if (w >= n_stream) return;
     const int slot = a.stream_slot0 + w;
     const int u = a.slot_user[slot];
+    if (a.flags[u] & UF_ONLY_NDCG) return;
     const int te0 = a.test_p[u], P = a.test_p[u + 1] - te0;
     unsigned long long above = 0, sum_ranks = 0;
     double s2 = 0;
@@ -341,7 +452,7 @@ __global__ void k_finalize(FinalArgs<T, S> a)
     const int te0 = a.test_p[u], npos = a.test_p[u + 1] - te0;
     if (a.status) a.status[u] = 1;
     Entry<S> *M = a.merged + (size_t)u * K;
-    for (int i = 0; i < K; i++) { M[i].s = (S)qnan<float>(); M[i].idx = -1; }
+    if (!a.ext_topk) for (int i = 0; i < K; i++) { M[i].s = (S)qnan<float>(); M[i].idx = -1; }
 
     const int ntr = a.train_p[u + 1] - a.train_p[u];
     const int C = n - ntr;
@@ -361,7 +472,7 @@ __global__ void k_finalize(FinalArgs<T, S> a)
         any_nan |= ps.has_nan != 0;
     }
     const Entry<S> *PL = a.pl + (size_t)s0 * NP * K;
-    for (int i = 0; i < K; i++) {
+    for (int i = 0; i < (a.ext_topk ? 0 : K); i++) {            // (ext_topk: k_select_topk has written M already)
         int best = -1; Entry<S> be; be.s = 0; be.idx = 0;
         for (int q = 0; q < NP; q++) {
             const int hq = head[q * FIN_THREADS];

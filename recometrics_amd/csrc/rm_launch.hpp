@@ -11,6 +11,8 @@ constexpr int GROUP_USERS64 = 16;      // users on the lanes of one wavefront in
 
 struct SweepArgs {
     int n, K;
+    int ngt;                              // factor groups of 8 when the kernel takes them at run time (more than 512 factors)
+    int ext_topk;                         // 1 = no top-K lists here: every lane streams its scores, k_select_topk picks the top-K
     int n_slots, n_groups, n_ublocks;     // n_ublocks = user blocks of THIS launch (ceil(n_groups / 4) when there is one)
     int ublock0;                          // first user block of this launch (depth-split calls launch twice)
     int n_splits, tiles_total;            // item splits (grid = n_ublocks * n_splits)
@@ -42,6 +44,8 @@ struct SweepArgs {
 
 struct Sweep64Args {
     int n, K;
+    int ngt;                              // factor groups of 8 when the kernel takes them at run time (more than 512 factors)
+    int ext_topk;                         // 1 = no top-K lists here: every lane streams its scores, k_select_topk picks the top-K
     int n_slots, n_groups, n_ublocks;     // n_ublocks = user blocks of THIS launch
     int ublock0;                          // first user block of this launch (depth-split calls launch twice)
     int n_splits, tiles_total;

@@ -155,8 +155,9 @@ template <class T> struct Prec;
 template <> struct Prec<float> {
     static constexpr int GU = GROUP_USERS;               // users per group
     typedef float4 PackT;  typedef u32x2 ListT;  typedef SweepArgs Args;
-    static int supported_ng(int k) { const int ng = (k + 7) / 8; for (int o : {2, 4, 8, 16, 32, 64}) if (ng <= o) return o; return -1; }
-    static const char *limit() { return "the fp32 path supports up to 512 factors"; }
+    // factor groups of 8: the instantiated counts up to 512 factors, beyond that whole 128-factor chunks (run-time count)
+    static int supported_ng(int k) { const int ng = (k + 7) / 8; for (int o : {2, 4, 8, 16, 32, 64}) if (ng <= o) return o; return (ng + 15) / 16 * 16; }
+    static const char *limit() { return "unsupported factor count"; }
     static size_t lds_b(int NG, int tile = TILE_ITEMS) { return 2ull * std::min(NG, 16) * 2 * tile * 16; }
     static long long items_units(int tiles, int NG, int tile = TILE_ITEMS) { return (long long)tiles * NG * 2 * tile; }
     static long long users_units(int groups, int NG) { return (long long)groups * NG * 2 * GU; }
@@ -172,8 +173,8 @@ template <> struct Prec<float> {
 template <> struct Prec<double> {
     static constexpr int GU = GROUP_USERS64;
     typedef double2 PackT;  typedef u32x4 ListT;  typedef Sweep64Args Args;
-    static int supported_ng(int k) { const int ng = (k + 7) / 8; for (int o : {2, 4, 8, 16, 32, 64}) if (ng <= o) return o; return -1; }
-    static const char *limit() { return "the fp64 path supports up to 512 factors"; }
+    static int supported_ng(int k) { const int ng = (k + 7) / 8; for (int o : {2, 4, 8, 16, 32, 64}) if (ng <= o) return o; return (ng + 7) / 8 * 8; }
+    static const char *limit() { return "unsupported factor count"; }
     static size_t lds_b(int NG, int = TILE_ITEMS) { return 2ull * std::min(NG, 8) * 4 * TILE_ITEMS * 16; }
     static long long items_units(int tiles, int NG, int = TILE_ITEMS) { return (long long)tiles * NG * 4 * TILE_ITEMS; }
     static long long users_units(int groups, int NG) { return (long long)groups * NG * 4 * GU; }
@@ -263,12 +264,19 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     // them fits the HBM budget: a third of the free memory unless RM_STREAM_BUDGET_MB says otherwise (0 = never; such
     // users then take one sweep slot per chunk of their test row -- same results, the contraction repeated per chunk).
     const long long stream_ld_max = ((long long)n + 191) / 192 * 192;             // row stride for either tile size (64 / 96 items)
-    if (want_auc) {
+    // k_metrics beyond the sweep's lists (append buffers + wave compaction reach 256): every user is streamed and
+    // k_select_topk picks its top-K from the stored row -- any k_metrics <= n, at one score row of HBM per user
+    const bool ext_topk = K > 256 || getenv("RM_DEBUG_EXT_TOPK") != nullptr;
+    if (want_auc || ext_topk) {
         long long budget;
         if (const char *e = getenv("RM_STREAM_BUDGET_MB")) budget = atoll(e) << 20;
         else { size_t fr = 0, tot = 0; HIP_CHECK(hipMemGetInfo(&fr, &tot)); budget = (long long)(fr / 3); }
         const long long cap = budget / (stream_ld_max * (long long)sizeof(T));
-        if (cap > 0) {
+        if (ext_topk) {
+            if (m > cap) throw RmError{RM_ERR_NOMEM, "k_metrics > 256 keeps one score row (" + std::to_string(stream_ld_max * (long long)sizeof(T)) +
+                                       " B) per user in device memory: " + std::to_string(m) + " users do not fit, at most " + std::to_string(cap) + " per call"};
+            ca.force_stream = 1;
+        } else if (cap > 0) {
             hipLaunchKernelGGL(k_count_long, dim3(cdiv(m, 1024)), dim3(1024), 0, stream, m, c.test_p, plan, c.only_users);
             hipLaunchKernelGGL(k_decide_stream, dim3(1), dim3(1), 0, stream, plan, cap);
         }
@@ -295,7 +303,8 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     long long *grow = (long long *)ws.get("grow", sizeof(long long) * (size_t)group_bound);
     int *sc_user = (int *)ws.get("sc_user", sizeof(int) * (size_t)slot_bound);
     int *sc_chunk = (int *)ws.get("sc_chunk", sizeof(int) * (size_t)slot_bound);
-    AssignArgs aa{m, c.test_p, flags, user_nslots, uslot_base, want_auc ? 1 : 0, plan, slot_user, slot_chunk, slot_index, slot_j, sc_user, sc_chunk};
+    AssignArgs aa{m, c.test_p, flags, user_nslots, uslot_base, want_auc ? 1 : 0, plan, slot_user, slot_chunk, slot_index, slot_j, sc_user, sc_chunk,
+                  ext_topk ? 1 : 0};
     hipLaunchKernelGGL(k_assign_slots, dim3(cdiv(m, ASSIGN_THREADS)), dim3(ASSIGN_THREADS), 0, stream, aa);
     const long long block_bound = group_bound / GROUPS_PER_BLOCK + 2;
     int *blk_j = (int *)ws.get("blk_j", sizeof(int) * (size_t)block_bound);
@@ -321,7 +330,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     const int n_slots = hp.n_slots, n_groups = hp.n_groups;
     const int jmax = want_auc ? hp.jmax : 0;
     // streamed users own the last slots; the tables and their kernels cover slots [0, stream_slot0)
-    const int n_stream = want_auc ? hp.class_count[STREAM_CLASS] : 0;
+    const int n_stream = (want_auc || ext_topk) ? hp.class_count[STREAM_CLASS] : 0;
     const int stream_slot0 = n_stream > 0 ? hp.class_offset[STREAM_CLASS] : n_slots;
     // |any partial sum| <= k * max|A| * max|B|: if that is comfortably finite in T, no score is NaN / Inf
     if (items_known) { hp.amax_b = cx.packed_amax_b; hp.nonfinite_b = cx.packed_nonfinite_b; }
@@ -343,7 +352,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         return want_auc ? (head + tb - 1) / tb * tb + (size_t)GROUPS_PER_BLOCK * (1 << j) * GU * (sizeof(T) + 4) : head;
     };
     auto lds_need_n = [&](bool with_lists, int ns) { return lds_need_j(with_lists, ns, jmax); };
-    if (P::max_nsub >= 3 && NG <= 8 && lds_need_n(true, 3) + 16 <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS") && !getenv("RM_DEBUG_NSUB2"))
+    if (!ext_topk && P::max_nsub >= 3 && NG <= 8 && lds_need_n(true, 3) + 16 <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS") && !getenv("RM_DEBUG_NSUB2"))
         nsub = 3;
     const int tile_items = 32 * nsub, n_waves = 4 * nsub;
     const int tiles_total = (n + tile_items - 1) / tile_items;
@@ -364,11 +373,11 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     if (const char *e = getenv("RM_DEBUG_SPLITS")) n_splits = std::max(1, std::min(atoi(e), std::max(1, MAX_PARTS / nsub)));   // A/B timing only
     const int n_part = nsub * n_splits;
     auto lds_need = [&](bool with_lists) { return lds_need_n(with_lists, nsub); };
-    const bool list_in_lds = lds_need(true) + 16 <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS");
+    const bool list_in_lds = !ext_topk && lds_need(true) + 16 <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS");
     size_t lds_total = lds_need(list_in_lds);
     // per-lane pending buffers for top-K candidates behind everything else when 2..8 keys per lane still fit
     // (fp32: not for the append-buffer lists of K > 32, whose appends are already single stores)
-    const bool want_pending = P::has_pending && (list_in_lds || K <= 32 || P::pending_for_append) && !getenv("RM_DEBUG_NO_PENDING");
+    const bool want_pending = !ext_topk && P::has_pending && (list_in_lds || K <= 32 || P::pending_for_append) && !getenv("RM_DEBUG_NO_PENDING");
     const size_t per_key = (size_t)n_waves * WAVE * P::pend_key_bytes;            // one key per lane and wave
     int pend_cap = 0; size_t pend_off = 0, sync_off = 0;
     if (P::block_carve) {
@@ -423,7 +432,6 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             }
             if (n_stream > 0) {
                 const size_t nz = (size_t)std::max<long long>(c.nnz_test, 1);
-                stream_scores = (T *)ws.get("stream_scores", sizeof(T) * (size_t)n_stream * (size_t)stream_ld);
                 spos_score = (T *)ws.get("spos_score", sizeof(T) * nz);
                 spos_item = (int *)ws.get("spos_item", sizeof(int) * nz);
                 shist = (unsigned *)ws.get("shist", sizeof(unsigned) * nz);
@@ -435,12 +443,12 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             }
         }
 
-        pl = (Entry<T> *)ws.get("pl", sizeof(Entry<T>) * (size_t)n_slots * n_part * K);
+        if (n_stream > 0) stream_scores = (T *)ws.get("stream_scores", sizeof(T) * (size_t)n_stream * (size_t)stream_ld);
+        if (!ext_topk) pl = (Entry<T> *)ws.get("pl", sizeof(Entry<T>) * (size_t)n_slots * n_part * K);
         pst = (PartialStat<T> *)ws.get("pst", sizeof(PartialStat<T>) * (size_t)n_slots * n_part);
         typename P::ListT *glists = nullptr;
         const unsigned n_blocks = (unsigned)n_ublocks * n_splits;
-        if (!list_in_lds) {
-            if (K > 256) throw RmError{RM_ERR_UNSUPPORTED, "k_metrics > 256 is not supported when the top-K lists do not fit LDS"};
+        if (!list_in_lds && !ext_topk) {
             glists = (typename P::ListT *)ws.get("glists", sizeof(typename P::ListT) * (size_t)n_blocks * n_waves * GU * (2 * K + 32));
         }
 
@@ -449,8 +457,8 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         HIP_CHECK(hipMemsetAsync(thr_shared, 0, sizeof(ThrT) * (size_t)n_slots, stream));
         typename P::Args sa{};
         sa.thr_shared = thr_shared;
-        sa.n = n; sa.K = K; sa.n_slots = n_slots; sa.n_groups = n_groups; sa.n_ublocks = n_ublocks;
-        sa.n_splits = n_splits; sa.tiles_total = tiles_total; sa.jmax = jmax; sa.check_nan = check_nan ? 1 : 0; sa.buffered_lists = K > 32 ? 1 : 0;
+        sa.n = n; sa.K = K; sa.ngt = NG; sa.n_slots = n_slots; sa.n_groups = n_groups; sa.n_ublocks = n_ublocks;
+        sa.n_splits = n_splits; sa.tiles_total = tiles_total; sa.jmax = jmax; sa.check_nan = check_nan ? 1 : 0; sa.buffered_lists = (K > 32 || ext_topk) ? 1 : 0; sa.ext_topk = ext_topk ? 1 : 0;
         sa.Ap = (decltype(sa.Ap))Ap; sa.Bp = (decltype(sa.Bp))Bp; sa.slot_user = slot_user; sa.slot_chunk = slot_chunk;
         sa.train_p = c.train_p; sa.train_i = c.train_i; sa.gj = gj; sa.grow = grow;
         sa.pos_score = pos_score; sa.pos_item = pos_item; sa.hist = hist; sa.glists = glists; sa.pl = pl; sa.pst = pst; sa.dump = nullptr;
@@ -521,10 +529,18 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         fa.heavy_users = heavy_users; fa.n_heavy = hp.n_heavy;
         hipLaunchKernelGGL((k_top_values<T, T>), dim3(cdiv((long long)hp.n_heavy * WAVE, 256)), dim3(256), 0, stream, fa);
     }
+    fa.stream_slot0 = stream_slot0; fa.stream_scores = stream_scores; fa.stream_ld = stream_ld;
+    if (n_slots > 0 && ext_topk) {
+        int sel_ld = 2;
+        while (sel_ld < K) sel_ld <<= 1;
+        fa.ext_topk = 1; fa.sel_ld = sel_ld;
+        fa.sel_hi = (unsigned long long *)ws.get("sel_hi", sizeof(unsigned long long) * (size_t)n_slots * sel_ld);
+        fa.sel_lo = (unsigned *)ws.get("sel_lo", sizeof(unsigned) * (size_t)n_slots * sel_ld);
+        hipLaunchKernelGGL((k_select_topk<T, T>), dim3(n_slots), dim3(SELECT_THREADS), 0, stream, fa);
+    }
     if (n_slots > 0) {
         if (want_auc) {
             fa.auc_part = (AucPart *)ws.get("auc_part", sizeof(AucPart) * (size_t)n_slots);
-            fa.stream_slot0 = stream_slot0; fa.stream_scores = stream_scores; fa.stream_ld = stream_ld;
             fa.spos_score = spos_score; fa.spos_item = spos_item; fa.shist = shist;
             if (n_stream > 0) {
                 const int parts = (int)cdiv(n, STREAM_RANK_THREADS * STREAM_RANK_ITEMS);
@@ -761,6 +777,12 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     if (const char *e = getenv("RM_BATCH_USERS")) bu = atof(e);      // tests
     long long batch = (long long)std::min<double>(std::max(bu, 1024.0), 2.0e9);
     batch = (batch + 1023) / 1024 * 1024;
+    if (K > 256) {                                                   // one score row per user of the batch (run(): ext_topk)
+        size_t fr = 0, tot = 0;
+        HIP_CHECK(hipMemGetInfo(&fr, &tot));
+        const long long row = (((long long)n + 191) / 192 * 192) * (long long)sizeof(T) + 16ll * K;
+        batch = std::max<long long>(1, std::min<long long>(batch, (long long)(fr / 4) / row));
+    }
     SignalGuard *sg = nullptr;                                       // the caller's guard polls; here only the flag is read
     (void)sg;
     for (long long b0 = 0; b0 < m; b0 += batch) {
@@ -894,7 +916,7 @@ void debug_scores(const T *A, size_t lda, const T *B, size_t ldb, int m, int n, 
     const int K = 1;
     typename P::ListT *glists = (typename P::ListT *)ws.get("glists", sizeof(typename P::ListT) * (size_t)n_ublocks * 8 * GU * (2 * K + 32));
     typename P::Args sa{};
-    sa.n = n; sa.K = K; sa.n_slots = m; sa.n_groups = n_groups; sa.n_ublocks = n_ublocks; sa.n_splits = 1;
+    sa.n = n; sa.K = K; sa.ngt = NG; sa.n_slots = m; sa.n_groups = n_groups; sa.n_ublocks = n_ublocks; sa.n_splits = 1;
     sa.tiles_total = tiles_total; sa.jmax = 0; sa.check_nan = 1; sa.Ap = (decltype(sa.Ap))Ap; sa.Bp = (decltype(sa.Bp))Bp;
     sa.slot_user = slot_user; sa.slot_chunk = zeros; sa.train_p = zeros; sa.train_i = zeros; sa.gj = zeros + m + 1; sa.grow = grow;
     sa.glists = glists; sa.dump = dump;

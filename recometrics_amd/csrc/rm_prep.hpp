@@ -19,6 +19,7 @@ struct ClassifyArgs {
     int *heavy_users;        // [m] list of the evaluated users with more than HEAVY_NPOS test items (plan->n_heavy of them)
     Plan *plan;
     const unsigned char *only;   // optional [m]: evaluate only the users with a non-zero entry (the others: UF_SKIP)
+    int force_stream;            // 1 = every evaluated user is streamed (top-K picked from its stored scores: k_metrics > 256)
 };
 
 __device__ __forceinline__ int chunk_depth(int pc)      // smallest j with 2^j - 1 >= pc   (pc in 1..63)
@@ -58,7 +59,7 @@ __global__ void k_classify(ClassifyArgs a)
     if (isnan_user) f = UF_NAN;
     else {
         f = UF_ACTIVE | (only_ndcg ? UF_ONLY_NDCG : 0) | (kleqn ? UF_KLEQN : 0);
-        if (a.want_auc && !only_ndcg && npos > POS_CHUNK && a.plan->stream_enable) {
+        if (a.force_stream || (a.want_auc && !only_ndcg && npos > POS_CHUNK && a.plan->stream_enable)) {
             nsl = 1;                                            // streamed user: one slot, ranks from its stored score row
             myclass = STREAM_CLASS;
         } else if (a.want_auc && !only_ndcg) {
@@ -163,6 +164,7 @@ struct AssignArgs {
     int *slot_user, *slot_chunk, *slot_index;
     unsigned char *slot_j;
     int *sc_user, *sc_chunk;     // work list of the streamed users' chunks of POS_CHUNK test entries (plan->n_stream_chunks of them)
+    int force_stream;
 };
 
 // scatter every (user, chunk) into its depth class; order inside a class is arbitrary (results do not depend on it).
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign_slots(AssignArgs a)
     const bool auc_user = nsl && a.want_auc && !(a.flags[u] & UF_ONLY_NDCG);
     // last (or only) chunk of every user: position inside the block's share of its class
     int jlast = -1, in_blk = 0;
-    const bool streamed = auc_user && nsl == 1 && npos > POS_CHUNK;
+    const bool streamed = nsl && (a.force_stream || (auc_user && nsl == 1 && npos > POS_CHUNK));
     if (nsl) jlast = streamed ? STREAM_CLASS : auc_user ? chunk_depth(min(POS_CHUNK, npos - (nsl - 1) * POS_CHUNK)) : 0;
     for (int j = 0; j < N_CLASSES; j++) {
         const unsigned long long mk = __ballot(jlast == j);
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign_slots(AssignArgs a)
     __syncthreads();
     if (threadIdx.x < N_CLASSES && blk_count[threadIdx.x]) blk_base[threadIdx.x] = atomicAdd(&a.plan->class_cursor[threadIdx.x], blk_count[threadIdx.x]);
     __syncthreads();
-    if (streamed) {                                              // rare: the order of the work list does not matter
+    if (streamed && auc_user) {                                  // rare: the order of the work list does not matter
         const int nch = (npos + POS_CHUNK - 1) / POS_CHUNK;
         const int at = atomicAdd(&a.plan->n_stream_chunks, nch);
         for (int c = 0; c < nch; c++) { a.sc_user[at + c] = u; a.sc_chunk[at + c] = c; }

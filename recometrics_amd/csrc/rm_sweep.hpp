@@ -169,9 +169,13 @@ void k_sweep(SweepArgs a)
     // factor axis: NGT groups of 8 factors; up to 128 factors (NGT <= 16) a tile is one LDS image and the user factors
     // stay in registers for the whole sweep; beyond that the axis is streamed in chunks of 128 factors (one barrier
     // per chunk) and each chunk of user factors is re-read from L2 when its turn comes.
-    constexpr int NG = NGT < 16 ? NGT : 16;                    // groups per LDS chunk
-    constexpr int NC = NGT / NG;                                // chunks per tile
-    constexpr bool AF_RESIDENT = NC == 1;
+    // NGT == 0: the group count is a run-time value (a.ngt, a multiple of 16): more than 512 factors, any number of chunks
+    constexpr bool NGT_RT = NGT == 0;
+    constexpr int NG = NGT_RT ? 16 : (NGT < 16 ? NGT : 16);     // groups per LDS chunk
+    constexpr int NC_CT = NGT_RT ? 0 : NGT / NG;                // chunks per tile when known at compile time
+    const int NGTV = NGT_RT ? a.ngt : NGT;
+    const int NC = NGT_RT ? a.ngt / NG : NC_CT;
+    constexpr bool AF_RESIDENT = NC_CT == 1;
     constexpr bool AF_PREFETCH = !AF_RESIDENT && LMODE != LM_HBM_APPEND;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BUF_F4 = NG * 2 * TILE;                 // float4 per packed tile
@@ -233,7 +237,7 @@ void k_sweep(SweepArgs a)
 
     // user factors -> registers (packed: [group][g][h][32][4 floats])
     float4 af[NG];
-    const float4 *af_src = a.Ap + ((size_t)(group_ok ? group : 0) * NGT * 2 + h) * GROUP_USERS + ul;      // + g * 2 * GROUP_USERS
+    const float4 *af_src = a.Ap + ((size_t)(group_ok ? group : 0) * NGTV * 2 + h) * GROUP_USERS + ul;     // + g * 2 * GROUP_USERS
     // resident factors, or chunk 0 of a streamed axis (every later chunk is prefetched by do_mfma)
     #pragma unroll
     for (int g = 0; g < NG; g++)
@@ -320,8 +324,8 @@ void k_sweep(SweepArgs a)
     // streamed users (more than POS_CHUNK test items; the last slots): no table, no rank counting here -- the lane writes
     // its masked scores to the user's row in HBM and k_rank_streamed counts from there.  Wave-uniform flag: a wave with
     // none of them (all but the last few user blocks) pays one scalar branch per tile.
-    const bool stream_lane = AUC && slot_ok && slot >= a.stream_slot0;
-    const bool wave_streams = AUC && __any(stream_lane);
+    const bool stream_lane = slot_ok && slot >= a.stream_slot0;
+    const bool wave_streams = __any(stream_lane);
     float *stream_row = stream_lane ? a.stream_scores + (size_t)(slot - a.stream_slot0) * (size_t)a.stream_ld : nullptr;
     // tie noise (rm_noise.hpp), exact passes only: the lane's user's row of per-item noise values
     const float *noise_lane = (a.noise_E && user >= 0)
@@ -464,7 +468,8 @@ void k_sweep(SweepArgs a)
         // every partial list of the user (other sub-tile wave, other item splits) publishes its K-th best; the largest
         // of them is a valid lower bound of the final K-th best, so it filters for all of them
         if (primary && thr_seen > thr_pub) { thr_pub = thr_seen; const float t = ord_unkey(thr_seen); thr = t > thr ? t : thr; }
-        const unsigned long long cm = __ballot(tmax >= thr);
+        // (a.ext_topk: k_metrics beyond the lists' reach -- every lane streams its scores and k_select_topk picks the top-K)
+        const unsigned long long cm = a.ext_topk ? 0ull : __ballot(tmax >= thr);
         RM_STAT(0, 1); RM_STAT(1, cm != 0); RM_STAT(2, __popcll(cm));
         if (cm && pend_cap) {
             unsigned ov = 0;                                    // score registers that did not fit the lane's buffer
@@ -537,7 +542,7 @@ void k_sweep(SweepArgs a)
 #endif
 #ifndef RM_ABL_NO_AUC
         // (4) AUC rank counting (replaces the full sort of :552 + the walk of :795-865)
-        if (AUC && wave_streams) {
+        if (wave_streams) {
             if (stream_lane) {                                  // registers 4q .. 4q+3 are four consecutive items
                 #pragma unroll
                 for (int q4 = 0; q4 < 4; q4++)
@@ -644,7 +649,7 @@ void k_sweep(SweepArgs a)
             list_sort_desc<float, GROUP_USERS>(Lr, K);
             for (int i = 0; i < K; i++) ListRaw<float>::unpack(Lr[i * GROUP_USERS], dst[i].s, dst[i].idx);
         }
-    } else if (!LLDS) {
+    } else if (!LLDS && !a.ext_topk) {
         compact_users(__ballot(slot_ok && h == 0 && primary && cnt > 0));
         if (slot_ok && h == 0) {
             ListEntry *dst = a.pl + ((size_t)slot * n_part + part) * K;

@@ -1,4 +1,5 @@
-// rm_sweep32_large.hip -- translation unit instantiating the fp32 sweep kernels for 129..512 factors.
+// rm_sweep32_large.hip -- translation unit instantiating the fp32 sweep kernels for more than 128 factors (129..512: chunk
+// count at compile time; beyond: one kernel with the chunk count at run time).
 #include <hip/hip_runtime.h>
 #include "rm_sweep.hpp"
 
@@ -16,7 +17,9 @@ static int launch_ng(int NG, dim3 grid, size_t lds, hipStream_t stream, const Sw
     } break;
     switch (NG) {
         RM_LAUNCH(32) RM_LAUNCH(64)
-        default: return -1;
+        default:
+            if (NG <= 64 || NG % 16 != 0 || sa.ngt != NG) return -1;
+            switch (0) { RM_LAUNCH(0) }                       // more than 512 factors: chunk count at run time
     }
 #undef RM_LAUNCH
     return (int)hipGetLastError();

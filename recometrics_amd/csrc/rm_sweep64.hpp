@@ -72,8 +72,12 @@ void k_sweep64(Sweep64Args a)
     constexpr bool buffered = LMODE == LM_HBM_APPEND;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int GU = GROUP_USERS64;
-    constexpr int NGC = NGT < 8 ? NGT : 8;                      // factor groups (of 8) per LDS chunk
-    constexpr int NC = NGT / NGC;                               // chunks per tile
+    // NGT == 0: the group count is a run-time value (a.ngt, a multiple of 8): more than 512 factors
+    constexpr bool NGT_RT = NGT == 0;
+    constexpr int NGC = NGT_RT ? 8 : (NGT < 8 ? NGT : 8);       // factor groups (of 8) per LDS chunk
+    constexpr int NC_CT = NGT_RT ? 0 : NGT / NGC;               // chunks per tile when known at compile time
+    const int NGTV = NGT_RT ? a.ngt : NGT;
+    const int NC = NGT_RT ? a.ngt / NGC : NC_CT;
     constexpr int BUF_D2 = NGC * 4 * TILE_ITEMS;                // double2 per chunk buffer
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gi = wave & 3, sub = wave >> 2;
@@ -128,13 +132,13 @@ void k_sweep64(Sweep64Args a)
 
     // user factors -> registers: [group][g][q][16 users][2 doubles].  Up to 128 factors (64 VGPRs) they stay resident
     // for the whole sweep; beyond that each 64-factor chunk is re-read from L2 when its turn comes.
-    constexpr bool AF_RESIDENT = NGT <= 16;
+    constexpr bool AF_RESIDENT = !NGT_RT && NGT <= 16;
     constexpr int NAF = AF_RESIDENT ? NGT : NGC;
     f64x2 af[NAF];
-    const f64x2 *af_src = a.Ap + ((size_t)(group_ok ? group : 0) * NGT * 4 + q) * GU + ul;     // + g * 4 * GU
+    const f64x2 *af_src = a.Ap + ((size_t)(group_ok ? group : 0) * NGTV * 4 + q) * GU + ul;    // + g * 4 * GU
     if (AF_RESIDENT) {
         #pragma unroll
-        for (int g = 0; g < NGT; g++) {
+        for (int g = 0; g < (AF_RESIDENT ? NGT : 0); g++) {
             f64x2 z; z.x = 0; z.y = 0;
             af[g] = group_ok ? af_src[(size_t)g * 4 * GU] : z;
         }
@@ -212,8 +216,8 @@ void k_sweep64(Sweep64Args a)
     char *histb = (char *)(histL + gi * (PLmax + 1) * GU + ul);
     const int *pos_item_g = (AUC && group_ok) ? a.pos_item + (a.grow[group] + group) * GU + ul : nullptr;
     // streamed users (see the fp32 sweep): the lane writes its masked scores to the user's row in HBM
-    const bool stream_lane = AUC && slot_ok && slot >= a.stream_slot0;
-    const bool wave_streams = AUC && __any(stream_lane);
+    const bool stream_lane = slot_ok && slot >= a.stream_slot0;
+    const bool wave_streams = __any(stream_lane);
     double *stream_row = stream_lane ? a.stream_scores + (size_t)(slot - a.stream_slot0) * (size_t)a.stream_ld : nullptr;
     // tie noise (rm_noise.hpp): the lane's user's row of per-item noise values
     const double *noise_lane = (a.noise_E && user >= 0)
@@ -221,7 +225,7 @@ void k_sweep64(Sweep64Args a)
 
     // unit u = (tile, chunk): contiguous BUF_D2 double2 of the packed image [tile][g][q][row][2]
     auto stage = [&](int tile, int chunk, int buf) {
-        const f64x2 *src = a.Bp + ((size_t)tile * NGT + (size_t)chunk * NGC) * 4 * TILE_ITEMS;
+        const f64x2 *src = a.Bp + ((size_t)tile * NGTV + (size_t)chunk * NGC) * 4 * TILE_ITEMS;
         f64x2 *dst = ldsB + buf * BUF_D2;
         // inline asm, not the builtin: see the note at the fp32 sweep's stage() (the compiler would otherwise wait for
         // the DMA in front of the next LDS read)
@@ -281,8 +285,10 @@ void k_sweep64(Sweep64Args a)
         }
         if (primary && thr_seen > thr_pub) { thr_pub = thr_seen; const double t = ord_unkey(thr_seen); thr = t > thr ? t : thr; }
         unsigned long long cm = 0;
-        #pragma unroll
-        for (int r = 0; r < 8; r++) cm |= __ballot(v[r] >= thr);
+        if (!a.ext_topk) {                                      // (ext_topk: see the fp32 sweep)
+            #pragma unroll
+            for (int r = 0; r < 8; r++) cm |= __ballot(v[r] >= thr);
+        }
         if (cm && pend_cap) {
             unsigned ov = 0;                                    // score registers that did not fit the lane's buffer
             #pragma unroll
@@ -350,7 +356,7 @@ void k_sweep64(Sweep64Args a)
                 thr_pub = kk > thr_pub ? kk : thr_pub;
             }
         }
-        if (AUC && wave_streams) {
+        if (wave_streams) {
             if (stream_lane) {
                 #pragma unroll
                 for (int r = 0; r < 8; r++) stream_row[sb + (r >> 2) * 16 + q + 4 * (r & 3)] = v[r];
@@ -386,7 +392,7 @@ void k_sweep64(Sweep64Args a)
         const unsigned long long thr_next = (primary && !DUMP) ? __hip_atomic_load(a.thr_shared + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         // resident user factors are indexed af[c * NGC + gl]: the chunk loop must then be unrolled; when each chunk's
         // factors are re-read the loop stays rolled (4x less code and register pressure at 256 factors)
-        #pragma unroll(AF_RESIDENT ? NC : 1)
+        #pragma unroll(AF_RESIDENT ? NC_CT : 1)
         for (int c = 0; c < NC; c++) {
             const int unit = i * NC + c;
             const int buf = unit & 1;
@@ -447,7 +453,7 @@ void k_sweep64(Sweep64Args a)
             list_sort_desc<double, GU>(Lr, K);
             for (int i = 0; i < K; i++) ListRaw<double>::unpack(Lr[i * GU], dst[i].s, dst[i].idx);
         }
-    } else if (!LLDS) {
+    } else if (!LLDS && !a.ext_topk) {
         compact_users(__ballot(slot_ok && q == 0 && primary && cnt > 0));
         if (slot_ok && q == 0) {
             Entry<double> *dst = a.pl + ((size_t)slot * n_part + part) * K;

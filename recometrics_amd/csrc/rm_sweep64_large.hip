@@ -16,7 +16,9 @@ static int launch_ng(int NG, dim3 grid, size_t lds, hipStream_t stream, const Sw
     } break;
     switch (NG) {
         RM_LAUNCH(16) RM_LAUNCH(32) RM_LAUNCH(64)
-        default: return -1;
+        default:
+            if (NG <= 64 || NG % 8 != 0 || sa.ngt != NG) return -1;
+            switch (0) { RM_LAUNCH(0) }                       // more than 512 factors: chunk count at run time
     }
 #undef RM_LAUNCH
     return (int)hipGetLastError();

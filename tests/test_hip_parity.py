@@ -39,7 +39,7 @@ def hip_calc(hip, A, B, train, test, k, metrics=("p", "tp", "r", "ap", "tap", "n
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("k", [1, 8, 24, 50, 64, 100, 128, 129, 200, 256, 300, 512])
+@pytest.mark.parametrize("k", [1, 8, 24, 50, 64, 100, 128, 129, 200, 256, 300, 512, 520, 1000, 1024, 1500])
 def test_mfma_scores_are_the_k_ordered_fma_chain(hip, oracle, k):
     """The sweep's v_mfma_f32_32x32x2_f32 contraction == strict index-order fmaf chain (reference dot1), bit for bit."""
     rng = np.random.default_rng(k)
@@ -50,7 +50,7 @@ def test_mfma_scores_are_the_k_ordered_fma_chain(hip, oracle, k):
     assert_same_bits(got, want, "scores k=%d" % k)
 
 
-@pytest.mark.parametrize("k", [3, 8, 40, 64, 100, 130, 256, 300, 512])
+@pytest.mark.parametrize("k", [3, 8, 40, 64, 100, 130, 256, 300, 512, 513, 700, 1024])
 def test_mfma_f64_scores_are_the_k_ordered_fma_chain(hip, oracle, k):
     """v_mfma_f64_16x16x4_f64 contraction == strict index-order fma chain (reference dot1, double), bit for bit."""
     rng = np.random.default_rng(100 + k)
@@ -143,6 +143,11 @@ def _check_against_oracle(hip, oracle, pr, k, dtype=np.float32, **kw):
     (160, 7000, 128, 32, 120),     # largest K of that scheme
     (900, 4000, 128, 20, 90),      # enough users for a depth split: shallow blocks with LDS lists beside deep ones with HBM lists
     (100, 6000, 256, 20, 100),     # the same with a streamed factor axis (prefetched user factors)
+    (120, 3000, 600, 10, 40),      # more than 512 factors: chunk count of the factor axis at run time
+    (70, 2500, 1024, 30, 60),
+    (150, 4000, 48, 300, 60),      # k_metrics > 256: every user streamed, top-K picked from the stored rows (k_select_topk)
+    (90, 2500, 130, 1000, 40),
+    (40, 700, 16, 699, 30),        # k_metrics = n - 1
 ])
 def test_random_problem_vs_oracle(hip, oracle, m, n, k, K, mean_c):
     from recometrics_amd.synth import make_problem
@@ -159,6 +164,8 @@ def test_random_problem_vs_oracle(hip, oracle, m, n, k, K, mean_c):
     (80, 6000, 256, 30, 120),      # fp64 replace-the-minimum lists in HBM (too large for LDS, K <= 32) + pending buffers
     (96, 9000, 64, 12, 60),        # fp64 LDS lists + pending buffers
     (500, 3000, 128, 28, 90),      # fp64 depth split: shallow blocks with LDS lists beside deep ones with HBM lists
+    (60, 2000, 600, 10, 40),       # fp64, more than 512 factors
+    (100, 3000, 40, 400, 50),      # fp64, k_metrics > 256
 ])
 def test_random_problem_vs_oracle_f64(hip, oracle, m, n, k, K, mean_c):
     from recometrics_amd.synth import make_problem
@@ -166,7 +173,7 @@ def test_random_problem_vs_oracle_f64(hip, oracle, m, n, k, K, mean_c):
     _check_against_oracle(hip, oracle, pr, K, dtype=np.float64)
 
 
-@pytest.mark.parametrize("env", [{"RM_DEBUG_NO_PENDING": "1"}, {"RM_DEBUG_HBM_LISTS": "1"},
+@pytest.mark.parametrize("env", [{"RM_DEBUG_NO_PENDING": "1"}, {"RM_DEBUG_HBM_LISTS": "1"}, {"RM_DEBUG_EXT_TOPK": "1"},
                                  {"RM_DEBUG_HBM_LISTS": "1", "RM_DEBUG_NO_PENDING": "1"},
                                  {"RM_DEBUG_NSUB2": "1"}, {"RM_DEBUG_NSUB2": "1", "RM_DEBUG_NO_PENDING": "1"}])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -331,9 +338,9 @@ def test_c_abi_error_statuses(hip):
     from recometrics_amd.synth import make_problem
     pr = make_problem(40, 300, 8, np.float32, mean_c=20, seed=3)
     good = hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], 5)
-    wide = np.zeros((40, 520), np.float32)                     # more factors than the kernels are built for
-    with pytest.raises(RuntimeError, match="512 factors"):
-        hip_calc(hip, wide, np.zeros((300, 520), np.float32), pr["train"], pr["test"], 5)
+    with pytest.raises(ValueError, match="leading dimension"):
+        hip.calc_metrics(pr["A"], 4, pr["B"], 8, pr["train"][0], pr["train"][1], pr["test"][0], pr["test"][1], pr["test"][2], 5,
+                         {name: True for name in hip.METRIC_ORDER}, False, False, True, 2, 1, 1, 1)
     with pytest.raises(ValueError, match="k_metrics"):
         hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], 0)
     again = hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], 5)
