@@ -95,7 +95,8 @@ class Oracle(_Lib):
     """This repo's restatement; also offers the ranking dump used by the index-set parity tests."""
 
     def __init__(self):
-        path = os.path.join(_HERE, "librecometrics_oracle.so")
+        # RECOMETRICS_ORACLE_LIB: another build of the same restatement (the sanitizer build of oracle/Makefile)
+        path = os.environ.get("RECOMETRICS_ORACLE_LIB") or os.path.join(_HERE, "librecometrics_oracle.so")
         if not os.path.exists(path):
             build()
         super().__init__(path)

@@ -74,6 +74,33 @@ def load():
     return lib
 
 
+_split_lib = None
+
+
+def _load_split():
+    """The library that provides rm_split_* (host-only code): librecometrics_hip.so, or -- RECOMETRICS_SPLIT_LIB -- another
+    build of csrc/rm_split.cpp alone (the sanitizer build of oracle/Makefile, which has no device code to link)."""
+    global _split_lib
+    alt = os.environ.get("RECOMETRICS_SPLIT_LIB")
+    if not alt:
+        return load()
+    if _split_lib is None:
+        lib = C.CDLL(alt)
+        vp, i32, i64, u64, ci = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_int
+        sig = [vp, vp, vp, i32, i32, ci, i32, C.c_double, ci, i32, i32, u64, C.POINTER(vp)]
+        lib.rm_split_f32.argtypes = lib.rm_split_f64.argtypes = sig
+        lib.rm_split_f32.restype = lib.rm_split_f64.restype = ci
+        lib.rm_split_size.argtypes = [vp, ci]
+        lib.rm_split_size.restype = i64
+        lib.rm_split_copy.argtypes = [vp, ci, vp]
+        lib.rm_split_copy.restype = ci
+        lib.rm_split_free.argtypes = [vp]
+        lib.rm_split_free.restype = None
+        lib.rm_split_last_error.restype = C.c_char_p
+        _split_lib = lib
+    return _split_lib
+
+
 def _raise(lib, rc):
     msg = (lib.rm_last_error() or b"").decode(errors="replace")
     if rc == 1:
@@ -221,7 +248,7 @@ def split_csr(indptr, indices, data, n_items, mode, n_users_test=0, test_fractio
               min_items_pool=2, min_pos_test=1, seed=1):
     """Host-side split (rm_split_*): returns a dict of raw arrays -- "train" / "test" / "rem" as (indptr, indices, data)
     tuples and "users_test".  mode: 0 every row, 1 separated, 2 joined (reference wrapper.pyx:523-818)."""
-    lib = load()
+    lib = _load_split()
     dtype = data.dtype.type
     fn = lib.rm_split_f32 if dtype == np.float32 else lib.rm_split_f64
     handle = C.c_void_p()

@@ -62,6 +62,38 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     return out
 
 
+CY_SRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_cy.pyx")
+
+
+def cython_module_path():
+    import sysconfig
+    return os.path.join(os.path.dirname(CY_SRC), "_cy" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_cython(force=False):
+    """Compiles recometrics_amd/_cy.pyx (the Cython binding over include/recometrics_hip.h) in-tree and links it against
+    csrc/librecometrics_hip.so.  Returns the path of the extension module."""
+    import sysconfig
+    build()
+    out = cython_module_path()
+    root = os.path.dirname(os.path.dirname(CSRC))
+    if not force and os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(CY_SRC), os.path.getmtime(os.path.join(root, "include", "recometrics_hip.h"))):
+        return out
+    csrc = os.path.join(os.path.dirname(CY_SRC), "_cy.c")
+    res = subprocess.run([shutil.which("cython") or "cython", "-3", CY_SRC, "-o", csrc], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("cython failed:\n" + res.stdout + res.stderr)
+    cmd = [shutil.which("gcc") or "gcc", "-O2", "-fPIC", "-shared", "-w", csrc, "-o", out,
+           "-I" + sysconfig.get_paths()["include"], "-I" + os.path.join(root, "include"),
+           "-L" + CSRC, "-lrecometrics_hip", "-Wl,-rpath,$ORIGIN/csrc"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("compiling the Cython binding failed:\n" + res.stdout + res.stderr)
+    os.remove(csrc)
+    return out
+
+
 if __name__ == "__main__":
     import sys
     print(build(force=True, verbose="-v" in sys.argv))
+    print(build_cython(force=True))

@@ -61,3 +61,14 @@ def test_product_never_imports_the_oracle():
                 low = line.lower()
                 if "oracle" in low and ("import" in low or "#include" in low or "cdll" in low or "dlopen" in low):
                     raise AssertionError("%s references the oracle: %s" % (f, line.strip()))
+
+
+def test_cython_binding_builds_and_imports():
+    """recometrics_amd/_cy.pyx compiles against include/recometrics_hip.h and links to the library (no GPU needed)"""
+    from recometrics_amd import build as rb
+    path = rb.build_cython()
+    assert os.path.exists(path)
+    from recometrics_amd import _cy
+    assert _cy.has_openmp() is True
+    assert _cy.device_count() >= 0
+    assert _cy.METRIC_ORDER == ("p", "tp", "r", "ap", "tap", "ndcg", "hit", "rr", "roc", "pr")

@@ -201,3 +201,25 @@ def test_torch_distributed_helper_with_the_hip_binding(hip, tmp_path):
     names = {"p": "P@K", "tp": "TP@K", "r": "R@K", "ap": "AP@K", "tap": "TAP@K", "ndcg": "NDCG@K", "hit": "Hit@K", "rr": "RR@K", "roc": "ROC_AUC", "pr": "PR_AUC"}
     for n, w in zip(hip.METRIC_ORDER, want):
         assert_same_bits(got[names[n]].astype(np.float32), w, "sharded over 2 ranks: " + names[n])
+
+
+def test_cython_binding_equals_the_ctypes_binding(hip, oracle=None):
+    """recometrics_amd/_cy.pyx (compiled for real): the same C-ABI through Cython -- outputs
+    bit-identical to the ctypes binding, single and cumulative, both precisions; status codes become the same exceptions"""
+    from recometrics_amd import build as rb
+    from recometrics_amd.synth import make_problem
+    assert os.path.exists(rb.cython_module_path()), "build the Cython binding first (python -m recometrics_amd.build)"
+    from recometrics_amd import _cy
+    assert _cy.has_openmp() and _cy.device_count() > 0
+    for dtype in (np.float32, np.float64):
+        pr = make_problem(400, 3000, 24, dtype, mean_c=50, seed=9)
+        trp, tri = pr["train"]
+        tep, tei, tev = pr["test"]
+        for cumulative in (False, True):
+            want = hip.calc_metrics(pr["A"], 24, pr["B"], 24, trp, tri, tep, tei, tev, 8, ALL, cumulative, True, True, 2, 1, 1, 123)
+            got = _cy.calc_metrics(pr["A"], 24, pr["B"], 24, trp, tri, tep, tei, tev, 8, ALL, cumulative, True, True, 2, 1, 1, 123)
+            for name, g, w in zip(hip.METRIC_ORDER, got, want):
+                assert g.dtype == w.dtype and g.shape == w.shape
+                assert_same_bits(g, w, "cython vs ctypes: %s" % name)
+    with pytest.raises(ValueError, match="k_metrics"):
+        _cy.calc_metrics(pr["A"], 24, pr["B"], 24, trp, tri, tep, tei, tev, 0, ALL, False, False, True, 2, 1, 1, 1)

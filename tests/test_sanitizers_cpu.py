@@ -1,0 +1,35 @@
+"""CPU-only: the host-side C++ of the repo under AddressSanitizer + UndefinedBehaviorSanitizer.
+
+oracle/Makefile's `sanitize` target builds the oracle restatement and the product's train/test splitting
+(recometrics_amd/csrc/rm_split.cpp) with -fsanitize=address,undefined; every golden fixture of both is then replayed through
+those builds in a child process with the ASan runtime preloaded.  Any out-of-bounds access, use-after-free or undefined
+arithmetic aborts the child.  (GPU sanitizers are not available on this pool; the device code is covered by the parity tests.)"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_host_code_under_asan_and_ubsan():
+    res = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "sanitize"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no ASan runtime on this machine")
+    # libstdc++ preloaded too: the ASan runtime resolves its __cxa_throw interceptor when it starts, and python itself does
+    # not link the C++ runtime (without this the first C++ exception thrown inside the sanitized code is a CHECK failure)
+    cxx = subprocess.run(["gcc", "-print-file-name=libstdc++.so.6"], capture_output=True, text=True).stdout.strip()
+    env = dict(os.environ,
+               LD_PRELOAD=asan + (" " + cxx if os.path.isabs(cxx) and os.path.exists(cxx) else ""),
+               ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
+               RECOMETRICS_ORACLE_LIB=os.path.join(ROOT, "oracle", "_san", "librecometrics_oracle_san.so"),
+               RECOMETRICS_SPLIT_LIB=os.path.join(ROOT, "oracle", "_san", "librm_split_san.so"))
+    res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider",
+                          os.path.join(ROOT, "tests", "test_oracle_golden.py"), os.path.join(ROOT, "tests", "test_split_cpu.py")],
+                         env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert "passed" in res.stdout
