@@ -139,7 +139,9 @@ void rm_request_interrupt(void);
 
 /* Timings of the most recent successful call on this thread, milliseconds measured with HIP events on the call's
  * stream: out[0] plan+pack+positives, out[1] sweep kernel, out[2] finalize, out[3] whole device section;
- * out[4] = launches of the sweep kernel, out[5] = item splits, out[6] = sweep blocks, out[7] = dynamic LDS bytes.
+ * out[4] = launches of the sweep kernel, out[5] = item splits, out[6] = sweep blocks, out[7] = dynamic LDS bytes,
+ * out[8] = user lanes (slots) of the launch that out[1] brackets -- when the blocks of streamed users run beside the main
+ * launch on a second stream, out[1] times the main launch only --, out[9] = user lanes of the whole call.
  * Forces a synchronisation of that stream.  Returns the number of values written. */
 int rm_get_timings(double *out, int n);
 

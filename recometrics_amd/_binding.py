@@ -157,9 +157,10 @@ def request_interrupt():
 
 def timings():
     lib = load()
-    buf = (C.c_double * 8)()
-    n = lib.rm_get_timings(buf, 8)
-    keys = ("prep_ms", "sweep_ms", "finalize_ms", "device_ms", "sweep_launches", "item_splits", "sweep_blocks", "lds_bytes")
+    buf = (C.c_double * 10)()
+    n = lib.rm_get_timings(buf, 10)
+    keys = ("prep_ms", "sweep_ms", "finalize_ms", "device_ms", "sweep_launches", "item_splits", "sweep_blocks", "lds_bytes",
+            "timed_slots", "total_slots")
     return {k: buf[i] for i, k in enumerate(keys[:n])}
 
 

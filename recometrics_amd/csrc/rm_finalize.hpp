@@ -171,10 +171,10 @@ __device__ __forceinline__ void rank_streamed_lds(const S *row, long long i0, in
 }
 
 template <class T, class S>
-__global__ __launch_bounds__(STREAM_RANK_THREADS) void k_rank_streamed(FinalArgs<T, S> a, int parts)
+__global__ __launch_bounds__(STREAM_RANK_THREADS) void k_rank_streamed(FinalArgs<T, S> a, int parts, int row0)
 {
     __shared__ __attribute__((aligned(16))) char rk_smem[STREAM_RANK_LDS];
-    const int d = blockIdx.x / parts, part = blockIdx.x % parts;
+    const int d = row0 + blockIdx.x / parts, part = blockIdx.x % parts;
     const int slot = a.stream_slot0 + d;
     const int u = a.slot_user[slot];
     if (a.flags[u] & UF_ONLY_NDCG) return;                            // (only when every user is streamed: no ranks wanted)
@@ -327,10 +327,10 @@ __global__ __launch_bounds__(SELECT_THREADS) void k_select_topk(FinalArgs<T, S> 
 // and the PR-AUC sum in the reference's own order -- left to right over the positives by descending score (:795-865) --
 // so that PR-AUC is bit-identical for these users whatever the length of the row.
 template <class T, class S>
-__global__ void k_auc_streamed(FinalArgs<T, S> a, int n_stream)
+__global__ void k_auc_streamed(FinalArgs<T, S> a, int row0, int row1)
 {
-    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (w >= n_stream) return;
+    const int w = row0 + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (w >= row1) return;
     const int slot = a.stream_slot0 + w;
     const int u = a.slot_user[slot];
     if (a.flags[u] & UF_ONLY_NDCG) return;

@@ -82,6 +82,7 @@ struct Ctx {
     hipEvent_t done = nullptr;               // end of the device work of the most recent call on this context
     hipStream_t own_stream = nullptr;        // stream of a shard worker (multi-device calls)
     double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int timed_slots = 0, total_slots = 0;     // slots (user lanes) of the sweep launch the "sweep" timing brackets / of the call
     double acc[4] = {0, 0, 0, 0};            // prep / sweep / finalize / total ms of the batches already read back (host entry)
     // what the packed item image (workspace buffer "Bp") currently holds, for batches of one host call that share B
     unsigned long long packed_tag = 0; int packed_tile = 0, packed_ng = 0; const void *packed_ptr = nullptr;
@@ -397,6 +398,30 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     }
 
     Entry<T> *merged = (Entry<T> *)ws.get("merged", sizeof(Entry<T>) * (size_t)m * K);
+    // the argument block of the finalisation kernels is filled in as the pieces come into being: the ranks of the streamed
+    // users are taken on a second stream while the sweep of the other users is still running
+    long long *rank_sorted = nullptr;
+    if (c.pos_rank) rank_sorted = (long long *)ws.get("rank_sorted", sizeof(long long) * (size_t)std::max<long long>(c.nnz_test, 1));
+    if (rank_sorted) HIP_CHECK(hipMemsetAsync(rank_sorted, 0, sizeof(long long) * (size_t)std::max<long long>(c.nnz_test, 1), stream));
+    FinalArgs<T, T> fa{};
+    fa.m = m; fa.n = n; fa.K = K; fa.req = req; fa.cumulative = c.cumulative ? 1 : 0; fa.noise = c.noise ? 1 : 0; fa.gu = GU;
+    fa.train_p = c.train_p; fa.test_p = c.test_p; fa.test_i = c.test_i; fa.test_v = c.test_v;
+    fa.flags = flags; fa.user_nslots = user_nslots; fa.uslot_base = uslot_base; fa.slot_index = slot_index;
+    fa.gj = gj; fa.grow = grow; fa.log2tab = log2tab;
+    fa.p = c.out[0]; fa.tp = c.out[1]; fa.r = c.out[2]; fa.ap = c.out[3]; fa.tap = c.out[4];
+    fa.ndcg = c.out[5]; fa.hit = c.out[6]; fa.rr = c.out[7]; fa.roc = c.out[8]; fa.pr = c.out[9];
+    fa.merged = merged; fa.rank_sorted = rank_sorted; fa.status = c.status;
+    fa.noise_flag = c.noise_flag; fa.plan = plan;
+    fa.n_slots = n_slots; fa.slot_user = slot_user; fa.slot_chunk = slot_chunk;
+    fa.stream_slot0 = stream_slot0;
+    if (want_auc && n_slots > 0) fa.auc_part = (AucPart *)ws.get("auc_part", sizeof(AucPart) * (size_t)n_slots);
+    int stream_rows_done = 0; bool ranked_beside = false;  // rows [stream_rows_done, n_stream) were ranked beside the sweep
+    const int stream_parts = (int)cdiv(n, STREAM_RANK_THREADS * STREAM_RANK_ITEMS);
+    auto rank_streamed_rows = [&](int r0, int r1, hipStream_t st) {
+        if (r1 <= r0) return;
+        hipLaunchKernelGGL((k_rank_streamed<T, T>), dim3((unsigned)((long long)(r1 - r0) * stream_parts)), dim3(STREAM_RANK_THREADS), 0, st, fa, stream_parts, r0);
+        hipLaunchKernelGGL((k_auc_streamed<T, T>), dim3(cdiv((long long)(r1 - r0) * WAVE, 256)), dim3(256), 0, st, fa, r0, r1);
+    };
     T *pos_score = nullptr; unsigned *hist = nullptr; int *pos_order = nullptr, *pos_item = nullptr;
     Entry<T> *pl = nullptr; PartialStat<T> *pst = nullptr;
     T *stream_scores = nullptr, *spos_score = nullptr; int *spos_item = nullptr; unsigned *shist = nullptr;
@@ -498,10 +523,18 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             dispatch_sweep(want_auc, false, true, nsub, NG, dim3((unsigned)u_split * n_splits), lds_l, stream, sl);
             HIP_CHECK(hipStreamWaitEvent(stream, g_side_ev[1], 0));
         } else {
+            // (Measured and dropped: the blocks made of streamed users only as a second launch of the sweep variant without rank
+            // counting on a side stream, followed there by k_rank_streamed, beside the main launch.  At C2 the step time did
+            // not move -- 11.61 vs 11.59 ms -- and at the north-star shape, where one launch is exactly one round of 256
+            // blocks, the side launch ran AFTER the main one instead of beside it: 61 ms of tail.  gpurun_out r2q.)
             dispatch_sweep(want_auc, false, list_in_lds, nsub, NG, dim3(n_blocks), lds_total, stream, sa);
         }
-        HIP_CHECK(hipEventRecord(g_ev[2], stream));
-        g_timings[4] = u_split > 0 ? 2 : 1; g_timings[5] = n_splits; g_timings[6] = n_blocks; g_timings[7] = (double)lds_total;
+        if (!ranked_beside) {
+            HIP_CHECK(hipEventRecord(g_ev[2], stream));
+            g_timings[4] = u_split > 0 ? 2 : 1; g_timings[5] = n_splits; g_timings[6] = n_blocks; g_timings[7] = (double)lds_total;
+            cx.timed_slots = n_slots;
+        }
+        cx.total_slots = n_slots;
     } else {
         HIP_CHECK(hipEventRecord(g_ev[1], stream));
         HIP_CHECK(hipEventRecord(g_ev[2], stream));
@@ -509,19 +542,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     }
 
     // ---- finalize ----
-    long long *rank_sorted = nullptr;
-    if (c.pos_rank) rank_sorted = (long long *)ws.get("rank_sorted", sizeof(long long) * (size_t)std::max<long long>(c.nnz_test, 1));
-    if (rank_sorted) HIP_CHECK(hipMemsetAsync(rank_sorted, 0, sizeof(long long) * (size_t)std::max<long long>(c.nnz_test, 1), stream));
-    FinalArgs<T, T> fa{};
-    fa.m = m; fa.n = n; fa.K = K; fa.n_part = n_part; fa.req = req; fa.cumulative = c.cumulative ? 1 : 0; fa.noise = c.noise ? 1 : 0; fa.gu = GU;
-    fa.train_p = c.train_p; fa.test_p = c.test_p; fa.test_i = c.test_i; fa.test_v = c.test_v;
-    fa.flags = flags; fa.user_nslots = user_nslots; fa.uslot_base = uslot_base; fa.slot_index = slot_index;
-    fa.gj = gj; fa.grow = grow; fa.pl = pl; fa.pst = pst; fa.hist = hist; fa.pos_score = pos_score; fa.log2tab = log2tab;
-    fa.p = c.out[0]; fa.tp = c.out[1]; fa.r = c.out[2]; fa.ap = c.out[3]; fa.tap = c.out[4];
-    fa.ndcg = c.out[5]; fa.hit = c.out[6]; fa.rr = c.out[7]; fa.roc = c.out[8]; fa.pr = c.out[9];
-    fa.merged = merged; fa.rank_sorted = rank_sorted; fa.status = c.status;
-    fa.noise_flag = c.noise_flag; fa.plan = plan;
-    fa.n_slots = n_slots; fa.slot_user = slot_user; fa.slot_chunk = slot_chunk;
+    fa.n_part = n_part; fa.pl = pl; fa.pst = pst; fa.hist = hist; fa.pos_score = pos_score;
     hipLaunchKernelGGL((k_finalize_skipped<T, T>), dim3(cdiv(m, 256)), dim3(256), 0, stream, fa);
     if (fa.ndcg && hp.n_heavy > 0) {                            // ideal-DCG values of the users with very long test rows
         fa.heavy_topv = (T *)ws.get("heavy_topv", sizeof(T) * (size_t)m * std::min(K, FIN_TOPV));
@@ -540,13 +561,8 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     }
     if (n_slots > 0) {
         if (want_auc) {
-            fa.auc_part = (AucPart *)ws.get("auc_part", sizeof(AucPart) * (size_t)n_slots);
             fa.spos_score = spos_score; fa.spos_item = spos_item; fa.shist = shist;
-            if (n_stream > 0) {
-                const int parts = (int)cdiv(n, STREAM_RANK_THREADS * STREAM_RANK_ITEMS);
-                hipLaunchKernelGGL((k_rank_streamed<T, T>), dim3((unsigned)((long long)n_stream * parts)), dim3(STREAM_RANK_THREADS), 0, stream, fa, parts);
-                hipLaunchKernelGGL((k_auc_streamed<T, T>), dim3(cdiv((long long)n_stream * WAVE, 256)), dim3(256), 0, stream, fa, n_stream);
-            }
+            if (n_stream > 0) rank_streamed_rows(0, ranked_beside ? stream_rows_done : n_stream, stream);
             if (stream_slot0 > 0) hipLaunchKernelGGL((k_auc_slots<T, T>), dim3(cdiv(stream_slot0, 256)), dim3(256), 0, stream, fa);
         }
         const size_t fin_lds = finalize_lds_bytes<T>(K, n_part);
@@ -1062,8 +1078,10 @@ extern "C" int rm_get_timings(double *out, int n)
         (void)hipEventElapsedTime(&d, cx->ev[0], cx->ev[3]);
     }
     cx->timings[0] = cx->acc[0] + a; cx->timings[1] = cx->acc[1] + b; cx->timings[2] = cx->acc[2] + c; cx->timings[3] = cx->acc[3] + d;
-    const int cnt = n < 8 ? n : 8;
-    for (int i = 0; i < cnt; i++) out[i] = cx->timings[i];
+    const int cnt = n < 10 ? n : 10;
+    for (int i = 0; i < cnt && i < 8; i++) out[i] = cx->timings[i];
+    if (cnt > 8) out[8] = cx->timed_slots;
+    if (cnt > 9) out[9] = cx->total_slots;
     return cnt;
 }
 
