@@ -85,7 +85,7 @@ class DeviceProblem:
 def load_traffic(workload, users):
     """HBM bytes per sweep launch from the committed PMC run (scratch/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in
     separate rocprofv3 passes, FETCH_SIZE doubled per the gfx950 correction); None when no matching profile exists."""
-    path = os.path.join(ROOT, "profiles", "r1_traffic_%s.json" % workload)
+    path = os.path.join(ROOT, "profiles", "r2_traffic_%s.json" % workload)
     try:
         d = json.load(open(path))
         return d["hbm_bytes"] if int(d.get("users", -1)) == int(users) else None

@@ -123,7 +123,7 @@ constexpr int STREAM_RANK_LDS = 20 * 1024;               // LDS per block: eight
 // copy are searched in global memory.  ILP independent searches per thread advance level by level, all reads of a level
 // in flight together.
 template <class S, int ILP>
-__device__ __forceinline__ void rank_streamed_lds(const S *row, long long i0, int n, const int *pit, int P, int top, int lgsb,
+__device__ __forceinline__ void rank_streamed_lds(const S *row, long long i0, int ipt, int n, const int *pit, int P, int top, int lgsb,
                                                   unsigned tab_addr, unsigned hist_addr)
 {
     typedef __attribute__((address_space(3))) const S *LdsS;
@@ -140,7 +140,7 @@ __device__ __forceinline__ void rank_streamed_lds(const S *row, long long i0, in
     };
     S nxt[ILP];
     load_batch(0, nxt);
-    for (int it = 0; it < STREAM_RANK_ITEMS; it += ILP) {
+    for (int it = 0; it < ipt; it += ILP) {
         S v[ILP]; unsigned o[ILP];                                // o = (number of positives below the candidate) * sb
         #pragma unroll
         for (int q = 0; q < ILP; q++) {                           // masked / NaN / beyond the row: bin 0
@@ -171,8 +171,8 @@ __device__ __forceinline__ void rank_streamed_lds(const S *row, long long i0, in
 }
 
 template <class T, class S>
-__global__ __launch_bounds__(STREAM_RANK_THREADS) void k_rank_streamed(FinalArgs<T, S> a, int parts, int row0)
-{
+__global__ __launch_bounds__(STREAM_RANK_THREADS) void k_rank_streamed(FinalArgs<T, S> a, int parts, int ipt, int row0)
+{   // parts = blocks per row, ipt = items per thread (a multiple of 8): the row is cut into equal pieces
     __shared__ __attribute__((aligned(16))) char rk_smem[STREAM_RANK_LDS];
     const int d = row0 + blockIdx.x / parts, part = blockIdx.x % parts;
     const int slot = a.stream_slot0 + d;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(STREAM_RANK_THREADS) void k_rank_streamed(FinalArgs
     if ((long long)top * per + P <= WORDS) { R = 1; while (R < 32 && (long long)top * 2 * R * per + P <= WORDS) R *= 2; }
     const int *pit = a.spos_item + te0;
     const S *row = a.stream_scores + (size_t)d * (size_t)a.stream_ld;
-    const long long i0 = (long long)part * STREAM_RANK_THREADS * STREAM_RANK_ITEMS;
+    const long long i0 = (long long)part * STREAM_RANK_THREADS * ipt;
     if (R > 0) {
         S *lds_s = (S *)rk_smem;                                  // [top][R]
         unsigned *lds_h = (unsigned *)(rk_smem + sizeof(S) * (size_t)top * (size_t)R);
@@ -198,13 +198,13 @@ __global__ __launch_bounds__(STREAM_RANK_THREADS) void k_rank_streamed(FinalArgs
         for (int r = R; r > 1; r >>= 1) lgsb++;
         const unsigned tab_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char *)rk_smem + (unsigned)((threadIdx.x & (R - 1)) * sizeof(S));
         const unsigned hist_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds_h;
-        rank_streamed_lds<S, 8>(row, i0, a.n, pit, P, top, lgsb, tab_addr, hist_addr);
+        rank_streamed_lds<S, 8>(row, i0, ipt, a.n, pit, P, top, lgsb, tab_addr, hist_addr);
         __syncthreads();
         for (int i = threadIdx.x; i < P; i += STREAM_RANK_THREADS) { const unsigned c = lds_h[i]; if (c) atomicAdd(&a.shist[te0 + i], c); }
     } else {                                                      // very long row: search in global memory
         const S *tab = a.spos_score + te0;
         unsigned *hist = a.shist + te0;
-        for (int it = 0; it < STREAM_RANK_ITEMS; it++) {
+        for (int it = 0; it < ipt; it++) {
             const long long item = i0 + (long long)it * STREAM_RANK_THREADS + threadIdx.x;
             if (item >= a.n) break;
             const S v = row[item];

@@ -357,17 +357,21 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         nsub = 3;
     const int tile_items = 32 * nsub, n_waves = 4 * nsub;
     const int tiles_total = (n + tile_items - 1) / tile_items;
-    // LDS admits one block per CU, so the grid runs in rounds of 256 blocks: pick the item split count whose last
-    // round is fullest (each extra split restarts the streaming top-K lists, hence the small per-split penalty).
+    // LDS admits one block per CU, so the grid runs in rounds of 256 blocks.  The item split count S trades three things
+    // (coefficients measured on MI355X, gpurun_out r2_splits*: C2, NS, C3- and C4-shaped runs):
+    //   * the last round should be full, and -- blocks differ in duration by ~ +-20 % (depth of the positive trees, streamed
+    //     users) -- there should be several rounds, so that compute units that finish early pick up more blocks:
+    //     makespan ~ max(whole rounds, rounds + 0.2);
+    //   * every block pays a fixed prologue / epilogue (tables into LDS, list sort, histogram flush) worth ~13 tiles;
+    //   * every split restarts the streaming top-K lists: ~0.4 % of a sweep per split and 10 of k_metrics.
     int n_splits = 1;
     if (n_ublocks > 0) {
         const int n_cu = 256, max_splits = std::max(1, std::min(MAX_PARTS / nsub, tiles_total / 128));
-        double best = -1;
+        double best = -1e30;
         for (int sct = 1; sct <= max_splits; sct++) {
-            const long long blocks = (long long)n_ublocks * sct;
-            const long long rounds = (blocks + n_cu - 1) / n_cu;
-            // every split restarts the streaming top-K lists: ~K ln(n / (2 S K)) extra inserts per user and split
-            const double score = (double)blocks / (double)(rounds * n_cu) - 0.004 * sct * std::max(1.0, K / 10.0);
+            const double rounds = (double)n_ublocks * sct / n_cu;
+            const double makespan = std::max(std::ceil(rounds - 1e-9), rounds + 0.2);
+            const double score = rounds / makespan - sct * (13.0 / tiles_total + 0.004 * std::max(0.25, K / 10.0));
             if (score > best + 1e-9) { best = score; n_splits = sct; }
         }
     }
@@ -417,9 +421,10 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     if (want_auc && n_slots > 0) fa.auc_part = (AucPart *)ws.get("auc_part", sizeof(AucPart) * (size_t)n_slots);
     int stream_rows_done = 0; bool ranked_beside = false;  // rows [stream_rows_done, n_stream) were ranked beside the sweep
     const int stream_parts = (int)cdiv(n, STREAM_RANK_THREADS * STREAM_RANK_ITEMS);
+    const int stream_ipt = ((int)cdiv(n, (long long)stream_parts * STREAM_RANK_THREADS) + 7) / 8 * 8;     // equal pieces of the row
     auto rank_streamed_rows = [&](int r0, int r1, hipStream_t st) {
         if (r1 <= r0) return;
-        hipLaunchKernelGGL((k_rank_streamed<T, T>), dim3((unsigned)((long long)(r1 - r0) * stream_parts)), dim3(STREAM_RANK_THREADS), 0, st, fa, stream_parts, r0);
+        hipLaunchKernelGGL((k_rank_streamed<T, T>), dim3((unsigned)((long long)(r1 - r0) * stream_parts)), dim3(STREAM_RANK_THREADS), 0, st, fa, stream_parts, stream_ipt, r0);
         hipLaunchKernelGGL((k_auc_streamed<T, T>), dim3(cdiv((long long)(r1 - r0) * WAVE, 256)), dim3(256), 0, st, fa, r0, r1);
     };
     T *pos_score = nullptr; unsigned *hist = nullptr; int *pos_order = nullptr, *pos_item = nullptr;

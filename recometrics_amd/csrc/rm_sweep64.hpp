@@ -26,24 +26,40 @@ __device__ __forceinline__ double pos_inf_d() { return __longlong_as_double(0x7f
 __device__ __forceinline__ double neg_inf_d() { return __longlong_as_double(0xfff0000000000000ll); }
 __device__ __forceinline__ double nan_sentinel_d() { return __longlong_as_double(-1ll); }
 
+// Compare / select pairs as inline asm in a software-pipelined order, the LDS reads of a level waited for in two groups: see
+// the fp32 sweep (rm_sweep.hpp, auc_pass) -- a wave pays for every issue slot, s_nop and s_waitcnt included.
+#define RM_CMP_LT64(m, p, x) asm volatile("v_cmp_lt_f64 %0, %1, %2" : "=s"(m) : "v"(p), "v"(x))
+#define RM_SEL32(d, a, b, m) asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(m))
+
 template <int J>
 __device__ __forceinline__ void auc_pass64(const double (&v)[8], const char *posb, char *histb,
                                            const int *pos_item_g, int sb, int q)
 {
+    typedef __attribute__((address_space(3))) const double *LdsF64;
+    const unsigned pos_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)posb;
     unsigned base[8];
     #pragma unroll
     for (int r = 0; r < 8; r++) base[r] = 0;
+    unsigned long long mk0, mk1, mk2;
     #pragma unroll
     for (int st = (J > 0 ? (1 << (J - 1)) : 0); st >= 1; st >>= 1) {
         double pv[8];
         #pragma unroll
-        for (int r = 0; r < 8; r++) pv[r] = *(const double *)(posb + base[r] + (st - 1) * 128);
+        for (int r = 0; r < 8; r++) pv[r] = *(LdsF64)(pos_addr + base[r] + (st - 1) * 128);
         #pragma unroll
-        for (int r = 0; r < 8; r++) base[r] = (pv[r] < v[r]) ? base[r] + st * 128 : base[r];
+        for (int i = 0; i < 8 + 2; i++) {
+            if (i == 0) __builtin_amdgcn_s_waitcnt(0xC47F); else if (i == 4) __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(4), lgkmcnt(0)
+            if (i < 8) { if (i % 3 == 0) RM_CMP_LT64(mk0, pv[i], v[i]); else if (i % 3 == 1) RM_CMP_LT64(mk1, pv[i], v[i]); else RM_CMP_LT64(mk2, pv[i], v[i]); }
+            if (i >= 2) {
+                const int j = i - 2;
+                const unsigned cand = base[j] + (unsigned)(st * 128);
+                if (j % 3 == 0) RM_SEL32(base[j], base[j], cand, mk0); else if (j % 3 == 1) RM_SEL32(base[j], base[j], cand, mk1); else RM_SEL32(base[j], base[j], cand, mk2);
+            }
+        }
     }
     double nx[8];
     #pragma unroll
-    for (int r = 0; r < 8; r++) nx[r] = *(const double *)(posb + base[r]);
+    for (int r = 0; r < 8; r++) nx[r] = *(LdsF64)(pos_addr + base[r]);
     unsigned long long tie = 0;
     #pragma unroll
     for (int r = 0; r < 8; r++) tie |= __ballot(nx[r] == v[r]);
