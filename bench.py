@@ -142,6 +142,9 @@ def cpu_baseline(host, K, n_users_total, budget_s, dtype=np.float32):
     """The CPU path on this host's cores over a bounded sample of the same workload."""
     from oracle import oracle as orc
     ncores = os.cpu_count() or 1
+    # the reference addresses its per-thread scratch as `buffer + omp_get_thread_num() * n` in int32
+    # (src/recometrics.hpp:499): more than (2^31 - 1) / n threads overflow it (214 at n = 10M; SURVEY.md section 5)
+    ncores = max(1, min(ncores, (2 ** 31 - 1) // int(host["B"].shape[0])))
     if orc.reference_available(fast=True):
         impl, kind = orc.Reference(fast=True), "reference"
     else:
