@@ -10,6 +10,22 @@ import numpy as np
 from . import _binding
 
 
+_MODES = {"all": 0, "separated": 1, "joined": 2}
+
+
+def _users_to_take(n_users, fraction, cap):
+    """number of test users (reference recometrics/__init__.py:805-815, warnings included)"""
+    if fraction is None:
+        if cap > n_users:
+            warn("'max_test_users' is larger than number of users. Will take all.")
+        return min(cap, n_users)
+    want = n_users * float(fraction)
+    if want < 1:
+        warn("Desired fraction of test users implies <1, will select 1 user.")
+        want = 1
+    return min(round(want), cap)
+
+
 def _csr(parts, n_items):
     from scipy.sparse import csr_array
     indptr, indices, data = parts
@@ -37,49 +53,34 @@ def split_reco_train_test(
     meaning of every argument; results are identical for the same ``seed``."""
     from . import _sorted_csr_int32                       # CSR normalisation shared with calc_reco_metrics
 
-    if not max_test_users:
-        max_test_users = X.shape[0]
-    assert max_test_users > 0 and seed >= 0 and min_pos_test >= 0 and min_items_pool >= 0
-    max_test_users, seed = int(max_test_users), int(seed)
-    min_pos_test, min_items_pool = int(min_pos_test), int(min_items_pool)
-    if users_test_fraction is not None:
-        assert 0 < users_test_fraction < 1
-        users_test_fraction = float(users_test_fraction)
-    assert 0 < items_test_fraction < 1
-    items_test_fraction = float(items_test_fraction)
-    assert split_type in ("all", "separated", "joined")
-
     n_users, n_items = X.shape
-    if min_pos_test >= n_items:
-        raise ValueError("'min_pos_test' must be smaller than the number of columns in 'X'.")
-    if min_items_pool >= n_items:
-        raise ValueError("'min_items_pool' must be smaller than the number of columns in 'X'.")
-
-    n_take = 0
-    if split_type != "all":
-        if n_users < 2:
-            raise ValueError("'X' has less than 2 rows.")
-        if users_test_fraction is not None:
-            n_take = n_users * users_test_fraction
-            if n_take < 1:
-                warn("Desired fraction of test users implies <1, will select 1 user.")
-                n_take = 1
-            n_take = min(round(n_take), max_test_users)
-        else:
-            if max_test_users > n_users:
-                warn("'max_test_users' is larger than number of users. Will take all.")
-            n_take = min(max_test_users, n_users)
+    mode = _MODES.get(split_type)
+    if not max_test_users:                                # None / 0: no cap
+        max_test_users = n_users
+    # argument domain (the reference asserts these, recometrics/__init__.py:771-790): one table, first violation raises
+    in_unit = lambda f: 0 < f < 1                          # noqa: E731
+    for ok in (max_test_users > 0, seed >= 0, min_pos_test >= 0, min_items_pool >= 0,
+               users_test_fraction is None or in_unit(users_test_fraction), in_unit(items_test_fraction), mode is not None):
+        assert ok
+    max_test_users, seed, min_pos_test, min_items_pool = (int(v) for v in (max_test_users, seed, min_pos_test, min_items_pool))
+    # value errors, in the reference's order and wording (:795-826)
+    for bad, message in (
+        (min_pos_test >= n_items, "'min_pos_test' must be smaller than the number of columns in 'X'."),
+        (min_items_pool >= n_items, "'min_items_pool' must be smaller than the number of columns in 'X'."),
+        (mode != 0 and n_users < 2, "'X' has less than 2 rows."),
+    ):
+        if bad:
+            raise ValueError(message)
+    n_take = _users_to_take(n_users, users_test_fraction, max_test_users) if mode != 0 else 0
 
     X = _sorted_csr_int32(X)
-    if not X.shape[0] or not X.shape[1]:
-        raise ValueError("'X' cannot be empty.")
     if X.dtype not in (np.float32, np.float64):
         X = X.astype(np.float64)
-    if not X.data.shape[0]:
-        raise ValueError("'X' contains no non-zero entries.")
+    for bad, message in ((0 in X.shape, "'X' cannot be empty."), (X.data.shape[0] == 0, "'X' contains no non-zero entries.")):
+        if bad:
+            raise ValueError(message)
 
-    mode = {"all": 0, "separated": 1, "joined": 2}[split_type]
-    res = _binding.split_csr(X.indptr, X.indices, X.data, n_items, mode, int(n_take), items_test_fraction,
+    res = _binding.split_csr(X.indptr, X.indices, X.data, n_items, mode, int(n_take), float(items_test_fraction),
                              bool(consider_cold_start), min_items_pool, min_pos_test, seed)
     if mode == 0:
         return _csr(res["train"], n_items), _csr(res["test"], n_items)
