@@ -172,6 +172,98 @@ template <class S>
 __device__ __forceinline__ void wave_compact(typename ListRaw<S>::raw *Gu, int cnt, int K, int lane, S &kth_s, int &kth_idx)
 #include "rm_compact_body.inc"
 
+// Compaction DURING the sweep does not need the survivors sorted, only to be the K best: the K-th best key is found by
+// bisection over the bits of the order-preserving key (count of entries at or above the candidate by ballots: 64 steps of a
+// few instructions per held entry, against cnt x entries for the rank count above -- about a quarter of the instructions at
+// K = 100), then the survivors are packed to the front in their old order.  The waves of a block wait for one another at
+// every tile, so the time a wave spends here is paid by all of them: compaction skew, not the appends, is what holds the
+// append-buffer variants back (profiles/r2: 35-48 % of their wave cycles parked).
+// Order: (score desc, item asc); `hi` = order-preserving score key, ties by the smaller item.
+__device__ __forceinline__ unsigned long long sel_score_key(float s) { return (unsigned long long)ord_key(s); }
+__device__ __forceinline__ unsigned long long sel_score_key(double s) { return ord_key(s); }
+// (E = entries per lane as a template constant, loads unconditional with a clamped index: with a run-time E and predicated
+// loads the compiler shuffled the register arrays through 240 VGPRs of copies)
+template <class S, int E>
+__device__ __forceinline__ void wave_select_e(typename ListRaw<S>::raw *Gu, int cnt, int K, int lane, S &kth_s, int &kth_idx)
+{
+    unsigned long long hi[E]; int it[E];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the owner lane's appends have reached L2
+    #pragma unroll
+    for (int t = 0; t < E; t++) {
+        const int i = lane + t * WAVE;
+        S es; int ei;
+        ListRaw<S>::unpack(ListRaw<S>::load_l2(Gu + (i < cnt ? i : 0)), es, ei);
+        hi[t] = i < cnt ? sel_score_key(es) : 0ull;          // key 0 is below every real score's key
+        it[t] = i < cnt ? ei : IDX_EMPTY;
+    }
+    // K-th largest score key
+    constexpr int BITS = sizeof(S) == 4 ? 32 : 64;
+    unsigned long long T = 0ull;
+    for (int bit = BITS - 1; bit >= 0; bit--) {
+        const unsigned long long cand = T | (1ull << bit);
+        int c = 0;
+        #pragma unroll
+        for (int t = 0; t < E; t++) c += __popcll(__ballot(hi[t] >= cand));
+        if (c >= K) T = cand;
+    }
+    int n_gt = 0, n_eq = 0;
+    #pragma unroll
+    for (int t = 0; t < E; t++) { n_gt += __popcll(__ballot(hi[t] > T)); n_eq += __popcll(__ballot(hi[t] == T)); }
+    // among the entries that tie the K-th score: the (K - n_gt) smallest items (usually there is exactly one such entry)
+    const int need = K - n_gt;
+    int item_max = IDX_EMPTY;                                 // keep equal-scored entries with item <= item_max
+    if (n_eq > need) {
+        unsigned I = 0u;                                      // the need-th smallest item among the ties, bit by bit
+        for (int bit = 30; bit >= 0; bit--) {
+            const unsigned cand = I | (1u << bit);
+            int c = 0;
+            #pragma unroll
+            for (int t = 0; t < E; t++) c += __popcll(__ballot(hi[t] == T && (unsigned)it[t] < cand));
+            if (c < need) I = cand;
+        }
+        item_max = (int)I;
+    }
+    // pack the survivors to the front (all entries are in registers: a write can only hit a slot already read)
+    int base = 0, worst_item = -1;
+    #pragma unroll
+    for (int t = 0; t < E; t++) {
+        const bool keep = hi[t] > T || (hi[t] == T && it[t] <= item_max);
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+            S es;
+            if (sizeof(S) == 4) es = (S)ord_unkey((unsigned)hi[t]); else es = (S)ord_unkey(hi[t]);
+            Gu[base + __popcll(m & ((1ull << lane) - 1ull))] = ListRaw<S>::pack(es, it[t]);
+        }
+        base += __popcll(m);
+        if (hi[t] == T && it[t] <= item_max && it[t] > worst_item) worst_item = it[t];
+    }
+    #pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(worst_item, d); worst_item = o > worst_item ? o : worst_item; }
+    if (sizeof(S) == 4) kth_s = (S)ord_unkey((unsigned)T); else kth_s = (S)ord_unkey(T);
+    kth_idx = worst_item;                                     // the K-th best = the tie with the largest kept item
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // survivors written before anyone appends behind them
+}
+template <class S>
+__device__ __forceinline__ void wave_select(typename ListRaw<S>::raw *Gu, int cnt, int K, int lane, S &kth_s, int &kth_idx)
+{
+    switch ((cnt + WAVE - 1) / WAVE) {                        // (2 * 256 + 32) / 64 rounded up = 9 at most
+        case 1: wave_select_e<S, 1>(Gu, cnt, K, lane, kth_s, kth_idx); break;
+        case 2: wave_select_e<S, 2>(Gu, cnt, K, lane, kth_s, kth_idx); break;
+        case 3: wave_select_e<S, 3>(Gu, cnt, K, lane, kth_s, kth_idx); break;
+        case 4: wave_select_e<S, 4>(Gu, cnt, K, lane, kth_s, kth_idx); break;
+        case 5: wave_select_e<S, 5>(Gu, cnt, K, lane, kth_s, kth_idx); break;
+        case 6: wave_select_e<S, 6>(Gu, cnt, K, lane, kth_s, kth_idx); break;
+        case 7: wave_select_e<S, 7>(Gu, cnt, K, lane, kth_s, kth_idx); break;
+        case 8: wave_select_e<S, 8>(Gu, cnt, K, lane, kth_s, kth_idx); break;
+        default: wave_select_e<S, 9>(Gu, cnt, K, lane, kth_s, kth_idx); break;
+    }
+}
+template <class S>
+__device__ __attribute__((noinline)) void wave_select_call(typename ListRaw<S>::raw *Gu, int cnt, int K, int lane, S &kth_s, int &kth_idx)
+{
+    wave_select<S>(Gu, cnt, K, lane, kth_s, kth_idx);
+}
+
 // Out-of-line form for the fp64 sweep: inlined, the nine-entry-per-lane working set is added to a register budget that
 // is already full (256 factors) and the hot loop spills; as a real call only the live registers around this rare path
 // are saved.  The fp32 sweep has the room and keeps the inlined form (a call there costs more than it saves).

@@ -257,14 +257,16 @@ void k_sweep(SweepArgs a)
         if (LLDS) Ll[i * GROUP_USERS] = 0ull; else Lr[i * GROUP_USERS] = ListRaw<float>::pack(neg_inf_f(), IDX_EMPTY);
     }
     // compaction of every owner lane in `need` (wave-uniform mask): K best kept, sorted; (ws, widx) = the K-th
-    auto compact_users = [&](unsigned long long need) {
+    auto compact_users = [&](unsigned long long need, bool final_sorted = false) {
         while (need) {
             const int l = __ffsll((long long)need) - 1;
             need &= need - 1;
             const int c = lane_bcast<int>(cnt, l);
             RM_STAT(8, 1); RM_STAT(9, c);
             float ks; int ki;
-            wave_compact<float>(Gw + (size_t)l * CAP, c, K, lane, ks, ki);
+            // during the sweep the K best need not be sorted (bisection select); the list handed to k_finalize must be
+            if (final_sorted || c < K) wave_compact<float>(Gw + (size_t)l * CAP, c, K, lane, ks, ki);
+            else wave_select_call<float>(Gw + (size_t)l * CAP, c, K, lane, ks, ki);
             if (lane == l) { cnt = c < K ? c : K; if (c >= K) { ws = ks; widx = ki; } }
         }
     };
@@ -650,7 +652,7 @@ void k_sweep(SweepArgs a)
             for (int i = 0; i < K; i++) ListRaw<float>::unpack(Lr[i * GROUP_USERS], dst[i].s, dst[i].idx);
         }
     } else if (!LLDS && !a.ext_topk) {
-        compact_users(__ballot(slot_ok && h == 0 && primary && cnt > 0));
+        compact_users(__ballot(slot_ok && h == 0 && primary && cnt > 0), true);
         if (slot_ok && h == 0) {
             ListEntry *dst = a.pl + ((size_t)slot * n_part + part) * K;
             for (int i = 0; i < K; i++) {

@@ -171,7 +171,7 @@ void k_sweep64(Sweep64Args a)
     if (q == 0 && (LLDS || !buffered)) for (int i = 0; i < K; i++) {
         if (LLDS) Ll[i * GU] = ListRaw<double>::pack(neg_inf_d(), IDX_EMPTY); else Lr[i * GU] = ListRaw<double>::pack(neg_inf_d(), IDX_EMPTY);
     }
-    auto compact_users = [&](unsigned long long need) {
+    auto compact_users = [&](unsigned long long need, bool final_sorted = false) {
         while (need) {
             const int l = __ffsll((long long)need) - 1;
             need &= need - 1;
@@ -180,7 +180,9 @@ void k_sweep64(Sweep64Args a)
 #ifdef RM_ABL_NO_COMPACT
             ks = 1e300; ki = 0;
 #else
-            wave_compact_call<double>(Gw + (size_t)l * CAP, c, K, lane, ks, ki);
+            // during the sweep the K best need not be sorted (bisection select); the list handed to k_finalize must be
+            if (final_sorted || c < K) wave_compact_call<double>(Gw + (size_t)l * CAP, c, K, lane, ks, ki);
+            else wave_select_call<double>(Gw + (size_t)l * CAP, c, K, lane, ks, ki);
 #endif
             if (lane == l) { cnt = c < K ? c : K; if (c >= K) { ws = ks; widx = ki; } }
         }
@@ -470,7 +472,7 @@ void k_sweep64(Sweep64Args a)
             for (int i = 0; i < K; i++) ListRaw<double>::unpack(Lr[i * GU], dst[i].s, dst[i].idx);
         }
     } else if (!LLDS && !a.ext_topk) {
-        compact_users(__ballot(slot_ok && q == 0 && primary && cnt > 0));
+        compact_users(__ballot(slot_ok && q == 0 && primary && cnt > 0), true);
         if (slot_ok && q == 0) {
             Entry<double> *dst = a.pl + ((size_t)slot * n_part + part) * K;
             for (int i = 0; i < K; i++) {
