@@ -35,8 +35,12 @@ __global__ void k_count_long(int m, const int *test_p, Plan *plan, const unsigne
     const int npos = (u < m && !(only && !only[u])) ? test_p[u + 1] - test_p[u] : 0;
     const bool lng = npos > POS_CHUNK;
     const unsigned long long mk = __ballot(lng);
-    if (mk && (threadIdx.x & 63) == __ffsll((long long)mk) - 1) atomicAdd(&plan->n_long, __popcll(mk));
-    if (lng) atomicMax(&plan->max_npos, npos);
+    if (mk) {                                                  // one atomic pair per wave that has any
+        int mx = lng ? npos : 0;
+        #pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+        if ((threadIdx.x & 63) == __ffsll((long long)mk) - 1) { atomicAdd(&plan->n_long, __popcll(mk)); atomicMax(&plan->max_npos, mx); }
+    }
 }
 __global__ void k_decide_stream(Plan *plan, long long cap) { plan->stream_enable = plan->n_long > 0 && plan->n_long <= cap; }
 
@@ -258,11 +262,25 @@ __global__ void k_absmax(const T *X, size_t ld, long long rows, int k, unsigned 
 {
     double mx = 0.; bool bad = false;
     const long long total = rows * k;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const double x = (double)X[(size_t)(i / k) * ld + (i % k)];
+    auto take = [&](T xv) {
+        const double x = (double)xv;
         const double ax = x < 0 ? -x : x;
         bad |= !(ax <= 1.7976931348623157e308);          // NaN or Inf
         mx = ax > mx ? ax : mx;
+    };
+    if (ld == (size_t)k && (((size_t)X) & 15) == 0) {      // dense rows: one flat array, 16-byte loads, no division per element
+        constexpr int V = 16 / (int)sizeof(T);
+        typedef T VecT __attribute__((ext_vector_type(16 / sizeof(T))));
+        const long long nv = total / V;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+            const VecT q = ((const VecT *)X)[i];
+            #pragma unroll
+            for (int e = 0; e < V; e++) take(q[e]);
+        }
+        for (long long i = nv * V + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) take(X[i]);
+    } else {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+            take(X[(size_t)(i / k) * ld + (i % k)]);
     }
     #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
