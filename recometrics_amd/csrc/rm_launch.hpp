@@ -25,6 +25,9 @@ struct SweepArgs {
     const float4 *Ap, *Bp;
     const int *slot_user, *slot_chunk;
     const int *train_p, *train_i;
+    // optional dense form of the train rows (small item counts): bit i of train_bits[user * train_words + (item >> 5)] = item is
+    // a train item of the user OR lies beyond n; one load per lane and tile replaces the cursor walk over the CSR row
+    const unsigned *train_bits; int train_words;
     const int *gj; const long long *grow;
     const float *pos_score;               // [(total_rows + n_groups)][32]  sorted positives, +inf padded (2^j rows per group)
     const int *pos_item;                  // same shape, item ids (read only when a candidate ties a positive's score)

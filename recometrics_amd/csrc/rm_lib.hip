@@ -219,6 +219,23 @@ inline void pack_operands(const double *A, size_t lda, const double *B, size_t l
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
+// Dense train rows for the fp32 sweep when they are small (m * n / 8 bytes <= 1 GiB, e.g. 463 MB at BASELINE C2): with ~100
+// train items per user among 27k items, some lane of a wave has one in nearly every 32-item sub-tile, and the per-item walk of
+// the CSR cursor (compare, consume, reload, loop) was 9 % of the C2 sweep; one word per lane and tile replaces it.
+template <class C> inline void set_train_bits(SweepArgs &sa, Workspace &ws, const C &c, int m, int n, long long n_pad, hipStream_t stream)
+{
+    const long long words = (n_pad + 31) / 32;
+    const size_t bytes = (size_t)m * (size_t)words * 4;
+    sa.train_bits = nullptr; sa.train_words = 0;
+    if (bytes > ((size_t)1 << 30) || words > TRAIN_BITS_MAX_WORDS || getenv("RM_DEBUG_NO_TRAIN_BITS")) return;
+    unsigned *bits = (unsigned *)ws.get("train_bits", bytes);
+    const unsigned blocks = (unsigned)std::min<long long>(((long long)m + TRAIN_BITS_WAVES - 1) / TRAIN_BITS_WAVES, 256 * 8);
+    hipLaunchKernelGGL(k_train_bits, dim3(blocks), dim3(TRAIN_BITS_WAVES * WAVE), sizeof(unsigned) * (size_t)TRAIN_BITS_WAVES * (size_t)words, stream,
+                       m, n, (int)words, c.train_p, c.train_i, bits);
+    sa.train_bits = bits; sa.train_words = (int)words;
+}
+template <class C> inline void set_train_bits(Sweep64Args &, Workspace &, const C &, int, int, long long, hipStream_t) {}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // device pipeline (T = float: v_mfma_f32_32x32x2_f32 sweep; T = double: v_mfma_f64_16x16x4_f64 sweep)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -495,6 +512,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         P::set_pending(sa, pend_cap, (int)pend_off);
         P::set_sync(sa, (int)sync_off);
         sa.stream_slot0 = stream_slot0; sa.stream_ld = stream_ld; sa.stream_scores = stream_scores;
+        set_train_bits(sa, ws, c, m, n, tiles_total * tile_items, stream);
         sa.noise_row = c.noise_row; sa.noise_row0 = c.noise_row0; sa.noise_E = c.noise_E; sa.noise_ld = c.noise_ld;
 
         HIP_CHECK(hipEventRecord(g_ev[1], stream));

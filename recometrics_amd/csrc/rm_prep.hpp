@@ -291,6 +291,30 @@ __global__ void k_absmax(const T *X, size_t ld, long long rows, int k, unsigned 
     }
 }
 
+// dense train rows for the sweep (SweepArgs::train_bits): one wavefront per user builds the row in LDS (coalesced reads of the
+// CSR row, LDS atomic OR per item, the padding beyond n set) and writes it out in one coalesced sweep -- every word of the
+// buffer is written, no memset.  words <= TRAIN_BITS_MAX_WORDS.
+constexpr int TRAIN_BITS_MAX_WORDS = 4096;            // 131,072 items: 16 KiB of LDS per wavefront
+constexpr int TRAIN_BITS_WAVES = 4;
+__global__ __launch_bounds__(TRAIN_BITS_WAVES * WAVE) void k_train_bits(int m, int n, int words, const int *train_p, const int *train_i, unsigned *bits)
+{
+    extern __shared__ unsigned tb_lds[];                      // [TRAIN_BITS_WAVES][words]
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned *row = tb_lds + (size_t)wv * words;
+    for (int u = blockIdx.x * TRAIN_BITS_WAVES + wv; u < m; u += gridDim.x * TRAIN_BITS_WAVES) {
+        for (int w = lane; w < words; w += WAVE) row[w] = (w << 5) >= n ? 0xffffffffu : (((w << 5) + 32 > n) ? (0xffffffffu << (n & 31)) : 0u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int e = train_p[u] + lane; e < train_p[u + 1]; e += WAVE) { const int item = train_i[e]; atomicOr(&row[item >> 5], 1u << (item & 31)); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        unsigned *out = bits + (size_t)u * words;
+        for (int w = lane; w < words; w += WAVE) out[w] = row[w];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <class T> __global__ void k_fill(T *p, T v, long long count)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

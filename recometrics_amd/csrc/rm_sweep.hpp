@@ -224,7 +224,9 @@ void k_sweep(SweepArgs a)
     const int t0 = split * tiles_per, t1 = min(a.tiles_total, t0 + tiles_per);
     const int ntiles = max(0, t1 - t0);
 
-    if (user >= 0) {
+    // dense train rows (small item counts): one word per lane and tile instead of the cursor below
+    const unsigned *tb_row = (a.train_bits && user >= 0) ? a.train_bits + (size_t)user * a.train_words : nullptr;
+    if (user >= 0 && !a.train_bits) {
         ntc = a.train_p[user]; nte = a.train_p[user + 1];
         // first train item at or after this wave's first item (lower_bound)
         const int first_item = t0 * TILE;
@@ -389,7 +391,7 @@ void k_sweep(SweepArgs a)
 
     // ---- epilogue of one 32-item x 32-user tile ----
     unsigned thr_pub = 0;                                       // last key this lane published / observed
-    auto do_epi = [&](const f32x16 &acc, int tile, unsigned thr_seen) {
+    auto do_epi = [&](const f32x16 &acc, int tile, unsigned thr_seen, unsigned tile_bits) {
         const int sb = tile * TILE + sub * 32;            // first item of this wave's sub-tile
         float v[16];
         #pragma unroll
@@ -407,10 +409,10 @@ void k_sweep(SweepArgs a)
 #ifdef RM_ABL_NO_MASK
         const bool slow = false;
 #else
-        const bool slow = __any(nt < sb + 32) || (sb + 32 > n);
+        const bool slow = a.train_bits ? __any(tile_bits != 0u) : (__any(nt < sb + 32) || (sb + 32 > n));
 #endif
         if (slow) {
-            unsigned mbits = 0;
+            unsigned mbits = tile_bits;                           // (dense rows: train items and the padding beyond n, ready-made)
             // `nt2` was loaded when the previous item was consumed, in an earlier step, and is drained by that step's
             // closing wait: the first consumption of a step (peeled) needs no wait-count.  Only a lane that consumes a
             // second item in the same step waits for its own fresh load (and with it for the tile prefetch).
@@ -420,11 +422,13 @@ void k_sweep(SweepArgs a)
                 nt = nt2;
                 nt2 = ntc + 1 < nte ? a.train_i[ntc + 1] : IDX_EMPTY;
             };
-            if (nt < sb + 32) {
-                consume();
-                while (nt < sb + 32) consume();
+            if (!a.train_bits) {
+                if (nt < sb + 32) {
+                    consume();
+                    while (nt < sb + 32) consume();
+                }
+                if (sb + 32 > n) mbits |= (n > sb) ? (0xffffffffu << (n - sb)) : 0xffffffffu;
             }
-            if (sb + 32 > n) mbits |= (n > sb) ? (0xffffffffu << (n - sb)) : 0xffffffffu;
             // the sentinel is all ones: OR-ing the sign-extended mask bit into the score masks it (2 VALU per register)
             // (skipping the registers no lane masks, by a scalar union of the lanes' patterns, was measured 2-4 % SLOWER:
             // the scalar loop and 16 branches are more issue slots than the 25 vector instructions they save)
@@ -608,6 +612,9 @@ void k_sweep(SweepArgs a)
             if (unit + 1 < nunits) stage(t0 * NC + unit + 1, (unit + 1) & 1);   // that buffer was last read one unit ago
 #endif
             if (c == 0) thr_next = load_thr();
+            // this tile's word of the dense train row: in flight during the MFMA phase, drained by the wait at the arrive point
+            unsigned tile_bits = 0u;
+            if (c == NC - 1 && tb_row) tile_bits = tb_row[((t0 + i) * TILE + sub * 32) >> 5];
 #ifndef RM_ABL_NO_MFMA
             do_mfma(acc, unit & 1, c);
 #endif
@@ -618,7 +625,7 @@ void k_sweep(SweepArgs a)
             if (lane == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
 #ifndef RM_ABL_NO_EPI
-            if (c == NC - 1) do_epi(acc, t0 + i, thr_seen);
+            if (c == NC - 1) do_epi(acc, t0 + i, thr_seen, tile_bits);
 #endif
 #if defined(RM_FULL_BARRIER)
             __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                              // the DMA of the next unit has landed
