@@ -502,6 +502,9 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         typedef typename std::remove_pointer<decltype(typename P::Args{}.thr_shared)>::type ThrT;
         ThrT *thr_shared = (ThrT *)ws.get("thr_shared", sizeof(ThrT) * (size_t)n_slots);
         HIP_CHECK(hipMemsetAsync(thr_shared, 0, sizeof(ThrT) * (size_t)n_slots, stream));
+        if (want_auc && !ext_topk && !getenv("RM_DEBUG_NO_SEED"))
+            hipLaunchKernelGGL((k_seed_thresholds<T, ThrT>), dim3(cdiv(n_slots, 256)), dim3(256), 0, stream, n_slots, stream_slot0, K, GU, slot_user, slot_chunk,
+                               user_nslots, flags, c.test_p, grow, pos_score, spos_score, thr_shared);
         typename P::Args sa{};
         sa.thr_shared = thr_shared;
         sa.n = n; sa.K = K; sa.ngt = NG; sa.n_slots = n_slots; sa.n_groups = n_groups; sa.n_ublocks = n_ublocks;
