@@ -114,7 +114,7 @@ __global__ void k_auc_slots(FinalArgs<T, S> a)
 // item asc: a candidate outranks the equal-scored positives with a LARGER item id), and bin b = "exactly b positives rank
 // below the candidate" is counted at shist[test_p[u] + b - 1] (bin 0, below every positive, is never needed).
 constexpr int STREAM_RANK_THREADS = 256;
-constexpr int STREAM_RANK_ITEMS = 64;                    // items per thread and block
+constexpr int STREAM_RANK_ITEMS = 128;                   // items per thread and block (at most; rows are cut into equal pieces)
 constexpr int STREAM_RANK_LDS = 20 * 1024;               // LDS per block: eight blocks per CU
 // The LDS copy of the sorted positives is padded with +inf to a power of two (no bounds test in the search) and
 // REPLICATED R times ([entry][R copies], lane l reads copy l mod R): with R = 32 lane l always hits bank l whatever it
