@@ -73,20 +73,28 @@ __global__ __launch_bounds__(MT_WAVES * WAVE) void k_mt_draws(const int *row_use
 }
 
 template <class T> __device__ __forceinline__ T noise_from_draws(const unsigned *d, long long c);
+// NO fused multiply-add here: the reference rounds r * (b - a) before it adds a, and HIP's __fmul_rn / __fadd_rn are plain
+// operators that the compiler's default -ffp-contract=fast fuses (found by scratch/fuzz.py: one noise value in ten was an ulp
+// off, and an exact tie of two noisy scores in the reference was not a tie here).
 template <> __device__ __forceinline__ float noise_from_draws<float>(const unsigned *d, long long c)
 {
-    float r = __fmul_rn((float)d[c], 2.3283064365386963e-10f);                 // float(d) / 2^32 (exact scaling)
+#pragma clang fp contract(off)
+    float r = (float)d[c] * 2.3283064365386963e-10f;                            // float(d) / 2^32 (exact scaling)
     if (r >= 1.0f) r = 0.99999994f;                                             // nextafter(1.0f, 0.0f)
     const float a = (float)(-1e-12), b = (float)1e-12;
-    return __fadd_rn(__fmul_rn(r, __fsub_rn(b, a)), a);
+    const float scaled = r * (b - a);
+    return scaled + a;
 }
 template <> __device__ __forceinline__ double noise_from_draws<double>(const unsigned *d, long long c)
 {
-    const double sum = __dadd_rn((double)d[2 * c], __dmul_rn((double)d[2 * c + 1], 4294967296.0));
-    double r = __dmul_rn(sum, 5.421010862427522e-20);                           // / 2^64 (exact scaling)
+#pragma clang fp contract(off)
+    const double high = (double)d[2 * c + 1] * 4294967296.0;
+    const double sum = (double)d[2 * c] + high;
+    double r = sum * 5.421010862427522e-20;                                     // / 2^64 (exact scaling)
     if (r >= 1.0) r = 0.9999999999999999;                                       // nextafter(1.0, 0.0)
     const double a = -1e-12, b = 1e-12;
-    return __dadd_rn(__dmul_rn(r, __dsub_rn(b, a)), a);
+    const double scaled = r * (b - a);
+    return scaled + a;
 }
 
 // E[row][item] = noise the reference adds to that item's score for the row's user (0 for train items and the padding):

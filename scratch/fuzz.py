@@ -19,16 +19,18 @@ for it in range(cases):
     m = int(rng.choice([1, 7, 33, 100, 300, 700, 1500]))
     n = int(rng.choice([20, 97, 300, 1111, 4000, 12000]))
     k = int(rng.choice([1, 5, 16, 33, 64, 100, 128, 200, 300]))
-    K = int(min(n - 1, rng.choice([1, 3, 10, 20, 33, 60, 100, 256])))
-    k = int(rng.choice([k, k, 500])) if rng.random() < 0.1 else k
+    K = int(min(n - 1, rng.choice([1, 3, 10, 20, 33, 60, 100, 256, 300, 600])))
+    k = int(rng.choice([k, 500, 520, 1100])) if rng.random() < 0.1 else k
     mean_c = float(min(n / 6, rng.choice([4, 20, 60, 150, 500, 900])))
     allm = ("p", "tp", "r", "ap", "tap", "ndcg", "hit", "rr", "roc", "pr")
     metrics = allm if rng.random() < 0.6 else tuple(x for x in allm if rng.random() < 0.4) or ("ndcg",)
     if "pr" in metrics and "roc" not in metrics: metrics = metrics + ("roc",)       # deviation D2
     if set(metrics) <= {"hit", "rr"}: metrics = metrics + ("p",)                      # deviation D1
-    kw = dict(cumulative=bool(rng.random() < 0.3), cold=bool(rng.random() < 0.7), noise=bool(rng.random() < 0.2), metrics=metrics,
-              min_items_pool=int(rng.choice([1, 2, 10])), min_pos_test=int(rng.choice([1, 1, 3])))
+    kw = dict(cumulative=bool(rng.random() < 0.3), cold=bool(rng.random() < 0.7), noise=bool(rng.random() < 0.45), metrics=metrics,
+              min_items_pool=int(rng.choice([1, 2, 10])), min_pos_test=int(rng.choice([1, 1, 3])), seed=int(rng.choice([1, 7, 2 ** 35 + 3])))
     pr = make_problem(m, n, k, dtype, mean_c=mean_c, seed=int(rng.integers(1 << 30)))
+    if kw["noise"] and rng.random() < 0.5:          # cold items: blocks of exactly tied scores that only the noise orders
+        pr["B"] = pr["B"].copy(); pr["B"][rng.random(n) < 0.2] = 0
     try:
         want = oracle.calc(pr["A"], pr["B"], pr["train"], pr["test"], K, dtype=dtype, nthreads=8, **kw)
         got = hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], K, dtype=dtype, **kw)
@@ -41,11 +43,14 @@ for it in range(cases):
             d = np.nanmax(np.abs(np.where(np.isnan(g), 0, g).astype(np.float64) - np.where(np.isnan(w), 0, w))) if g.size else 0.0
             if not nan_ok or d > 1e-5:
                 msg.append("%s nan_ok=%s maxdiff=%g" % (name, nan_ok, d))
-            elif name not in ("ROC_AUC", "PR_AUC") and not kw["noise"] and not same_bits(g, w).all():
+            elif name != "ROC_AUC" and not same_bits(g, w).all():
                 msg.append("%s not bitwise (%d)" % (name, (~same_bits(g, w)).sum()))
-        wr = oracle.rank(pr["A"], pr["B"], pr["train"], pr["test"], K, dtype=dtype, nthreads=8)
+        rkw = dict(noise=kw["noise"], seed=kw["seed"], cold=kw["cold"], min_items_pool=kw["min_items_pool"], min_pos_test=kw["min_pos_test"])
+        wr = oracle.rank(pr["A"], pr["B"], pr["train"], pr["test"], K, dtype=dtype, nthreads=8, **rkw)
         trp, tri = pr["train"]; tei = pr["test"][1]
-        gr = hip.rank(np.ascontiguousarray(pr["A"], dtype), np.ascontiguousarray(pr["B"], dtype), trp, tri, tep, tei, K)
+        gr = hip.rank(np.ascontiguousarray(pr["A"], dtype), np.ascontiguousarray(pr["B"], dtype), trp, tri, tep, tei, K,
+                      break_ties_with_noise=kw["noise"], seed=kw["seed"], consider_cold_start=kw["cold"], min_items_pool=kw["min_items_pool"],
+                      min_pos_test=kw["min_pos_test"])
         if not (gr["status"] == wr["status"]).all(): msg.append("status")
         if not (gr["topk_idx"] == wr["topk_idx"]).all(): msg.append("topk_idx")
         if not (gr["pos_rank"] == wr["pos_rank"]).all(): msg.append("pos_rank")

@@ -244,6 +244,28 @@ def test_tie_noise_rankings_equal_the_oracle(hip, oracle, dtype, budget, monkeyp
                 assert_same_bits(got[name], want[name], "%s cumulative=%s (bitwise, noise on)" % (name, cumulative))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_tie_noise_values_bit_for_bit(hip, oracle, dtype):
+    """every candidate's noisy score (the whole ranking of a few users: k_metrics = candidates - 1) equals the oracle's bit
+    for bit.  Pins the libstdc++ arithmetic of the noise itself -- r * (b - a) rounded BEFORE a is added: a fused multiply-add
+    there (the compiler's default contraction) leaves one value in ten an ulp off, which no top-10 list notices but an exact
+    tie of two noisy scores does (found by scratch/fuzz.py)."""
+    from recometrics_amd.synth import make_problem
+    pr = make_problem(5, 3000, 12, dtype, mean_c=200, seed=77)
+    pr["B"] = pr["B"].copy()
+    pr["B"][np.random.default_rng(1).random(3000) < 0.3] = 0           # zero scores: the noise IS the score
+    trp, tri = pr["train"]
+    tep, tei = pr["test"][:2]
+    K = 3000 - int(np.diff(trp).max()) - 1
+    for seed in (1, 2 ** 40 + 9):
+        want = oracle.rank(pr["A"], pr["B"], pr["train"], pr["test"], K, dtype=dtype, nthreads=NT, noise=True, seed=seed)
+        got = hip.rank(np.ascontiguousarray(pr["A"], dtype), np.ascontiguousarray(pr["B"], dtype), trp, tri, tep, tei, K,
+                       break_ties_with_noise=True, seed=seed)
+        assert (got["topk_idx"] == want["topk_idx"]).all(), "full rankings differ"
+        assert_same_bits(got["topk_score"], want["topk_score"], "noisy scores of every candidate")
+        assert (got["pos_rank"] == want["pos_rank"]).all()
+
+
 def test_rank_outputs_do_not_depend_on_the_previous_call(hip, oracle):
     """the device workspace is reused between calls: users that are never ranked (here: all candidates fit into K, no
     AUC tables) must report rank 0 whatever an earlier, larger problem left behind"""
