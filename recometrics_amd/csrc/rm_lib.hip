@@ -219,6 +219,16 @@ inline void pack_operands(const double *A, size_t lda, const double *B, size_t l
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
+// HBM the score rows of streamed users (and of every user when k_metrics > 256) may take: a third of what is free now, or
+// RM_STREAM_BUDGET_MB (tests)
+inline long long stream_budget_bytes()
+{
+    if (const char *e = getenv("RM_STREAM_BUDGET_MB")) return atoll(e) << 20;
+    size_t fr = 0, tot = 0;
+    HIP_CHECK(hipMemGetInfo(&fr, &tot));
+    return (long long)(fr / 3);
+}
+
 // Dense train rows for the fp32 sweep when they are small (m * n / 8 bytes <= 1 GiB, e.g. 463 MB at BASELINE C2): with ~100
 // train items per user among 27k items, some lane of a wave has one in nearly every 32-item sub-tile, and the per-item walk of
 // the CSR cursor (compare, consume, reload, loop) was 9 % of the C2 sweep; one word per lane and tile replaces it.
@@ -286,10 +296,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     // k_select_topk picks its top-K from the stored row -- any k_metrics <= n, at one score row of HBM per user
     const bool ext_topk = K > 256 || getenv("RM_DEBUG_EXT_TOPK") != nullptr;
     if (want_auc || ext_topk) {
-        long long budget;
-        if (const char *e = getenv("RM_STREAM_BUDGET_MB")) budget = atoll(e) << 20;
-        else { size_t fr = 0, tot = 0; HIP_CHECK(hipMemGetInfo(&fr, &tot)); budget = (long long)(fr / 3); }
-        const long long cap = budget / (stream_ld_max * (long long)sizeof(T));
+        const long long cap = stream_budget_bytes() / (stream_ld_max * (long long)sizeof(T));
         if (ext_topk) {
             if (m > cap) throw RmError{RM_ERR_NOMEM, "k_metrics > 256 keeps one score row (" + std::to_string(stream_ld_max * (long long)sizeof(T)) +
                                        " B) per user in device memory: " + std::to_string(m) + " users do not fit, at most " + std::to_string(cap) + " per call"};
@@ -819,11 +826,9 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     if (const char *e = getenv("RM_BATCH_USERS")) bu = atof(e);      // tests
     long long batch = (long long)std::min<double>(std::max(bu, 1024.0), 2.0e9);
     batch = (batch + 1023) / 1024 * 1024;
-    if (K > 256) {                                                   // one score row per user of the batch (run(): ext_topk)
-        size_t fr = 0, tot = 0;
-        HIP_CHECK(hipMemGetInfo(&fr, &tot));
-        const long long row = (((long long)n + 191) / 192 * 192) * (long long)sizeof(T) + 16ll * K;
-        batch = std::max<long long>(1, std::min<long long>(batch, (long long)(fr / 4) / row));
+    if (K > 256) {                                                   // one score row per user of the batch (run(): ext_topk),
+        const long long row = (((long long)n + 191) / 192 * 192) * (long long)sizeof(T);    // with a margin for what run() allocates first
+        batch = std::max<long long>(1, std::min<long long>(batch, stream_budget_bytes() * 3 / 4 / row));
     }
     SignalGuard *sg = nullptr;                                       // the caller's guard polls; here only the flag is read
     (void)sg;

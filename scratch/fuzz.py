@@ -43,6 +43,8 @@ for it in range(cases):
             d = np.nanmax(np.abs(np.where(np.isnan(g), 0, g).astype(np.float64) - np.where(np.isnan(w), 0, w))) if g.size else 0.0
             if not nan_ok or d > 1e-5:
                 msg.append("%s nan_ok=%s maxdiff=%g" % (name, nan_ok, d))
+            elif name == "PR_AUC" and "RM_STREAM_BUDGET_MB" in os.environ:      # chunked sums of long rows: 1e-12
+                if d > 1e-12: msg.append("PR_AUC maxdiff=%g" % d)
             elif name != "ROC_AUC" and not same_bits(g, w).all():
                 msg.append("%s not bitwise (%d)" % (name, (~same_bits(g, w)).sum()))
         rkw = dict(noise=kw["noise"], seed=kw["seed"], cold=kw["cold"], min_items_pool=kw["min_items_pool"], min_pos_test=kw["min_pos_test"])
