@@ -18,7 +18,8 @@
 //                  that the factor axis is streamed in 128-factor chunks); packed item tiles (rm_prep.hpp
 //                  k_pack_items) stream HBM -> LDS by LDS-DMA (inline asm), double buffered.
 //   synchronisation  a split barrier on an LDS arrival counter instead of s_barrier per tile: arrive after the tile's
-//                  last MFMA, wait before the next tile touches the buffers, the whole epilogue in between.
+//                  last MFMA, wait before the next tile touches the buffers, the whole epilogue in between -- per
+//                  sub-tile (the four waves that stage and read the same 32 items), not per block.
 //   diagnostics    the RM_ABL_* macros compile single stages out (wrong results, timing only): they are how the cost
 //                  breakdown in DESIGN.md was measured and are never defined in a product build.
 #pragma once
@@ -335,9 +336,11 @@ void k_sweep(SweepArgs a)
     const float *noise_lane = (a.noise_E && user >= 0)
         ? a.noise_E + (size_t)(a.noise_row ? a.noise_row[user] - a.noise_row0 : user) * (size_t)a.noise_ld : nullptr;
 
-    // ---- staging: packed tile (BUF_F4 float4, contiguous) HBM -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging
-    // registers, the wave never waits for the bytes before the end-of-step barrier.  One wave-instruction moves 1 KiB
-    // (64 lanes x 16 B) to a lane-linear LDS image, which is exactly how the packed tile is laid out. ----
+    // ---- staging: packed tile (BUF_F4 float4, [g][h][TILE items]) HBM -> LDS by LDS-DMA (global_load_lds_dwordx4): no
+    // staging registers, the wave never waits for the bytes before the end-of-step barrier.  One wave-instruction moves
+    // 1 KiB (64 lanes x 16 B, two 512-byte runs of the packed tile) to a lane-linear piece of the LDS image, which is
+    // laid out [sub][g][h][32 items]: a sub-tile's 32 items are staged by the four waves that read them (one per user
+    // group) and by nobody else, so those four are a synchronisation domain of their own (main loop). ----
     auto stage = [&](int unit, int buf) {                     // unit = tile * NC + chunk: contiguous in the packed image
 #ifdef RM_ABL_SAME_TILE
         const float4 *src = a.Bp + (size_t)(unit & 7) * BUF_F4;
@@ -349,21 +352,21 @@ void k_sweep(SweepArgs a)
         // the DMA's LDS write and puts s_waitcnt vmcnt(0) in front of the MFMA operand reads, which serialises the
         // prefetch with the step it was meant to overlap.  The wait that matters is the explicit one before the
         // end-of-step barrier.
-        constexpr int PIECES = BUF_F4 / 64;                       // 1 KiB each
         #pragma unroll
-        for (int j = 0; j < (PIECES + NWAVES - 1) / NWAVES; j++) {
-            const int pc = wave + NWAVES * j;
-            if (PIECES % NWAVES == 0 || pc < PIECES) {
-                const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)(dst + pc * 64));
+        for (int j = 0; j < (NG + 3) / 4; j++) {
+            const int g = gi + 4 * j;
+            if (NG % 4 == 0 || g < NG) {
+                const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)(dst + (sub * NG + g) * 64));
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-                             :: "s"(m0v), "v"(src + pc * 64 + lane) : "memory", "m0");
+                             :: "s"(m0v), "v"(src + g * 2 * TILE + h * TILE + sub * 32 + ul) : "memory", "m0");
             }
         }
     };
 
     // ---- MFMA: 32 items (registers) x 32 users (lanes), k in index order ----
     auto do_mfma = [&](f32x16 &acc, int buf, int chunk) {
-        const float4 *bb = ldsB + buf * BUF_F4 + h * TILE + sub * 32 + ul;
+        const float4 *bb = ldsB + buf * BUF_F4 + sub * NG * 64 + h * 32 + ul;      // LDS image [sub][g][h][32 items]
+        constexpr int G_STRIDE = 64;
         if (!AF_RESIDENT && !AF_PREFETCH) {
             #pragma unroll
             for (int g = 0; g < NG; g++) af[g] = af_src[(size_t)(chunk * NG + g) * 2 * GROUP_USERS];
@@ -379,7 +382,7 @@ void k_sweep(SweepArgs a)
         const int next_chunk = chunk + 1 == NC ? 0 : chunk + 1;
         #pragma unroll
         for (int g = 0; g < NG; g++) {
-            const float4 b = bb[g * 2 * TILE];
+            const float4 b = bb[g * G_STRIDE];
             const float4 u = af[g];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, u.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, u.y, acc, 0, 0, 0);
@@ -574,15 +577,18 @@ void k_sweep(SweepArgs a)
     // two waves of a SIMD run in phase: both chains back to back, then both epilogues sharing the VALU at full rate. ----
     f32x16 acc;
     const int nunits = ntiles * NC;
-    // Synchronisation between the 8 waves is a SPLIT barrier on an LDS counter, not s_barrier: a wave "arrives" for
-    // unit u once it has issued its last MFMA of the unit (its LDS reads of that buffer are done) and its share of the
-    // next unit's DMA has landed; it only "waits" -- for all 8 arrivals of unit u -- right before it touches the
-    // buffers again at the start of unit u + 1.  The whole epilogue sits between the two, so a wave whose epilogue
-    // runs long (train-mask walk, top-K merge, tie path) delays the others only when it is a full epilogue behind,
-    // instead of at every tile.  Arrivals of unit u + 1 cannot start before all of unit u are in, so one monotonic
-    // counter is unambiguous: all arrived for unit u  <=>  counter >= 8 (u + 1).
-    LdsU32Ptr arrive = (LdsU32Ptr)(smem + a.sync_off);
-    if (tid == 0) *arrive = 0u;
+    // Synchronisation is a SPLIT barrier on an LDS counter, not s_barrier, and its domain is the FOUR waves that share a
+    // 32-item sub-tile (one per user group / SIMD), not the block: a wave "arrives" for unit u once it has issued its last
+    // MFMA of the unit (its LDS reads of that buffer are done) and its share of the next unit's DMA has landed; it only
+    // "waits" -- for the 4 arrivals of unit u -- right before it touches the buffers again at the start of unit u + 1.
+    // The whole epilogue sits between the two, so a wave whose epilogue runs long (train-mask walk, top-K merge, tie path)
+    // delays its three partners only when it is a full epilogue behind, and the other sub-tiles' waves (its SIMD
+    // neighbours) never: they drift apart freely and fill the vector pipe while it waits (12 -> 4 waves per domain:
+    // -3.8 % at C2, gpurun_out r4a).  Arrivals of unit u + 1 cannot start before all of unit u are in, so one monotonic
+    // counter per sub-tile is unambiguous: all arrived for unit u  <=>  counter >= 4 (u + 1).
+    constexpr unsigned SYNC_WAVES = 4;
+    LdsU32Ptr arrive = (LdsU32Ptr)(smem + a.sync_off) + sub;
+    if (tid < 4) ((LdsU32Ptr)(smem + a.sync_off))[tid] = 0u;
     if (ntiles > 0) stage(t0 * NC, 0);
     // vmcnt(0) through the builtin (not asm) so that the compiler's own wait-count bookkeeping sees the drain: every
     // load it issued before this point is known complete and needs no further wait inside the loop.
@@ -604,7 +610,7 @@ void k_sweep(SweepArgs a)
             const int unit = i * NC + c;
 #if !defined(RM_FULL_BARRIER) && !defined(RM_ABL_NO_BARRIER)
             if (unit > 0) {                                                       // wait half of the split barrier
-                const unsigned target = (unsigned)NWAVES * (unsigned)unit;
+                const unsigned target = SYNC_WAVES * (unsigned)unit;
                 while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
             }
 #endif

@@ -241,18 +241,22 @@ void k_sweep64(Sweep64Args a)
     const double *noise_lane = (a.noise_E && user >= 0)
         ? a.noise_E + (size_t)(a.noise_row ? a.noise_row[user] - a.noise_row0 : user) * (size_t)a.noise_ld : nullptr;
 
-    // unit u = (tile, chunk): contiguous BUF_D2 double2 of the packed image [tile][g][q][row][2]
+    // unit u = (tile, chunk): contiguous BUF_D2 double2 of the packed image [tile][g][q][row][2].  The LDS image is
+    // [sub][g][q][32 items]: a sub-tile is staged by the four waves that read it (see the fp32 sweep), 1 KiB pieces of
+    // two 512-byte runs (q pair x 32 items)
     auto stage = [&](int tile, int chunk, int buf) {
         const f64x2 *src = a.Bp + ((size_t)tile * NGTV + (size_t)chunk * NGC) * 4 * TILE_ITEMS;
-        f64x2 *dst = ldsB + buf * BUF_D2;
+        f64x2 *dst = ldsB + buf * BUF_D2 + sub * NGC * 128;
         // inline asm, not the builtin: see the note at the fp32 sweep's stage() (the compiler would otherwise wait for
         // the DMA in front of the next LDS read)
         #pragma unroll
-        for (int j = 0; j < NGC * 4 / 8; j++) {
-            const int pc = wave + 8 * j;
-            const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)(dst + pc * 64));
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-                         :: "s"(m0v), "v"(src + pc * 64 + lane) : "memory", "m0");
+        for (int j = 0; j < (NGC * 2 + 3) / 4; j++) {
+            const int pc = gi + 4 * j;                       // piece = (g, q pair)
+            if ((NGC * 2) % 4 == 0 || pc < NGC * 2) {
+                const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)(dst + pc * 64));
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                             :: "s"(m0v), "v"(src + ((pc >> 1) * 4 + (pc & 1) * 2 + (lane >> 5)) * TILE_ITEMS + sub * 32 + (lane & 31)) : "memory", "m0");
+            }
         }
     };
 
@@ -400,8 +404,8 @@ void k_sweep64(Sweep64Args a)
     // split barrier on an LDS arrival counter (see the fp32 sweep): arrive after the unit's last MFMA, wait before the
     // next unit touches the buffers; the epilogue in between absorbs the skew between waves
     typedef __attribute__((address_space(3))) unsigned *LdsSyncPtr;
-    LdsSyncPtr arrive = (LdsSyncPtr)(smem + a.sync_off);
-    if (tid == 0) *arrive = 0u;
+    LdsSyncPtr arrive = (LdsSyncPtr)(smem + a.sync_off) + sub;       // one domain per sub-tile: its four waves
+    if (tid < 4) ((LdsSyncPtr)(smem + a.sync_off))[tid] = 0u;
     if (ntiles > 0) stage(t0, 0, 0);
     __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);      // builtin: the compiler's wait-count bookkeeping sees the drain
     __syncthreads();
@@ -415,14 +419,14 @@ void k_sweep64(Sweep64Args a)
             const int unit = i * NC + c;
             const int buf = unit & 1;
             if (unit > 0) {                                                       // wait half of the split barrier
-                const unsigned target = 8u * (unsigned)unit;
+                const unsigned target = 4u * (unsigned)unit;
                 while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
             }
             if (unit + 1 < nunits) {
                 const int nu = unit + 1;
                 stage(t0 + nu / NC, nu % NC, nu & 1);
             }
-            const f64x2 *bb = ldsB + buf * BUF_D2 + q * TILE_ITEMS + sub * 32 + ul;
+            const f64x2 *bb = ldsB + buf * BUF_D2 + sub * NGC * 128 + q * 32 + ul;
             // streamed factor axis: this chunk's user factors come from L2 right before use.  (Prefetching them one chunk
             // ahead into the registers just consumed, as the fp32 sweep does, costs more in spills here than it hides.)
             if (!AF_RESIDENT) {
@@ -435,7 +439,7 @@ void k_sweep64(Sweep64Args a)
             }
             #pragma unroll
             for (int gl = 0; gl < NGC; gl++) {
-                const f64x2 b0 = bb[gl * 4 * TILE_ITEMS], b1 = bb[gl * 4 * TILE_ITEMS + 16];
+                const f64x2 b0 = bb[gl * 128], b1 = bb[gl * 128 + 16];
                 const f64x2 u = af[AF_RESIDENT ? c * NGC + gl : gl];
                 clo = __builtin_amdgcn_mfma_f64_16x16x4f64(b0.x, u.x, clo, 0, 0, 0);
                 chi = __builtin_amdgcn_mfma_f64_16x16x4f64(b1.x, u.x, chi, 0, 0, 0);
