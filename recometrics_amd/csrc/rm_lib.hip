@@ -166,6 +166,7 @@ template <> struct Prec<float> {
     static constexpr size_t pend_key_bytes = 8;
     static constexpr int pend_cap_max = 8;                // keys per lane: measured flat from 3 to 8 at C2, best at 6-8
     static constexpr int max_nsub = 3;
+    static size_t lists_b(int, int K) { return (size_t)GROUPS_PER_BLOCK * (K + 2) * GU * 8; }      // one list per group, shared by its waves
     static constexpr bool block_carve = true;
     static void set_pending(SweepArgs &sa, int cap, int off) { sa.pend_cap = cap; sa.pend_off = off; }
     static void set_sync(SweepArgs &sa, int off) { sa.sync_off = off; }
@@ -183,6 +184,7 @@ template <> struct Prec<double> {
     static constexpr size_t pend_key_bytes = 12;
     static constexpr int pend_cap_max = 3;                // a user spans four lanes here: larger buffers only delay the bound (measured)
     static constexpr int max_nsub = 2;
+    static size_t lists_b(int ns, int K) { return 4ull * ns * K * GU * sizeof(ListT); }               // one list per wave
     static constexpr bool block_carve = true;
     static void set_pending(Sweep64Args &sa, int cap, int off) { sa.pend_cap = cap; sa.pend_off = off; }
     static void set_sync(Sweep64Args &sa, int off) { sa.sync_off = off; }
@@ -218,6 +220,7 @@ inline void pack_operands(const double *A, size_t lda, const double *B, size_t l
 }
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
+constexpr size_t SYNC_BYTES = 32;          // end of the sweep's LDS: arrival counters of the sub-tiles (4 words), list locks of the groups (4 words)
 
 // HBM the score rows of streamed users (and of every user when k_metrics > 256) may take: a third of what is free now, or
 // RM_STREAM_BUDGET_MB (tests)
@@ -372,12 +375,12 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     // next to the larger item tile -- the third wave per SIMD fills the vector pipe the epilogue leaves idle
     int nsub = 2;
     auto lds_need_j = [&](bool with_lists, int ns, int j) {                      // LDS of a block of depth j
-        const size_t head = P::lds_b(NG, 32 * ns) + (with_lists ? 4ull * ns * K * GU * sizeof(typename P::ListT) : 0);
+        const size_t head = P::lds_b(NG, 32 * ns) + (with_lists ? P::lists_b(ns, K) : 0);
         const size_t tb = ((size_t)1 << j) * GU * sizeof(T);
         return want_auc ? (head + tb - 1) / tb * tb + (size_t)GROUPS_PER_BLOCK * (1 << j) * GU * (sizeof(T) + 4) : head;
     };
     auto lds_need_n = [&](bool with_lists, int ns) { return lds_need_j(with_lists, ns, jmax); };
-    if (!ext_topk && P::max_nsub >= 3 && NG <= 8 && lds_need_n(true, 3) + 16 <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS") && !getenv("RM_DEBUG_NSUB2"))
+    if (!ext_topk && P::max_nsub >= 3 && NG <= 8 && lds_need_n(true, 3) + SYNC_BYTES <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS") && !getenv("RM_DEBUG_NSUB2"))
         nsub = 3;
     const int tile_items = 32 * nsub, n_waves = 4 * nsub;
     const int tiles_total = (n + tile_items - 1) / tile_items;
@@ -402,7 +405,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     if (const char *e = getenv("RM_DEBUG_SPLITS")) n_splits = std::max(1, std::min(atoi(e), std::max(1, MAX_PARTS / nsub)));   // A/B timing only
     const int n_part = nsub * n_splits;
     auto lds_need = [&](bool with_lists) { return lds_need_n(with_lists, nsub); };
-    const bool list_in_lds = !ext_topk && lds_need(true) + 16 <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS");
+    const bool list_in_lds = !ext_topk && lds_need(true) + SYNC_BYTES <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS");
     size_t lds_total = lds_need(list_in_lds);
     // per-lane pending buffers for top-K candidates behind everything else when 2..8 keys per lane still fit
     // (fp32: not for the append-buffer lists of K > 32, whose appends are already single stores)
@@ -413,10 +416,10 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         // the kernel sizes its tables per block (by the block's own depth) and computes the pending capacity from what
         // is left below the counter: allocate for the deepest block plus, if it still fits, 8 keys per lane
         pend_cap = want_pending ? P::pend_cap_max : 0;
-        lds_total = std::min<size_t>(LDS_LIMIT, lds_total + 16 + pend_cap * per_key);
-        sync_off = lds_total - 16;                         // split-barrier counter of the sweep, last 16 bytes
+        lds_total = std::min<size_t>(LDS_LIMIT, lds_total + SYNC_BYTES + pend_cap * per_key);
+        sync_off = lds_total - SYNC_BYTES;                         // split-barrier counter of the sweep, last 16 bytes
     } else {
-        sync_off = lds_total; lds_total += 16;
+        sync_off = lds_total; lds_total += SYNC_BYTES;
         pend_off = lds_total;
         if (want_pending) {
             pend_cap = (int)std::min<size_t>(8, (LDS_LIMIT - lds_total) / per_key);
@@ -532,7 +535,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         int u_split = 0, j_shallow = -1;
         if (P::block_carve && !list_in_lds && K <= 32 && want_auc && !getenv("RM_DEBUG_HBM_LISTS") && !getenv("RM_DEBUG_NO_DEPTH_SPLIT")) {
             for (int j = jmax - 1; j >= 0 && j_shallow < 0; j--)
-                if (lds_need_j(true, nsub, j) + 16 <= LDS_LIMIT) j_shallow = j;
+                if (lds_need_j(true, nsub, j) + SYNC_BYTES <= LDS_LIMIT) j_shallow = j;
             if (j_shallow >= 0) u_split = hp.class_offset[j_shallow + 1] / (GROUPS_PER_BLOCK * GU);
         }
         if (u_split > 0) {
@@ -546,9 +549,9 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             P::set_ublocks(sb, u_split, n_ublocks - u_split);
             typename P::Args sl = sa;                              // the shallow blocks: lists in LDS
             P::set_ublocks(sl, 0, u_split);
-            const size_t lds_l = std::min<size_t>(LDS_LIMIT, lds_need_j(true, nsub, j_shallow) + 16 + (want_pending ? P::pend_cap_max : 0) * per_key);
+            const size_t lds_l = std::min<size_t>(LDS_LIMIT, lds_need_j(true, nsub, j_shallow) + SYNC_BYTES + (want_pending ? P::pend_cap_max : 0) * per_key);
             P::set_pending(sl, want_pending ? P::pend_cap_max : 0, 0);
-            P::set_sync(sl, (int)lds_l - 16);
+            P::set_sync(sl, (int)(lds_l - SYNC_BYTES));
             HIP_CHECK(hipEventRecord(g_side_ev[0], stream));
             HIP_CHECK(hipStreamWaitEvent(g_side_stream, g_side_ev[0], 0));
             dispatch_sweep(want_auc, false, false, nsub, NG, dim3((unsigned)(n_ublocks - u_split) * n_splits), lds_total, g_side_stream, sb);
@@ -968,7 +971,7 @@ void debug_scores(const T *A, size_t lda, const T *B, size_t ldb, int m, int n, 
     sa.slot_user = slot_user; sa.slot_chunk = zeros; sa.train_p = zeros; sa.train_i = zeros; sa.gj = zeros + m + 1; sa.grow = grow;
     sa.glists = glists; sa.dump = dump;
     P::set_sync(sa, (int)P::lds_b(NG));
-    dispatch_sweep(false, true, false, 2, NG, dim3(n_ublocks), P::lds_b(NG) + 16, stream, sa);
+    dispatch_sweep(false, true, false, 2, NG, dim3(n_ublocks), P::lds_b(NG) + SYNC_BYTES, stream, sa);
     HIP_CHECK(hipMemcpyAsync(out, dump, sizeof(T) * (size_t)m * n, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
 }

@@ -202,7 +202,7 @@ void k_sweep(SweepArgs a)
     float4 *ldsB = (float4 *)smem;
     char *p = smem + 2 * BUF_F4 * 16;
     ListEntry *lists_lds = (ListEntry *)p;
-    if (LLDS) p += NWAVES * K * GROUP_USERS * (int)sizeof(ListEntry);
+    if (LLDS) p += GROUPS_PER_BLOCK * (K + 2) * GROUP_USERS * (int)sizeof(ListEntry);     // per group: K keys, worst key, its position
     const int PLmax = PLb;
     // each group's positives table (2^jb rows x 128 B) is aligned to its own size (see auc_pass)
     const unsigned tbytes = (unsigned)(PLmax + 1) * GROUP_USERS * 4;
@@ -215,7 +215,11 @@ void k_sweep(SweepArgs a)
     // ---- per-lane user state ----
     const int user = slot_ok ? a.slot_user[slot] : -1;
     const bool primary = slot_ok && a.slot_chunk[slot] == 0;
+#ifdef RM_ABL_TOPK_NOHIT
+    float thr = pos_inf_f();
+#else
     float thr = primary ? neg_inf_f() : nan_sentinel_f();        // NaN threshold: "v >= thr" never true
+#endif
     float vmax = neg_inf_f(), vmin = pos_inf_f();
     unsigned long long nanmask = 0;
     int ntc = 0, nte = 0, nt = IDX_EMPTY, nt2 = IDX_EMPTY;     // train cursor: next item and the one after (prefetched)
@@ -249,16 +253,40 @@ void k_sweep(SweepArgs a)
     // top-K list of this wave, owned by the lanes with h == 0.  LDS: [K][32 users], unsorted, replace-the-minimum.
     // HBM (lists that do not fit LDS): per user an append buffer of 2K + 32 entries + wave-cooperative compaction.
     const int CAP = 2 * K + 32;
-    LdsListPtr Ll = (LdsListPtr)((unsigned long long *)lists_lds + wave * K * GROUP_USERS + ul);
+    // The LDS list is shared by the NSUB waves of a user group (same users, interleaved item sub-tiles): its K-th best is
+    // the K-th best of everything the group has seen, not of a third of it, so fewer scores pass the bound (C2: 180
+    // candidates per user and split instead of 410).  Rows K and K + 1 hold the worst key and its position; a wave takes
+    // the group's lock (LDS word behind the arrival counters) around its updates -- pending-buffer merges, mostly.
+    LdsListPtr Ll = (LdsListPtr)((unsigned long long *)lists_lds + gi * (K + 2) * GROUP_USERS + ul);
+    LdsListPtr Lwk = Ll + K * GROUP_USERS, Lwp = Ll + (K + 1) * GROUP_USERS;
+    LdsU32Ptr list_lock = (LdsU32Ptr)(smem + a.sync_off) + 4 + gi;
     unsigned long long wkey = 0;                                   // LDS list: key of its worst entry (0 = empty slot)
     GblListPtr Gw = LLDS ? nullptr : a.glists + ((size_t)blockIdx.x * NWAVES + wave) * GROUP_USERS * CAP;    // wave's 32 buffers
     GblListPtr Gu = LLDS ? nullptr : Gw + (size_t)ul * CAP;                                                // this user's
     // small K in HBM: [K][32 users] replace-the-minimum like the LDS list (cheaper than compactions below K ~ 32)
     GblListPtr Lr = LLDS ? nullptr : a.glists + ((size_t)blockIdx.x * NWAVES + wave) * GROUP_USERS * CAP + ul;
     float ws = neg_inf_f(); int widx = IDX_EMPTY, wpos = 0, cnt = 0;
-    if (h == 0 && (LLDS || !buffered)) for (int i = 0; i < K; i++) {
-        if (LLDS) Ll[i * GROUP_USERS] = 0ull; else Lr[i * GROUP_USERS] = ListRaw<float>::pack(neg_inf_f(), IDX_EMPTY);
+    if (LLDS) {
+        if (sub == 0 && h == 0) for (int i = 0; i < K + 2; i++) Ll[i * GROUP_USERS] = 0ull;
+        if (tid < 4) ((LdsU32Ptr)(smem + a.sync_off))[4 + tid] = 0u;
+    } else if (h == 0 && !buffered) {
+        for (int i = 0; i < K; i++) Lr[i * GROUP_USERS] = ListRaw<float>::pack(neg_inf_f(), IDX_EMPTY);
     }
+    auto list_acquire = [&]() {                                   // wave-uniform; the holder never waits for another wave
+        if (!LLDS) return;
+        for (;;) {
+            unsigned got = 1u;
+            if (lane == 0) { unsigned expect = 0u; got = __hip_atomic_compare_exchange_strong(list_lock, &expect, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 0u : 1u; }
+            if (__builtin_amdgcn_readfirstlane(got) == 0u) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (h == 0) { wkey = Lwk[0]; wpos = (int)Lwp[0]; }
+    };
+    auto list_release = [&]() {
+        if (!LLDS) return;
+        if (h == 0) { Lwk[0] = wkey; Lwp[0] = (unsigned long long)wpos; }
+        if (lane == 0) __hip_atomic_store(list_lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     // compaction of every owner lane in `need` (wave-uniform mask): K best kept, sorted; (ws, widx) = the K-th
     auto compact_users = [&](unsigned long long need, bool final_sorted = false) {
         while (need) {
@@ -295,6 +323,7 @@ void k_sweep(SweepArgs a)
         const int pc = __shfl_xor(pcnt, 32);                      // the partner lane's count (same user, other item rows)
         const int lim = h == 0 ? (pcnt > pc ? pcnt : pc) : 0;
         RM_STAT(5, 1);
+        list_acquire();
         for (int i = 0; __any(i < lim); i++) {
             RM_STAT(6, 1);
             if (h == 0) {
@@ -302,6 +331,7 @@ void k_sweep(SweepArgs a)
                 if (i < pc) offer_key(Pp[i * WAVE + 32]);
             }
         }
+        list_release();
         pcnt = 0;
         if (LLDS) ws = (wkey >> 32) ? ord_unkey((unsigned)(wkey >> 32)) : neg_inf_f();
         else if (buffered) compact_users(__ballot(h == 0 && primary && cnt > 2 * K));   // <= 2 * pend_cap <= 32 appended since the last check
@@ -446,7 +476,6 @@ void k_sweep(SweepArgs a)
             #pragma unroll
             for (int r = 0; r < 16; r++) nanmask |= __ballot(v[r] != v[r]);
         }
-#ifndef RM_ABL_NO_STATS
         // (2) min / max over candidates (NaN-ignoring, so the sentinel is invisible) (:519-524): v_max3 / v_min3 trees
         // (the maxima of the four register quads are kept: the top-K path below skips a whole quad with one test)
         float qmax[4] = {hw_max3(v[0], v[1], hw_max(v[2], v[3])), hw_max3(v[4], v[5], hw_max(v[6], v[7])),
@@ -468,7 +497,6 @@ void k_sweep(SweepArgs a)
             for (int q4 = 0; q4 < 4; q4++) qmax[q4] = hw_max3(v[4 * q4], v[4 * q4 + 1], hw_max(v[4 * q4 + 2], v[4 * q4 + 3]));
             tmax = hw_max3(qmax[0], qmax[1], hw_max(qmax[2], qmax[3]));
         }
-#endif
 #ifndef RM_ABL_NO_TOPK
         // (3) streaming top-K: anything at or above the user's current K-th best is offered to the list (:537-540).
         // One compare per tile on the lane's tile maximum; the per-score work happens only in the rare hit path.
@@ -484,9 +512,7 @@ void k_sweep(SweepArgs a)
             unsigned ov = 0;                                    // score registers that did not fit the lane's buffer
             #pragma unroll
             for (int qd = 0; qd < 4; qd++) {
-#ifndef RM_ABL_NO_STATS
                 if (!__ballot(qmax[qd] >= thr)) continue;         // no lane has a candidate among these four registers
-#endif
                 #pragma unroll
                 for (int r = 4 * qd; r < 4 * qd + 4; r++) {
                     const bool c = v[r] >= thr;
@@ -517,6 +543,8 @@ void k_sweep(SweepArgs a)
                 merge_pending();
             }
         } else if (cm) {
+            list_acquire();
+            if (LLDS) ws = (wkey >> 32) ? ord_unkey((unsigned)(wkey >> 32)) : neg_inf_f();
             #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const unsigned long long hitm = __ballot(v[r] >= thr);
@@ -536,6 +564,7 @@ void k_sweep(SweepArgs a)
                     }
                 }
             }
+            list_release();
             if (!LLDS && buffered) compact_users(__ballot(h == 0 && primary && cnt > 2 * K));
         }
         if (cm && (!pend_cap || merged)) {                      // with pending buffers the K-th best only moves in a merge
@@ -587,7 +616,7 @@ void k_sweep(SweepArgs a)
     // -3.8 % at C2, gpurun_out r4a).  Arrivals of unit u + 1 cannot start before all of unit u are in, so one monotonic
     // counter per sub-tile is unambiguous: all arrived for unit u  <=>  counter >= 4 (u + 1).
     constexpr unsigned SYNC_WAVES = 4;
-    LdsU32Ptr arrive = (LdsU32Ptr)(smem + a.sync_off) + sub;
+    LdsU32Ptr arrive = (LdsU32Ptr)(smem + a.sync_off) + sub;            // (words 4..7 of the area: the groups' list locks)
     if (tid < 4) ((LdsU32Ptr)(smem + a.sync_off))[tid] = 0u;
     if (ntiles > 0) stage(t0 * NC, 0);
     // vmcnt(0) through the builtin (not asm) so that the compiler's own wait-count bookkeeping sees the drain: every
@@ -642,6 +671,7 @@ void k_sweep(SweepArgs a)
     }
     if (DUMP) return;
     if (pend_cap) merge_pending();
+    if (LLDS) __syncthreads();                                  // every wave of the group has merged into the shared list
 
     // ---- write this wave's partial: top-K list, validity stats, AUC sum; flush the LDS histogram ----
     const int n_part = a.n_splits * NSUB;
@@ -655,7 +685,8 @@ void k_sweep(SweepArgs a)
             ps.vmax = vmax; ps.vmin = vmin; ps.rocsum = 0; ps.has_nan = hn ? 1 : 0; ps.pad = 0;
             a.pst[(size_t)slot * n_part + part] = ps;
             ListEntry *dst = a.pl + ((size_t)slot * n_part + part) * K;
-            if (LLDS) { keylist_sort_desc<GROUP_USERS>(Ll, K); for (int i = 0; i < K; i++) unpack_key(Ll[i * GROUP_USERS], dst[i].s, dst[i].idx); }
+            if (LLDS && sub == 0) { keylist_sort_desc<GROUP_USERS>(Ll, K); for (int i = 0; i < K; i++) unpack_key(Ll[i * GROUP_USERS], dst[i].s, dst[i].idx); }
+            if (LLDS && sub != 0) for (int i = 0; i < K; i++) { dst[i].s = neg_inf_f(); dst[i].idx = IDX_EMPTY; }      // the group's list is written once
         }
     }
     if (!LLDS && !buffered) {
