@@ -73,8 +73,8 @@ class DeviceProblem:
         self.nnz_tr, self.nnz_te = int(tri.shape[0]), int(tei.shape[0])
         self.out = torch.empty((10, m), dtype=torch.float32 if dtype == np.float32 else torch.float64, device=dev)   # per-user metric block
 
-    def step(self, binding, stream):
-        o = self.out
+    def step(self, binding, stream, out=None):
+        o = self.out if out is None else out
         binding.calc_metrics_device(
             self.dtype, self.A.data_ptr(), self.k, self.B.data_ptr(), self.k, self.m, self.n, self.k,
             self.trp.data_ptr(), self.tri.data_ptr(), self.nnz_tr, self.tep.data_ptr(), self.tei.data_ptr(),
@@ -173,13 +173,31 @@ def cpu_baseline(host, K, n_users_total, budget_s, dtype=np.float32):
 def measure(torch, dist, binding, prob, steps, warmup, world, gather_buf):
     stream = torch.cuda.current_stream().cuda_stream
     sweep_ms, prep_ms, fin_ms = [], [], []
+    # N > 1: the all-gather of step i's metric block runs on RCCL's stream while step i + 1 computes; two metric blocks and
+    # two gather buffers in rotation, and a block is not written again before the gather that reads it has finished
+    outs = [prob.out, torch.empty_like(prob.out)] if world > 1 else [prob.out]
+    gbufs = [gather_buf, torch.empty_like(gather_buf)] if world > 1 else [None]
+    pending = [None, None]
+    count = [0]
 
     def one():
-        prob.step(binding, stream)
+        i = count[0] % len(outs)
+        count[0] += 1
+        if pending[i] is not None:
+            pending[i].wait()                               # stream-level: the compute stream waits, the host does not
+            pending[i] = None
+        prob.step(binding, stream, outs[i])
         if world > 1:
-            dist.all_gather_into_tensor(gather_buf, prob.out)
+            pending[i] = dist.all_gather_into_tensor(gbufs[i], outs[i], async_op=True)
+
+    def drain():
+        for i, h in enumerate(pending):
+            if h is not None:
+                h.wait()
+                pending[i] = None
     for _ in range(warmup):
         one()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -189,6 +207,7 @@ def measure(torch, dist, binding, prob, steps, warmup, world, gather_buf):
         one()
         tm = binding.timings()                              # HIP events recorded on the stream the kernels ran on
         sweep_ms.append(tm["sweep_ms"]); prep_ms.append(tm["prep_ms"]); fin_ms.append(tm["finalize_ms"])
+    drain()                                                 # every step's gather is inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -198,6 +217,9 @@ def measure(torch, dist, binding, prob, steps, warmup, world, gather_buf):
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        last = (count[0] - 1) % len(outs)
+        if last != 0:
+            prob.out.copy_(outs[last])                      # parity_check reads prob.out
     return dt, float(np.mean(sweep_ms)), float(np.mean(prep_ms)), float(np.mean(fin_ms)), binding.timings()
 
 
@@ -213,10 +235,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # RM_BENCH_BACKEND=gloo (tests on a one-GPU box): the ranks share the devices there are; RCCL wants one GPU per rank
+    backend = os.environ.get("RM_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     binding.load()
     binding.set_device(local_rank)
@@ -246,9 +272,7 @@ def main():
     dt, sweep_ms, prep_ms, fin_ms, tm = measure(torch, dist, binding, prob, args.steps, args.warmup, world, gather_buf)
     users_done = (world * m) if args.scaling == "weak" else m_total
     users_per_s = users_done * args.steps / dt
-    # 2*n*k per user x users of one launch.  The blocks of streamed users (more than 63 test items) run as
-    # a second, smaller launch of the sweep variant without rank counting, beside the main one; the HIP events bracket the
-    # main launch, so its share of the users is what it is credited with.
+    # 2*n*k per user x users of one launch (`share` = the slots the timed launch covers: all of them).
     share = (tm.get("timed_slots") or 0) / tm["total_slots"] if tm.get("total_slots") else 1.0
     flops_per_launch = 2.0 * n * k * m * share
     achieved_tf = flops_per_launch / (sweep_ms * 1e-3) / 1e12
@@ -259,7 +283,7 @@ def main():
         "config": {"workload": "%s: %d users/GPU x %d items, %d factors %s, K=%d, all 10 metrics, noise off"
                                % (args.workload, m, n, k, dname, K),
                    "users_per_gpu": m, "n_items": n, "n_factors": k, "k_metrics": K,
-                   "sharding": "users sharded, item factors replicated, 1 all-gather of the metric block per step"},
+                   "sharding": "users sharded, item factors replicated, 1 all-gather of the metric block per step (overlapped with the next step)"},
         "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved_tf / peak, "traffic": load_traffic(args.workload, m),
                      "kernel": "k_sweep (main launch: %.1f %% of the users)" % (100 * share), "avg_launch_ms": sweep_ms, "flops_per_launch": flops_per_launch,

@@ -203,6 +203,25 @@ def test_torch_distributed_helper_with_the_hip_binding(hip, tmp_path):
         assert_same_bits(got[names[n]].astype(np.float32), w, "sharded over 2 ranks: " + names[n])
 
 
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_with_two_ranks(hip, scaling):
+    """bench.py --gpus 2 end to end (it starts torch.distributed.run itself): two ranks, the metric blocks gathered while the
+    next step computes, one JSON line from rank 0 with the parity check green.  gloo and a shared GPU stand in for RCCL
+    and two GPUs on the one-GPU test box (RM_BENCH_BACKEND)."""
+    import json
+    env = dict(os.environ, RM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--users", "6001",
+                          "--no-cpu", "--no-extra", "--scaling", scaling], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == scaling
+    assert line["value"] > 0 and line["parity_checked"] > 0 and line["parity"]["ok"]
+    users = 2 * 6001 if scaling == "weak" else 6001
+    assert abs(line["value"] - users * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]
+
+
 def test_cython_binding_equals_the_ctypes_binding(hip, oracle=None):
     """recometrics_amd/_cy.pyx (compiled for real): the same C-ABI through Cython -- outputs
     bit-identical to the ctypes binding, single and cumulative, both precisions; status codes become the same exceptions"""
