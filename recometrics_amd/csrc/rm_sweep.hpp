@@ -394,7 +394,7 @@ void k_sweep(SweepArgs a)
     };
 
     // ---- MFMA: 32 items (registers) x 32 users (lanes), k in index order ----
-    auto do_mfma = [&](f32x16 &acc, int buf, int chunk) {
+    auto do_mfma = [&](f32x16 &acc, int buf, int chunk, unsigned tile_bits) {
         const float4 *bb = ldsB + buf * BUF_F4 + sub * NG * 64 + h * 32 + ul;      // LDS image [sub][g][h][32 items]
         constexpr int G_STRIDE = 64;
         if (!AF_RESIDENT && !AF_PREFETCH) {
@@ -402,8 +402,17 @@ void k_sweep(SweepArgs a)
             for (int g = 0; g < NG; g++) af[g] = af_src[(size_t)(chunk * NG + g) * 2 * GROUP_USERS];
         }
         if (chunk == 0) {
-            #pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            // Dense train rows: a masked item's accumulator STARTS as the all-ones NaN instead of +0 and the matrix
+            // instructions carry the NaN through -- masking costs the one v_bfe that replaces the zero, not a v_bfe and a
+            // v_or per score after the fact (16 fewer vector instructions per tile; unmasked chains still start at +0).
+            if (a.train_bits) {
+                const int mb = (int)(tile_bits >> (4 * h));
+                #pragma unroll
+                for (int r = 0; r < 16; r++) acc[r] = __int_as_float(__builtin_amdgcn_sbfe(mb, (r & 3) + 8 * (r >> 2), 1));
+            } else {
+                #pragma unroll
+                for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            }
         }
         // streamed factor axis: as soon as the four MFMAs of a factor group are issued its registers are free, and the
         // same group of the NEXT chunk is loaded into them -- a whole MFMA phase ahead of its use, drained by the
@@ -442,10 +451,16 @@ void k_sweep(SweepArgs a)
 #ifdef RM_ABL_NO_MASK
         const bool slow = false;
 #else
-        const bool slow = a.train_bits ? __any(tile_bits != 0u) : (__any(nt < sb + 32) || (sb + 32 > n));
+        const bool slow = !a.train_bits && (__any(nt < sb + 32) || (sb + 32 > n));
 #endif
-        if (slow) {
-            unsigned mbits = tile_bits;                           // (dense rows: train items and the padding beyond n, ready-made)
+        if (a.train_bits) {                                       // masked in the accumulators already (do_mfma)
+            if (a.check_nan) {
+                const int mb = (int)(tile_bits >> (4 * h));
+                #pragma unroll
+                for (int r = 0; r < 16; r++) nanmask |= __ballot(!__builtin_amdgcn_sbfe(mb, (r & 3) + 8 * (r >> 2), 1) && (v[r] != v[r]));
+            }
+        } else if (slow) {
+            unsigned mbits = 0u;
             // `nt2` was loaded when the previous item was consumed, in an earlier step, and is drained by that step's
             // closing wait: the first consumption of a step (peeled) needs no wait-count.  Only a lane that consumes a
             // second item in the same step waits for its own fresh load (and with it for the tile prefetch).
@@ -455,13 +470,11 @@ void k_sweep(SweepArgs a)
                 nt = nt2;
                 nt2 = ntc + 1 < nte ? a.train_i[ntc + 1] : IDX_EMPTY;
             };
-            if (!a.train_bits) {
-                if (nt < sb + 32) {
-                    consume();
-                    while (nt < sb + 32) consume();
-                }
-                if (sb + 32 > n) mbits |= (n > sb) ? (0xffffffffu << (n - sb)) : 0xffffffffu;
+            if (nt < sb + 32) {
+                consume();
+                while (nt < sb + 32) consume();
             }
+            if (sb + 32 > n) mbits |= (n > sb) ? (0xffffffffu << (n - sb)) : 0xffffffffu;
             // the sentinel is all ones: OR-ing the sign-extended mask bit into the score masks it (2 VALU per register)
             // (skipping the registers no lane masks, by a scalar union of the lanes' patterns, was measured 2-4 % SLOWER:
             // the scalar loop and 16 branches are more issue slots than the 25 vector instructions they save)
@@ -619,6 +632,7 @@ void k_sweep(SweepArgs a)
     LdsU32Ptr arrive = (LdsU32Ptr)(smem + a.sync_off) + sub;            // (words 4..7 of the area: the groups' list locks)
     if (tid < 4) ((LdsU32Ptr)(smem + a.sync_off))[tid] = 0u;
     if (ntiles > 0) stage(t0 * NC, 0);
+    unsigned tile_bits = (tb_row && ntiles > 0) ? tb_row[t0 * NSUB + sub] : 0u;       // first tile's word of the dense train row
     // vmcnt(0) through the builtin (not asm) so that the compiler's own wait-count bookkeeping sees the drain: every
     // load it issued before this point is known complete and needs no further wait inside the loop.
     __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);
@@ -647,11 +661,12 @@ void k_sweep(SweepArgs a)
             if (unit + 1 < nunits) stage(t0 * NC + unit + 1, (unit + 1) & 1);   // that buffer was last read one unit ago
 #endif
             if (c == 0) thr_next = load_thr();
-            // this tile's word of the dense train row: in flight during the MFMA phase, drained by the wait at the arrive point
-            unsigned tile_bits = 0u;
-            if (c == NC - 1 && tb_row) tile_bits = tb_row[((t0 + i) * TILE + sub * 32) >> 5];
+            // the NEXT tile's word of the dense train row (the accumulators start from it): in flight during the MFMA phase,
+            // drained by the wait at the arrive point
+            unsigned bits_next = 0u;
+            if (c == NC - 1 && tb_row && i + 1 < ntiles) bits_next = tb_row[(t0 + i + 1) * NSUB + sub];
 #ifndef RM_ABL_NO_MFMA
-            do_mfma(acc, unit & 1, c);
+            do_mfma(acc, unit & 1, c, tile_bits);
 #endif
 #if !defined(RM_FULL_BARRIER) && !defined(RM_ABL_NO_BARRIER)
 #ifndef RM_ABL_NO_ARRIVE_WAIT
@@ -662,6 +677,7 @@ void k_sweep(SweepArgs a)
 #ifndef RM_ABL_NO_EPI
             if (c == NC - 1) do_epi(acc, t0 + i, thr_seen, tile_bits);
 #endif
+            if (c == NC - 1) tile_bits = bits_next;
 #if defined(RM_FULL_BARRIER)
             __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                              // the DMA of the next unit has landed
             __syncthreads();
