@@ -15,7 +15,12 @@ struct SweepArgs {
     int ext_topk;                         // 1 = no top-K lists here: every lane streams its scores, k_select_topk picks the top-K
     int n_slots, n_groups, n_ublocks;     // n_ublocks = user blocks of THIS launch (ceil(n_groups / 4) when there is one)
     int ublock0;                          // first user block of this launch (depth-split calls launch twice)
-    int n_splits, tiles_total;            // item splits (grid = n_ublocks * n_splits)
+    int n_splits, tiles_total;            // item splits of the main part of the grid
+    // Two-level grid: the LAST `tail_ublocks` user blocks in launch order (the cheapest) are cut into `tail_splits` item
+    // ranges instead of n_splits -- small blocks that fill the last, partial round of the grid.  part_splits =
+    // max(n_splits, tail_splits) is the split dimension of pl / pst (grid = (n_ublocks - tail_ublocks) * n_splits +
+    // tail_ublocks * tail_splits)
+    int tail_ublocks, tail_splits, part_splits;
     int jmax;                             // LDS sizing (all blocks)
     int list_in_lds;
     int check_nan;                        // 0 when the host proved all scores finite (skips the NaN scan)
@@ -52,6 +57,7 @@ struct Sweep64Args {
     int n_slots, n_groups, n_ublocks;     // n_ublocks = user blocks of THIS launch
     int ublock0;                          // first user block of this launch (depth-split calls launch twice)
     int n_splits, tiles_total;
+    int tail_ublocks, tail_splits, part_splits;       // as in SweepArgs
     int jmax;
     int check_nan;
     int buffered_lists;

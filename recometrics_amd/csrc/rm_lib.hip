@@ -384,26 +384,44 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         nsub = 3;
     const int tile_items = 32 * nsub, n_waves = 4 * nsub;
     const int tiles_total = (n + tile_items - 1) / tile_items;
-    // LDS admits one block per CU, so the grid runs in rounds of 256 blocks.  The item split count S trades three things
-    // (coefficients measured on MI355X, gpurun_out r2_splits*: C2, NS, C3- and C4-shaped runs):
-    //   * the last round should be full, and -- blocks differ in duration by ~ +-20 % (depth of the positive trees, streamed
-    //     users) -- there should be several rounds, so that compute units that finish early pick up more blocks:
-    //     makespan ~ max(whole rounds, rounds + 0.2);
-    //   * every block pays a fixed prologue / epilogue (tables into LDS, list sort, histogram flush) worth ~13 tiles;
-    //   * every split restarts the streaming top-K lists: ~0.4 % of a sweep per split and 10 of k_metrics.
-    int n_splits = 1;
+    // LDS admits one block per CU, so the grid runs in rounds of 256 blocks, and a block costs its tiles plus a fixed part:
+    //   block(s) = tiles_total / s + 13 (tables into LDS, the top-K lists filling up, list sort, histogram flush)
+    //              + 0.4 % of the sweep per 10 of k_metrics (every item range restarts the streaming top-K lists)
+    // (coefficients measured on MI355X, profiles/r2_splits*: C2, NS, C3- and C4-shaped runs).  One split count for the whole
+    // grid leaves the last round partly empty -- 8.45 rounds cost 9 at C2 -- so the grid has two levels: whole rounds of
+    // blocks with n_splits item ranges, then the `tail_ublocks` cheapest user blocks cut into `tail_splits` (more, smaller)
+    // ranges that fill the last round.  Blocks differ in duration by ~ +-20 % (depth of the positive trees, streamed
+    // users), so a part that ends the grid is charged max(whole rounds, rounds + 0.2).
+    int n_splits = 1, tail_ublocks = 0, tail_splits = 0;
     if (n_ublocks > 0) {
-        const int n_cu = 256, max_splits = std::max(1, std::min(MAX_PARTS / nsub, tiles_total / 128));
-        double best = -1e30;
+        const int n_cu = 256;
+        const int max_splits = std::max(1, std::min(MAX_PARTS / nsub, tiles_total / 128));
+        const int max_tail = std::max(1, std::min(MAX_PARTS / nsub, tiles_total / 48));
+        const double fixed = 13.0 + 0.004 * std::max(0.25, K / 10.0) * tiles_total;
+        auto block = [&](int sct) { return (double)tiles_total / sct + fixed; };
+        auto last = [&](double rounds) { return std::max(std::ceil(rounds - 1e-9), rounds + 0.2); };
+        double best = 1e300;
         for (int sct = 1; sct <= max_splits; sct++) {
-            const double rounds = (double)n_ublocks * sct / n_cu;
-            const double makespan = std::max(std::ceil(rounds - 1e-9), rounds + 0.2);
-            const double score = rounds / makespan - sct * (13.0 / tiles_total + 0.004 * std::max(0.25, K / 10.0));
-            if (score > best + 1e-9) { best = score; n_splits = sct; }
+            const double t1 = last((double)n_ublocks * sct / n_cu) * block(sct);
+            if (t1 < best - 1e-9) { best = t1; n_splits = sct; tail_ublocks = 0; tail_splits = 0; }
+            const long long full = (long long)n_ublocks * sct / n_cu;               // whole rounds of the main part
+            const int main_ub = (int)(full * n_cu / sct), tail_ub = n_ublocks - main_ub;
+            if (full == 0 || tail_ub == 0) continue;
+            for (int ts = sct + 1; ts <= max_tail; ts++) {
+                const double t2 = (double)main_ub * sct / n_cu * block(sct) + last((double)tail_ub * ts / n_cu) * block(ts);
+                if (t2 < best * 0.99) { best = t2; n_splits = sct; tail_ublocks = tail_ub; tail_splits = ts; }
+            }
         }
     }
-    if (const char *e = getenv("RM_DEBUG_SPLITS")) n_splits = std::max(1, std::min(atoi(e), std::max(1, MAX_PARTS / nsub)));   // A/B timing only
-    const int n_part = nsub * n_splits;
+    if (const char *e = getenv("RM_DEBUG_SPLITS")) {                                // A/B timing and tests: "S" or "S,tail_ublocks,tail_splits"
+        int v[3] = {1, 0, 0};
+        sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]);
+        n_splits = std::max(1, std::min(v[0], std::max(1, MAX_PARTS / nsub)));
+        tail_ublocks = std::max(0, std::min(v[1], n_ublocks)); tail_splits = std::max(1, std::min(v[2], std::max(1, MAX_PARTS / nsub)));
+        if (tail_ublocks == 0) tail_splits = 0;
+    }
+    const int part_splits = std::max(n_splits, tail_splits);
+    const int n_part = nsub * part_splits;
     auto lds_need = [&](bool with_lists) { return lds_need_n(with_lists, nsub); };
     const bool list_in_lds = !ext_topk && lds_need(true) + SYNC_BYTES <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS");
     size_t lds_total = lds_need(list_in_lds);
@@ -504,7 +522,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         if (!ext_topk) pl = (Entry<T> *)ws.get("pl", sizeof(Entry<T>) * (size_t)n_slots * n_part * K);
         pst = (PartialStat<T> *)ws.get("pst", sizeof(PartialStat<T>) * (size_t)n_slots * n_part);
         typename P::ListT *glists = nullptr;
-        const unsigned n_blocks = (unsigned)n_ublocks * n_splits;
+        const unsigned n_blocks = (unsigned)((n_ublocks - tail_ublocks) * n_splits + tail_ublocks * tail_splits);
         if (!list_in_lds && !ext_topk) {
             glists = (typename P::ListT *)ws.get("glists", sizeof(typename P::ListT) * (size_t)n_blocks * n_waves * GU * (2 * K + 32));
         }
@@ -518,7 +536,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         typename P::Args sa{};
         sa.thr_shared = thr_shared;
         sa.n = n; sa.K = K; sa.ngt = NG; sa.n_slots = n_slots; sa.n_groups = n_groups; sa.n_ublocks = n_ublocks;
-        sa.n_splits = n_splits; sa.tiles_total = tiles_total; sa.jmax = jmax; sa.check_nan = check_nan ? 1 : 0; sa.buffered_lists = (K > 32 || ext_topk) ? 1 : 0; sa.ext_topk = ext_topk ? 1 : 0;
+        sa.n_splits = n_splits; sa.tail_ublocks = tail_ublocks; sa.tail_splits = tail_splits; sa.part_splits = part_splits; sa.tiles_total = tiles_total; sa.jmax = jmax; sa.check_nan = check_nan ? 1 : 0; sa.buffered_lists = (K > 32 || ext_topk) ? 1 : 0; sa.ext_topk = ext_topk ? 1 : 0;
         sa.Ap = (decltype(sa.Ap))Ap; sa.Bp = (decltype(sa.Bp))Bp; sa.slot_user = slot_user; sa.slot_chunk = slot_chunk;
         sa.train_p = c.train_p; sa.train_i = c.train_i; sa.gj = gj; sa.grow = grow;
         sa.pos_score = pos_score; sa.pos_item = pos_item; sa.hist = hist; sa.glists = glists; sa.pl = pl; sa.pst = pst; sa.dump = nullptr;
@@ -549,14 +567,17 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             P::set_ublocks(sb, u_split, n_ublocks - u_split);
             typename P::Args sl = sa;                              // the shallow blocks: lists in LDS
             P::set_ublocks(sl, 0, u_split);
+            // (the tail of the two-level grid = the cheapest user blocks = the first ones: the shallow launch's, then the deep one's)
+            sl.tail_ublocks = std::min(tail_ublocks, u_split);
+            sb.tail_ublocks = tail_ublocks - sl.tail_ublocks;
             const size_t lds_l = std::min<size_t>(LDS_LIMIT, lds_need_j(true, nsub, j_shallow) + SYNC_BYTES + (want_pending ? P::pend_cap_max : 0) * per_key);
             P::set_pending(sl, want_pending ? P::pend_cap_max : 0, 0);
             P::set_sync(sl, (int)(lds_l - SYNC_BYTES));
             HIP_CHECK(hipEventRecord(g_side_ev[0], stream));
             HIP_CHECK(hipStreamWaitEvent(g_side_stream, g_side_ev[0], 0));
-            dispatch_sweep(want_auc, false, false, nsub, NG, dim3((unsigned)(n_ublocks - u_split) * n_splits), lds_total, g_side_stream, sb);
+            dispatch_sweep(want_auc, false, false, nsub, NG, dim3((unsigned)((n_ublocks - u_split - sb.tail_ublocks) * n_splits + sb.tail_ublocks * tail_splits)), lds_total, g_side_stream, sb);
             HIP_CHECK(hipEventRecord(g_side_ev[1], g_side_stream));
-            dispatch_sweep(want_auc, false, true, nsub, NG, dim3((unsigned)u_split * n_splits), lds_l, stream, sl);
+            dispatch_sweep(want_auc, false, true, nsub, NG, dim3((unsigned)((u_split - sl.tail_ublocks) * n_splits + sl.tail_ublocks * tail_splits)), lds_l, stream, sl);
             HIP_CHECK(hipStreamWaitEvent(stream, g_side_ev[1], 0));
         } else {
             // (Measured and dropped: the blocks made of streamed users only as a second launch of the sweep variant without rank
@@ -966,7 +987,7 @@ void debug_scores(const T *A, size_t lda, const T *B, size_t ldb, int m, int n, 
     const int K = 1;
     typename P::ListT *glists = (typename P::ListT *)ws.get("glists", sizeof(typename P::ListT) * (size_t)n_ublocks * 8 * GU * (2 * K + 32));
     typename P::Args sa{};
-    sa.n = n; sa.K = K; sa.ngt = NG; sa.n_slots = m; sa.n_groups = n_groups; sa.n_ublocks = n_ublocks; sa.n_splits = 1;
+    sa.n = n; sa.K = K; sa.ngt = NG; sa.n_slots = m; sa.n_groups = n_groups; sa.n_ublocks = n_ublocks; sa.n_splits = 1; sa.part_splits = 1;
     sa.tiles_total = tiles_total; sa.jmax = 0; sa.check_nan = 1; sa.Ap = (decltype(sa.Ap))Ap; sa.Bp = (decltype(sa.Bp))Bp;
     sa.slot_user = slot_user; sa.slot_chunk = zeros; sa.train_p = zeros; sa.train_i = zeros; sa.gj = zeros + m + 1; sa.grow = grow;
     sa.glists = glists; sa.dump = dump;

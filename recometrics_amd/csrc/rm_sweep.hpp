@@ -184,8 +184,14 @@ void k_sweep(SweepArgs a)
     const int gi = wave & 3, sub = wave >> 2;                   // group in block / 32-item sub-tile
     const int ul = lane & 31, h = lane >> 5;
     // user blocks are sorted by positive-tree depth (cheapest first): launch the deepest (slowest) ones first so that
-    // the last round of the grid is made of the cheap ones
-    const int blk_u = a.ublock0 + a.n_ublocks - 1 - (int)(blockIdx.x % a.n_ublocks), split = blockIdx.x / a.n_ublocks;
+    // the last round of the grid is made of the cheap ones -- and of SMALL ones: the tail_ublocks cheapest user blocks
+    // come last, cut into tail_splits item ranges each (rm_launch.hpp)
+    int blk_u, split, nsplit;
+    {
+        const int n_ub1 = a.n_ublocks - a.tail_ublocks, b1 = n_ub1 * a.n_splits;
+        if ((int)blockIdx.x < b1) { blk_u = a.ublock0 + a.n_ublocks - 1 - (int)(blockIdx.x % n_ub1); split = blockIdx.x / n_ub1; nsplit = a.n_splits; }
+        else { const int j = (int)blockIdx.x - b1; blk_u = a.ublock0 + a.tail_ublocks - 1 - j % a.tail_ublocks; split = j / a.tail_ublocks; nsplit = a.tail_splits; }
+    }
     const int group = blk_u * GROUPS_PER_BLOCK + gi;
     const bool group_ok = group < a.n_groups;
     const int slot = group * GROUP_USERS + ul;
@@ -225,7 +231,7 @@ void k_sweep(SweepArgs a)
     int ntc = 0, nte = 0, nt = IDX_EMPTY, nt2 = IDX_EMPTY;     // train cursor: next item and the one after (prefetched)
 
     // item range of this split
-    const int tiles_per = (a.tiles_total + a.n_splits - 1) / a.n_splits;
+    const int tiles_per = (a.tiles_total + nsplit - 1) / nsplit;
     const int t0 = split * tiles_per, t1 = min(a.tiles_total, t0 + tiles_per);
     const int ntiles = max(0, t1 - t0);
 
@@ -419,15 +425,35 @@ void k_sweep(SweepArgs a)
         // wait at the arrive point, so the L2 latency of the user factors is never in front of a matrix instruction.
         // (Not with the append-buffer lists: that variant has no registers to spare and the prefetch turns into spills.)
         const int next_chunk = chunk + 1 == NC ? 0 : chunk + 1;
+        // The item operands of factor group g + 2 are read from LDS right after the four MFMAs of group g have been
+        // issued (two register quads in rotation, the order pinned by scheduling barriers): a read is in flight for the
+        // 256 cycles of the other quad's MFMAs and the chain never stalls for an LDS round trip.  (Left to itself the
+        // compiler reads, waits, issues four MFMAs, reads again: ~100 idle cycles per 256 busy ones.)
+        float4 b0 = bb[0], b1 = NG > 1 ? bb[G_STRIDE] : b0;
         #pragma unroll
-        for (int g = 0; g < NG; g++) {
-            const float4 b = bb[g * G_STRIDE];
-            const float4 u = af[g];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, u.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, u.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, u.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, u.w, acc, 0, 0, 0);
-            if (AF_PREFETCH) af[g] = af_src[(size_t)(next_chunk * NG + g) * 2 * GROUP_USERS];
+        for (int g = 0; g < NG; g += 2) {
+            {
+                const float4 u = af[g];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b0.x, u.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b0.y, u.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b0.z, u.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b0.w, u.w, acc, 0, 0, 0);
+                if (AF_PREFETCH) af[g] = af_src[(size_t)(next_chunk * NG + g) * 2 * GROUP_USERS];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 2 < NG) b0 = bb[(g + 2) * G_STRIDE];
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < NG) {
+                const float4 u = af[g + 1];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b1.x, u.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b1.y, u.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b1.z, u.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b1.w, u.w, acc, 0, 0, 0);
+                if (AF_PREFETCH) af[g + 1] = af_src[(size_t)(next_chunk * NG + g + 1) * 2 * GROUP_USERS];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 3 < NG) b1 = bb[(g + 3) * G_STRIDE];
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -690,7 +716,7 @@ void k_sweep(SweepArgs a)
     if (LLDS) __syncthreads();                                  // every wave of the group has merged into the shared list
 
     // ---- write this wave's partial: top-K list, validity stats, AUC sum; flush the LDS histogram ----
-    const int n_part = a.n_splits * NSUB;
+    const int n_part = a.part_splits * NSUB;
     const int part = split * NSUB + sub;
     {   // lanes u and u+32 hold two halves of the same user's stats
         const float omax = __shfl_xor(vmax, 32), omin = __shfl_xor(vmin, 32);
@@ -703,6 +729,13 @@ void k_sweep(SweepArgs a)
             ListEntry *dst = a.pl + ((size_t)slot * n_part + part) * K;
             if (LLDS && sub == 0) { keylist_sort_desc<GROUP_USERS>(Ll, K); for (int i = 0; i < K; i++) unpack_key(Ll[i * GROUP_USERS], dst[i].s, dst[i].idx); }
             if (LLDS && sub != 0) for (int i = 0; i < K; i++) { dst[i].s = neg_inf_f(); dst[i].idx = IDX_EMPTY; }      // the group's list is written once
+            // a user block cut into fewer ranges than the arrays are laid out for: its first block fills in the missing parts
+            if (split == 0) for (int sp = nsplit; sp < a.part_splits; sp++) {
+                ps.vmax = neg_inf_f(); ps.vmin = pos_inf_f(); ps.has_nan = 0;
+                a.pst[(size_t)slot * n_part + sp * NSUB + sub] = ps;
+                ListEntry *de = a.pl + ((size_t)slot * n_part + sp * NSUB + sub) * K;
+                if (a.pl) for (int i = 0; i < K; i++) { de[i].s = neg_inf_f(); de[i].idx = IDX_EMPTY; }
+            }
         }
     }
     if (!LLDS && !buffered) {

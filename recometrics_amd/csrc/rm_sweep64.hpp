@@ -99,8 +99,14 @@ void k_sweep64(Sweep64Args a)
     const int gi = wave & 3, sub = wave >> 2;
     const int ul = lane & 15, q = lane >> 4;
     // user blocks are sorted by positive-tree depth (cheapest first): launch the deepest (slowest) ones first so that
-    // the last round of the grid is made of the cheap ones
-    const int blk_u = a.ublock0 + a.n_ublocks - 1 - (int)(blockIdx.x % a.n_ublocks), split = blockIdx.x / a.n_ublocks;
+    // the last round of the grid is made of the cheap ones -- and of SMALL ones: the tail_ublocks cheapest user blocks
+    // come last, cut into tail_splits item ranges each (rm_launch.hpp)
+    int blk_u, split, nsplit;
+    {
+        const int n_ub1 = a.n_ublocks - a.tail_ublocks, b1 = n_ub1 * a.n_splits;
+        if ((int)blockIdx.x < b1) { blk_u = a.ublock0 + a.n_ublocks - 1 - (int)(blockIdx.x % n_ub1); split = blockIdx.x / n_ub1; nsplit = a.n_splits; }
+        else { const int j = (int)blockIdx.x - b1; blk_u = a.ublock0 + a.tail_ublocks - 1 - j % a.tail_ublocks; split = j / a.tail_ublocks; nsplit = a.tail_splits; }
+    }
     const int group = blk_u * GROUPS_PER_BLOCK + gi;
     const bool group_ok = group < a.n_groups;
     const int slot = group * GU + ul;
@@ -132,7 +138,7 @@ void k_sweep64(Sweep64Args a)
     unsigned long long nanmask = 0;
     int ntc = 0, nte = 0, nt = IDX_EMPTY, nt2 = IDX_EMPTY;     // train cursor: next item and the one after (prefetched)
 
-    const int tiles_per = (a.tiles_total + a.n_splits - 1) / a.n_splits;
+    const int tiles_per = (a.tiles_total + nsplit - 1) / nsplit;
     const int t0 = split * tiles_per, t1 = min(a.tiles_total, t0 + tiles_per);
     const int ntiles = max(0, t1 - t0);
 
@@ -455,7 +461,7 @@ void k_sweep64(Sweep64Args a)
     if (DUMP) return;
     if (pend_cap) merge_pending();
 
-    const int n_part = a.n_splits * 2;
+    const int n_part = a.part_splits * 2;
     const int part = split * 2 + sub;
     {   // the four lanes of a user hold four quarters of its stats
         vmax = __builtin_fmax(vmax, __shfl_xor(vmax, 16)); vmax = __builtin_fmax(vmax, __shfl_xor(vmax, 32));
@@ -467,6 +473,13 @@ void k_sweep64(Sweep64Args a)
             a.pst[(size_t)slot * n_part + part] = ps;
             Entry<double> *dst = a.pl + ((size_t)slot * n_part + part) * K;
             if (LLDS) { list_sort_desc<double, GU>(Ll, K); for (int i = 0; i < K; i++) ListRaw<double>::unpack(Ll[i * GU], dst[i].s, dst[i].idx); }
+            // a user block cut into fewer ranges than the arrays are laid out for: its first block fills in the missing parts
+            if (split == 0) for (int sp = nsplit; sp < a.part_splits; sp++) {
+                ps.vmax = neg_inf_d(); ps.vmin = pos_inf_d(); ps.has_nan = 0;
+                a.pst[(size_t)slot * n_part + sp * 2 + sub] = ps;
+                Entry<double> *de = a.pl + ((size_t)slot * n_part + sp * 2 + sub) * K;
+                if (a.pl) for (int i = 0; i < K; i++) { de[i].s = neg_inf_d(); de[i].idx = IDX_EMPTY; }
+            }
         }
     }
     if (!LLDS && !buffered) {

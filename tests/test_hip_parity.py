@@ -175,12 +175,14 @@ def test_random_problem_vs_oracle_f64(hip, oracle, m, n, k, K, mean_c):
 
 @pytest.mark.parametrize("env", [{"RM_DEBUG_NO_PENDING": "1"}, {"RM_DEBUG_HBM_LISTS": "1"}, {"RM_DEBUG_EXT_TOPK": "1"},
                                  {"RM_DEBUG_NO_TRAIN_BITS": "1"}, {"RM_DEBUG_NO_SEED": "1"}, {"RM_DEBUG_SPLITS": "5"},
+                                 {"RM_DEBUG_SPLITS": "2,1,5"}, {"RM_DEBUG_SPLITS": "1,2,3"}, {"RM_DEBUG_SPLITS": "3,1,7", "RM_DEBUG_HBM_LISTS": "1"},
                                  {"RM_DEBUG_HBM_LISTS": "1", "RM_DEBUG_NO_PENDING": "1"},
                                  {"RM_DEBUG_NSUB2": "1"}, {"RM_DEBUG_NSUB2": "1", "RM_DEBUG_NO_PENDING": "1"}])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_list_schemes_agree(hip, oracle, env, dtype, monkeypatch):
     """the same problem through every top-K list scheme the sweep has (the library reads the switches per call), with the
-    CSR cursor instead of the dense train rows, without the seeded bounds, with another item split count:
+    CSR cursor instead of the dense train rows, without the seeded bounds, with another item split count, with a two-level
+    grid ("S,tail user blocks,tail splits": the cheapest user blocks cut into more item ranges than the others):
     LDS lists without pending buffers, HBM replace-the-minimum lists with and without them, and (fp32, <= 64 factors,
     where three item sub-tiles per step are the default) the two-sub-tile block"""
     from recometrics_amd.synth import make_problem
