@@ -148,7 +148,11 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
 
 #ifdef RM_STATS
 __device__ unsigned long long g_stats[16];
+#ifdef RM_STATS_TIME_ONLY
+#define RM_STAT(i, x) do {} while (0)
+#else
 #define RM_STAT(i, x) do { if (lane == 0) atomicAdd(&g_stats[i], (unsigned long long)(x)); } while (0)
+#endif
 #else
 #define RM_STAT(i, x) do {} while (0)
 #endif
@@ -164,6 +168,9 @@ __global__ __launch_bounds__(256 * NSUB)
 void k_sweep(SweepArgs a)
 {
     constexpr int TILE = 32 * NSUB;                             // items per step and per packed tile
+#ifdef RM_STATS
+    const unsigned long long prof_t0 = __builtin_readcyclecounter();
+#endif
     constexpr int NWAVES = 4 * NSUB, THREADS = 64 * NWAVES;
     constexpr bool LLDS = LMODE == LM_LDS;
     constexpr bool buffered = LMODE == LM_HBM_APPEND;
@@ -673,6 +680,9 @@ void k_sweep(SweepArgs a)
 #endif
     };
     unsigned thr_seen = 0u;
+#ifdef RM_STATS
+    const unsigned long long prof_t1 = __builtin_readcyclecounter();
+#endif
     for (int i = 0; i < ntiles; i++) {
         unsigned thr_next = thr_seen;
         for (int c = 0; c < NC; c++) {
@@ -682,6 +692,23 @@ void k_sweep(SweepArgs a)
                 const unsigned target = SYNC_WAVES * (unsigned)unit;
                 while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
             }
+#ifndef RM_ABL_NO_PRIO
+            // The sub-tile domains progress independently, and the instruction arbiter serves the oldest wave first: left
+            // alone, sub-tile 0 finishes its range ~20 % ahead of sub-tile 2 and the block ends on one wave per SIMD.
+            // Every fourth unit a wave compares its domain's arrival counter with the others' and sets its issue priority:
+            // behind -> high, ahead -> low (more than half a unit apart), so that all domains reach the end together.
+            if ((unit & 3) == 0) {
+                const u32x4 cnt4 = *(__attribute__((address_space(3))) const u32x4 *)(smem + a.sync_off);
+                const unsigned c0 = __builtin_amdgcn_readfirstlane(cnt4.x), c1 = __builtin_amdgcn_readfirstlane(cnt4.y), c2 = __builtin_amdgcn_readfirstlane(cnt4.z);
+                const int sub_s = __builtin_amdgcn_readfirstlane(sub);                      // (wave-uniform, and known to be to the compiler)
+                const unsigned mine = sub_s == 0 ? c0 : (sub_s == 1 ? c1 : c2);
+                const unsigned o1 = sub_s == 0 ? c1 : c0, o2 = (NSUB == 3) ? (sub_s == 2 ? c1 : c2) : o1;
+                const bool behind = mine + 2 < o1 || mine + 2 < o2, ahead = mine > o1 + 2 && mine > o2 + 2;
+                if (behind) __builtin_amdgcn_s_setprio(2);
+                else if (ahead) __builtin_amdgcn_s_setprio(0);
+                else __builtin_amdgcn_s_setprio(1);
+            }
+#endif
 #endif
 #ifndef RM_ABL_NO_STAGE
             if (unit + 1 < nunits) stage(t0 * NC + unit + 1, (unit + 1) & 1);   // that buffer was last read one unit ago
@@ -712,8 +739,19 @@ void k_sweep(SweepArgs a)
         thr_seen = thr_next;
     }
     if (DUMP) return;
+#ifdef RM_STATS
+    const unsigned long long prof_t2 = __builtin_readcyclecounter();
+#endif
     if (pend_cap) merge_pending();
+#ifdef RM_STATS
+    if (lane == 0 && gi == 0 && sub == 1) atomicAdd(&g_stats[14], prof_t2 - prof_t1);
+    if (lane == 0 && gi == 0 && sub == 2) atomicAdd(&g_stats[15], prof_t2 - prof_t1);
+    if (lane == 0 && gi == 3 && sub == 0) atomicAdd(&g_stats[8], prof_t2 - prof_t1);
+#endif
     if (LLDS) __syncthreads();                                  // every wave of the group has merged into the shared list
+#ifdef RM_STATS
+    if (threadIdx.x == 0) atomicAdd(&g_stats[9], __builtin_readcyclecounter() - prof_t2);
+#endif
 
     // ---- write this wave's partial: top-K list, validity stats, AUC sum; flush the LDS histogram ----
     const int n_part = a.part_splits * NSUB;
@@ -764,6 +802,13 @@ void k_sweep(SweepArgs a)
             if (gg < a.n_groups && c) atomicAdd(&a.hist[(a.grow[gg] + gg) * GROUP_USERS + rem], c);
         }
     }
+#ifdef RM_STATS
+    if (threadIdx.x == 0) {
+        const unsigned long long prof_t3 = __builtin_readcyclecounter();
+        atomicAdd(&g_stats[10], prof_t1 - prof_t0); atomicAdd(&g_stats[11], prof_t2 - prof_t1); atomicAdd(&g_stats[12], prof_t3 - prof_t2);
+        atomicAdd(&g_stats[13], (unsigned long long)ntiles);
+    }
+#endif
 }
 
 } // namespace rm

@@ -10,3 +10,12 @@ int launch_sweep32_n3(bool auc, int NG, dim3 grid, size_t lds, hipStream_t strea
 }
 
 } // namespace rm
+
+#ifdef RM_STATS
+extern "C" int rm_debug_stats_n3(unsigned long long *out, int reset)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(rm::g_stats), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(rm::g_stats), z, sizeof(z)); }
+    return 0;
+}
+#endif

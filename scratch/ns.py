@@ -22,9 +22,9 @@ print(json.dumps({"workload": wl, "users": m, "users_per_s": m * steps / dt, "sw
 if os.environ.get("RM_PRINT_STATS"):
     import ctypes
     lib = binding.load()
-    lib = lib if hasattr(lib, "rm_debug_stats") else ctypes.CDLL(os.environ["RECOMETRICS_HIP_LIB"])
+    lib = ctypes.CDLL(os.environ["RECOMETRICS_HIP_LIB"])
     buf = (ctypes.c_ulonglong * 16)()
-    lib.rm_debug_stats(buf, 1)
+    getattr(lib, os.environ.get("RM_STATS_FN", "rm_debug_stats"))(buf, 1)
     runs = steps + 1
-    names = ["wave_steps", "event_steps", "event_lanes", "hit_cells", "hit_lanes", "merges", "merge_iters", "merge_replacing", "compactions", "compacted_entries"]
+    names = ["wave_steps", "event_steps", "event_lanes", "hit_cells", "hit_lanes", "merges", "merge_iters", "merge_replacing", "cyc_loop_g3s0", "cyc_wait_sync", "cyc_prologue", "cyc_loop", "cyc_epilogue", "tiles", "cyc_loop_sub1", "cyc_loop_sub2"]
     print(json.dumps({nm: buf[i] / runs for i, nm in enumerate(names)}))
