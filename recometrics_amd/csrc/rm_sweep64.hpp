@@ -428,17 +428,7 @@ void k_sweep64(Sweep64Args a)
                 const unsigned target = 4u * (unsigned)unit;
                 while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
             }
-            // the two sub-tile domains progress independently; the one that is behind gets the higher issue priority so that
-            // both reach the end of their ranges together (see the fp32 sweep)
-            if ((unit & 3) == 0) {
-                const u32x2 cnt2 = *(__attribute__((address_space(3))) const u32x2 *)(smem + a.sync_off);
-                const unsigned c0 = __builtin_amdgcn_readfirstlane(cnt2.x), c1 = __builtin_amdgcn_readfirstlane(cnt2.y);
-                const int sub_s = __builtin_amdgcn_readfirstlane(sub);
-                const unsigned mine = sub_s == 0 ? c0 : c1, other = sub_s == 0 ? c1 : c0;
-                if (mine + 2 < other) __builtin_amdgcn_s_setprio(2);
-                else if (mine > other + 2) __builtin_amdgcn_s_setprio(0);
-                else __builtin_amdgcn_s_setprio(1);
-            }
+            // (the fp32 sweep's priority balancing of the two domains was measured here too: 1.2 % slower at C5, not adopted)
             if (unit + 1 < nunits) {
                 const int nu = unit + 1;
                 stage(t0 + nu / NC, nu % NC, nu & 1);
