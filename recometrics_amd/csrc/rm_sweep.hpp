@@ -56,6 +56,9 @@ typedef __attribute__((address_space(3))) unsigned *LdsU32Ptr;
 // the select), v_cndmask -- so the compare / select pairs are written as inline asm in a software-pipelined order: the
 // select of score i issues after the compares of scores i+1 and i+2, which are the two wait states the hazard asks for
 // (three mask registers in rotation), and the LDS reads of a level are waited for in four groups instead of one by one.
+// (Measured and dropped: comparing into the EXEC mask -- v_cmpx, v_or of the step under the mask, s_mov exec -- is two vector
+// instructions and a scalar one per score and level instead of three vector ones, and 1.3 % (C2) to 2.4 % (NS) SLOWER: a
+// vector write of EXEC stalls the vector instruction behind it.  gpurun_out r4w.)
 #define RM_CMP_LT(m, p, x) asm volatile("v_cmp_lt_f32 %0, %1, %2" : "=s"(m) : "v"(p), "v"(x))
 #define RM_SEL(d, a, b, m) asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(m))
 __device__ __forceinline__ float hw_absmin3(float a, float b, float c) { float d; asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
