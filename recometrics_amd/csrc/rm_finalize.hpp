@@ -464,14 +464,16 @@ __global__ void k_finalize(FinalArgs<T, S> a)
     // ---- merge the partial top-K lists (each descending) and the validity stats ----
     unsigned short *head = head_base + threadIdx.x;               // head[q * FIN_THREADS]: entries of partial list q consumed
     S vmax = -(S)INFINITY, vmin = (S)INFINITY; bool any_nan = false;
+    const Entry<S> *PL = a.pl + (size_t)s0 * NP * K;
     for (int q = 0; q < NP; q++) {
-        head[q * FIN_THREADS] = 0;
+        // a part without entries (the sub-tile waves that share a group's LDS list write it once; item ranges this user's
+        // block was not cut into) is exhausted from the start: the merge below never loads from it
+        head[q * FIN_THREADS] = (!a.ext_topk && PL[(size_t)q * K].idx == IDX_EMPTY) ? (unsigned short)K : (unsigned short)0;
         const PartialStat<S> ps = a.pst[(size_t)s0 * NP + q];
         vmax = ps.vmax > vmax ? ps.vmax : vmax;
         vmin = ps.vmin < vmin ? ps.vmin : vmin;
         any_nan |= ps.has_nan != 0;
     }
-    const Entry<S> *PL = a.pl + (size_t)s0 * NP * K;
     for (int i = 0; i < (a.ext_topk ? 0 : K); i++) {            // (ext_topk: k_select_topk has written M already)
         int best = -1; Entry<S> be; be.s = 0; be.idx = 0;
         for (int q = 0; q < NP; q++) {
@@ -480,7 +482,8 @@ __global__ void k_finalize(FinalArgs<T, S> a)
             const Entry<S> e = PL[(size_t)q * K + hq];
             if (best < 0 || ent_before(e, be)) { best = q; be = e; }
         }
-        head[best * FIN_THREADS]++;
+        if (best >= 0) head[best * FIN_THREADS]++;
+        else be.idx = IDX_EMPTY;                                 // every part empty (e.g. all scores NaN)
         if (be.idx == IDX_EMPTY) { be.idx = -1; be.s = (S)qnan<float>(); }
         M[i] = be;
     }
