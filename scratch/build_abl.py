@@ -7,7 +7,7 @@ os.makedirs("scratch/libs", exist_ok=True)
 objs = [os.path.join(B.CSRC, os.path.splitext(s)[0] + ".o") for s in B.SOURCES if s != "rm_sweep32_n3.hip"]
 procs = []
 for spec in sys.argv[1:]:
-    name, flags = spec.split("=")
+    name, flags = spec.split("=", 1)
     obj = "scratch/libs/n3_%s.o" % name
     procs.append((name, obj, subprocess.Popen([B._hipcc()] + B.FLAGS + flags.split(",") + ["-c", os.path.join(B.CSRC, "rm_sweep32_n3.hip"), "-o", obj])))
 for name, obj, p in procs:
