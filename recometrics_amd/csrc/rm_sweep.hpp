@@ -125,9 +125,13 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
     float nx[16];
     #pragma unroll
     for (int r = 0; r < 16; r++) nx[r] = *(LdsF32Ptr)(at[r]);
-    float df[16];
+    float df[16];                                              // two differences per instruction (v_pk_add_f32)
     #pragma unroll
-    for (int r = 0; r < 16; r++) df[r] = nx[r] - v[r];
+    for (int r = 0; r < 16; r += 2) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 d2 = f32x2{nx[r], nx[r + 1]} - f32x2{v[r], v[r + 1]};
+        df[r] = d2.x; df[r + 1] = d2.y;
+    }
     const float dmin = hw_absmin3(hw_absmin3(hw_absmin3(df[0], df[1], df[2]), hw_absmin3(df[3], df[4], df[5]), hw_absmin3(df[6], df[7], df[8])),
                                   hw_absmin3(hw_absmin3(df[9], df[10], df[11]), hw_absmin3(df[12], df[13], df[14]), df[15]), df[15]);
     if (__any(dmin == 0.f)) {
