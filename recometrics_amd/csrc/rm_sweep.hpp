@@ -194,7 +194,7 @@ void k_sweep(SweepArgs a)
     constexpr bool AF_PREFETCH = !AF_RESIDENT && LMODE != LM_HBM_APPEND;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BUF_F4 = NG * 2 * TILE;                 // float4 per packed tile
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (scalar, and known to be)
     const int gi = wave & 3, sub = wave >> 2;                   // group in block / 32-item sub-tile
     const int ul = lane & 31, h = lane >> 5;
     // user blocks are sorted by positive-tree depth (cheapest first): launch the deepest (slowest) ones first so that
@@ -251,6 +251,8 @@ void k_sweep(SweepArgs a)
 
     // dense train rows (small item counts): one word per lane and tile instead of the cursor below
     const unsigned *tb_row = (a.train_bits && user >= 0) ? a.train_bits + (size_t)user * a.train_words : nullptr;
+    // (the rows are <= 1 GiB in all: a 32-bit word index, advanced by NSUB per tile, addresses them)
+    unsigned tb_idx = (a.train_bits && user >= 0) ? (unsigned)user * (unsigned)a.train_words + (unsigned)(t0 * NSUB + sub) : 0u;
     if (user >= 0 && !a.train_bits) {
         ntc = a.train_p[user]; nte = a.train_p[user + 1];
         // first train item at or after this wave's first item (lower_bound)
@@ -391,24 +393,31 @@ void k_sweep(SweepArgs a)
     // 1 KiB (64 lanes x 16 B, two 512-byte runs of the packed tile) to a lane-linear piece of the LDS image, which is
     // laid out [sub][g][h][32 items]: a sub-tile's 32 items are staged by the four waves that read them (one per user
     // group) and by nobody else, so those four are a synchronisation domain of their own (main loop). ----
+    // Addressing: the tile's base is scalar (64 bits: the packed image of 10M items is 5 GB), the lane's offset inside the
+    // tile is a per-sweep constant in one VGPR per piece, the LDS destination is an integer in M0 -- no 64-bit vector adds,
+    // no generic-to-LDS pointer casts (a null check each) per tile.
+    const unsigned lds_base = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)smem;
+    constexpr int STAGE_PIECES = (NG + 3) / 4;
+    unsigned stage_voff[STAGE_PIECES];
+    #pragma unroll
+    for (int j = 0; j < STAGE_PIECES; j++) stage_voff[j] = (unsigned)(((gi + 4 * j) * 2 * TILE + h * TILE + sub * 32 + ul) * 16);
     auto stage = [&](int unit, int buf) {                     // unit = tile * NC + chunk: contiguous in the packed image
 #ifdef RM_ABL_SAME_TILE
-        const float4 *src = a.Bp + (size_t)(unit & 7) * BUF_F4;
+        const char *src = (const char *)a.Bp + (size_t)(unit & 7) * (BUF_F4 * 16);
 #else
-        const float4 *src = a.Bp + (size_t)unit * BUF_F4;
+        const char *src = (const char *)a.Bp + (size_t)unit * (BUF_F4 * 16);
 #endif
-        float4 *dst = ldsB + buf * BUF_F4;
         // Issued through inline asm on purpose: with the builtin the compiler assumes every later LDS read may alias
         // the DMA's LDS write and puts s_waitcnt vmcnt(0) in front of the MFMA operand reads, which serialises the
         // prefetch with the step it was meant to overlap.  The wait that matters is the explicit one before the
         // end-of-step barrier.
         #pragma unroll
-        for (int j = 0; j < (NG + 3) / 4; j++) {
+        for (int j = 0; j < STAGE_PIECES; j++) {
             const int g = gi + 4 * j;
             if (NG % 4 == 0 || g < NG) {
-                const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)(dst + (sub * NG + g) * 64));
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-                             :: "s"(m0v), "v"(src + g * 2 * TILE + h * TILE + sub * 32 + ul) : "memory", "m0");
+                const unsigned m0v = lds_base + (unsigned)((buf * BUF_F4 + (sub * NG + g) * 64) * 16);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                             :: "s"(m0v), "v"(stage_voff[j]), "s"(src) : "memory", "m0");
             }
         }
     };
@@ -672,7 +681,7 @@ void k_sweep(SweepArgs a)
     LdsU32Ptr arrive = (LdsU32Ptr)(smem + a.sync_off) + sub;            // (words 4..7 of the area: the groups' list locks)
     if (tid < 4) ((LdsU32Ptr)(smem + a.sync_off))[tid] = 0u;
     if (ntiles > 0) stage(t0 * NC, 0);
-    unsigned tile_bits = (tb_row && ntiles > 0) ? tb_row[t0 * NSUB + sub] : 0u;       // first tile's word of the dense train row
+    unsigned tile_bits = (tb_row && ntiles > 0) ? a.train_bits[tb_idx] : 0u;           // first tile's word of the dense train row
     // vmcnt(0) through the builtin (not asm) so that the compiler's own wait-count bookkeeping sees the drain: every
     // load it issued before this point is known complete and needs no further wait inside the loop.
     __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);
@@ -724,7 +733,7 @@ void k_sweep(SweepArgs a)
             // the NEXT tile's word of the dense train row (the accumulators start from it): in flight during the MFMA phase,
             // drained by the wait at the arrive point
             unsigned bits_next = 0u;
-            if (c == NC - 1 && tb_row && i + 1 < ntiles) bits_next = tb_row[(t0 + i + 1) * NSUB + sub];
+            if (c == NC - 1 && tb_row && i + 1 < ntiles) { tb_idx += NSUB; bits_next = a.train_bits[tb_idx]; }
 #ifndef RM_ABL_NO_MFMA
             do_mfma(acc, unit & 1, c, tile_bits);
 #endif
