@@ -95,7 +95,7 @@ void k_sweep64(Sweep64Args a)
     const int NGTV = NGT_RT ? a.ngt : NGT;
     const int NC = NGT_RT ? a.ngt / NGC : NC_CT;
     constexpr int BUF_D2 = NGC * 4 * TILE_ITEMS;                // double2 per chunk buffer
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int gi = wave & 3, sub = wave >> 2;
     const int ul = lane & 15, q = lane >> 4;
     // user blocks are sorted by positive-tree depth (cheapest first): launch the deepest (slowest) ones first so that
@@ -250,18 +250,26 @@ void k_sweep64(Sweep64Args a)
     // unit u = (tile, chunk): contiguous BUF_D2 double2 of the packed image [tile][g][q][row][2].  The LDS image is
     // [sub][g][q][32 items]: a sub-tile is staged by the four waves that read it (see the fp32 sweep), 1 KiB pieces of
     // two 512-byte runs (q pair x 32 items)
+    // (addressing as in the fp32 sweep: scalar tile base, one constant VGPR offset per piece, integer M0)
+    const unsigned lds_base = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)smem;
+    constexpr int STAGE_PIECES = (NGC * 2 + 3) / 4;
+    unsigned stage_voff[STAGE_PIECES];
+    #pragma unroll
+    for (int j = 0; j < STAGE_PIECES; j++) {
+        const int pc = gi + 4 * j;                           // piece = (g, q pair)
+        stage_voff[j] = (unsigned)((((pc >> 1) * 4 + (pc & 1) * 2 + (lane >> 5)) * TILE_ITEMS + sub * 32 + (lane & 31)) * 16);
+    }
     auto stage = [&](int tile, int chunk, int buf) {
-        const f64x2 *src = a.Bp + ((size_t)tile * NGTV + (size_t)chunk * NGC) * 4 * TILE_ITEMS;
-        f64x2 *dst = ldsB + buf * BUF_D2 + sub * NGC * 128;
+        const char *src = (const char *)a.Bp + ((size_t)tile * NGTV + (size_t)chunk * NGC) * (4 * TILE_ITEMS * 16);
         // inline asm, not the builtin: see the note at the fp32 sweep's stage() (the compiler would otherwise wait for
         // the DMA in front of the next LDS read)
         #pragma unroll
-        for (int j = 0; j < (NGC * 2 + 3) / 4; j++) {
-            const int pc = gi + 4 * j;                       // piece = (g, q pair)
+        for (int j = 0; j < STAGE_PIECES; j++) {
+            const int pc = gi + 4 * j;
             if ((NGC * 2) % 4 == 0 || pc < NGC * 2) {
-                const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)(dst + pc * 64));
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-                             :: "s"(m0v), "v"(src + ((pc >> 1) * 4 + (pc & 1) * 2 + (lane >> 5)) * TILE_ITEMS + sub * 32 + (lane & 31)) : "memory", "m0");
+                const unsigned m0v = lds_base + (unsigned)((buf * BUF_D2 + sub * NGC * 128 + pc * 64) * 16);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                             :: "s"(m0v), "v"(stage_voff[j]), "s"(src) : "memory", "m0");
             }
         }
     };
