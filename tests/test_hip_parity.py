@@ -192,6 +192,19 @@ def test_list_schemes_agree(hip, oracle, env, dtype, monkeypatch):
     _check_against_oracle(hip, oracle, pr, 12, dtype=dtype)
 
 
+@pytest.mark.parametrize("splits", [None, "2,2,3", "1,1,4"])
+def test_depth_split_launches_with_a_two_level_grid(hip, oracle, splits, monkeypatch):
+    """128 factors, K = 32, users with deep and with shallow positive trees: the LDS lists fit next to the shallow blocks'
+    tables only, so the sweep runs as two launches side by side (deep blocks with HBM lists, shallow ones with LDS lists);
+    with a two-level grid the tail user blocks are the shallow launch's first, then the deep one's"""
+    from recometrics_amd.synth import make_problem
+    if splits:
+        monkeypatch.setenv("RM_DEBUG_SPLITS", splits)
+    pr = make_problem(700, 6000, 128, np.float32, mean_c=120, seed=77)
+    _check_against_oracle(hip, oracle, pr, 32)
+    assert hip.timings()["sweep_launches"] == 2, hip.timings()
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("budget", ["0", "1", None])
 def test_long_test_rows_streamed_or_chunked(hip, oracle, dtype, budget, monkeypatch):
