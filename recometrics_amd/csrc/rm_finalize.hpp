@@ -122,10 +122,14 @@ constexpr int STREAM_RANK_LDS = 20 * 1024;               // LDS per block: eight
 // per read at 3-5 bank cycles).  R = the largest power of two that fits next to the counters; rows too long even for one
 // copy are searched in global memory.  ILP independent searches per thread advance level by level, all reads of a level
 // in flight together.
-template <class S, int ILP>
-__device__ __forceinline__ void rank_streamed_lds(const S *row, long long i0, int ipt, int n, const int *pit, int P, int top, int lgsb,
+// LV = log2(table entries) as a template constant for the usual depths (the search steps become immediates: offset of the
+// LDS read, literal of the add), 0 = taken from `top` / `lgsb` at run time.  With LV known the copies fill 16 KiB.
+template <class S, int ILP, int LV>
+__device__ __forceinline__ void rank_streamed_lds(const S *row, long long i0, int ipt, int n, const int *pit, int P, int top_rt, int lgsb_rt,
                                                   unsigned tab_addr, unsigned hist_addr)
 {
+    const int top = LV ? (1 << LV) : top_rt;
+    const int lgsb = LV ? 14 - LV : lgsb_rt;               // 16 KiB of copies: entry stride = 2^14 / entries
     typedef __attribute__((address_space(3))) const S *LdsS;
     typedef __attribute__((address_space(3))) unsigned *LdsU;
     const unsigned sb = 1u << lgsb;                               // bytes between consecutive entries of the lane's copy
@@ -148,6 +152,7 @@ __device__ __forceinline__ void rank_streamed_lds(const S *row, long long i0, in
             v[q] = (nxt[q] == nxt[q] && item < n) ? nxt[q] : -(S)INFINITY; o[q] = 0;
         }
         load_batch(it + ILP, nxt);                                // the next batch's HBM latency hides behind this batch's searches
+        #pragma unroll
         for (unsigned st = ((unsigned)top >> 1) << lgsb; st >= sb; st >>= 1) {
             S pv[ILP];
             #pragma unroll
@@ -198,7 +203,13 @@ __global__ __launch_bounds__(STREAM_RANK_THREADS) void k_rank_streamed(FinalArgs
         for (int r = R; r > 1; r >>= 1) lgsb++;
         const unsigned tab_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char *)rk_smem + (unsigned)((threadIdx.x & (R - 1)) * sizeof(S));
         const unsigned hist_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds_h;
-        rank_streamed_lds<S, 8>(row, i0, ipt, a.n, pit, P, top, lgsb, tab_addr, hist_addr);
+        // (depth as a template constant when the copies fill the 4096-entry table: 64 ... 1023 positives)
+        const bool full = (long long)top * R == 4096 / per;
+        if (full && top == 128) rank_streamed_lds<S, 8, 7>(row, i0, ipt, a.n, pit, P, top, lgsb, tab_addr, hist_addr);
+        else if (full && top == 256) rank_streamed_lds<S, 8, 8>(row, i0, ipt, a.n, pit, P, top, lgsb, tab_addr, hist_addr);
+        else if (full && top == 512) rank_streamed_lds<S, 8, 9>(row, i0, ipt, a.n, pit, P, top, lgsb, tab_addr, hist_addr);
+        else if (full && top == 1024) rank_streamed_lds<S, 8, 10>(row, i0, ipt, a.n, pit, P, top, lgsb, tab_addr, hist_addr);
+        else rank_streamed_lds<S, 8, 0>(row, i0, ipt, a.n, pit, P, top, lgsb, tab_addr, hist_addr);
         __syncthreads();
         for (int i = threadIdx.x; i < P; i += STREAM_RANK_THREADS) { const unsigned c = lds_h[i]; if (c) atomicAdd(&a.shist[te0 + i], c); }
     } else {                                                      // very long row: search in global memory
