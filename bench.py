@@ -73,13 +73,13 @@ class DeviceProblem:
         self.nnz_tr, self.nnz_te = int(tri.shape[0]), int(tei.shape[0])
         self.out = torch.empty((10, m), dtype=torch.float32 if dtype == np.float32 else torch.float64, device=dev)   # per-user metric block
 
-    def step(self, binding, stream, out=None):
+    def step(self, binding, stream, out=None, noise=False):
         o = self.out if out is None else out
         binding.calc_metrics_device(
             self.dtype, self.A.data_ptr(), self.k, self.B.data_ptr(), self.k, self.m, self.n, self.k,
             self.trp.data_ptr(), self.tri.data_ptr(), self.nnz_tr, self.tep.data_ptr(), self.tei.data_ptr(),
             self.tev.data_ptr(), self.nnz_te, self.K, [o[i].data_ptr() for i in range(10)],
-            cumulative=False, break_ties_with_noise=False, stream=stream)
+            cumulative=False, break_ties_with_noise=noise, stream=stream)
 
 
 def load_traffic(workload, users):
@@ -307,6 +307,25 @@ def main():
             line["e2e_host"] = e2e_host(binding, prob)
         except Exception as e:      # noqa: BLE001
             line["e2e_host"] = {"error": repr(e)}
+
+    if rank == 0 and world == 1 and not args.no_extra:
+        # the API's default, break_ties_with_noise=True (exact mt19937 noise: a second pass over the users it can touch);
+        # `value` above is with the noise off, as the config string says
+        try:
+            stream = torch.cuda.current_stream().cuda_stream
+            scratch_out = torch.empty_like(prob.out)
+            prob.step(binding, stream, scratch_out, noise=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                prob.step(binding, stream, scratch_out, noise=True)
+            torch.cuda.synchronize()
+            dtn = (time.perf_counter() - t0) / 3
+            line["noise_on"] = {"users_per_s": m / dtn, "ms_per_step": dtn * 1e3,
+                                "what": "same workload with break_ties_with_noise=True (the API default), seed 1; never `value`"}
+            del scratch_out
+        except Exception as e:      # noqa: BLE001
+            line["noise_on"] = {"error": repr(e)}
 
     if rank == 0 and world == 1 and not args.no_extra and args.workload != "NS":
         # the north-star shape (n = 1M items, 128 factors): B = 512 MB does not fit the Infinity Cache

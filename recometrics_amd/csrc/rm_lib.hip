@@ -395,8 +395,10 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     int n_splits = 1, tail_ublocks = 0, tail_splits = 0;
     if (n_ublocks > 0) {
         const int n_cu = 256;
-        const int max_splits = std::max(1, std::min(MAX_PARTS / nsub, tiles_total / 128));
-        const int max_tail = std::max(1, std::min(MAX_PARTS / nsub, tiles_total / 48));
+        // (ranges of at least 16 tiles: a call with few users -- the second, exact pass of the tie noise over the flagged
+        // users, a small batch -- is cut into many ranges so that its few user blocks still fill the chip)
+        const int max_splits = std::max(1, std::min(MAX_PARTS / nsub, tiles_total / 16));
+        const int max_tail = max_splits;
         const double fixed = 13.0 + 0.004 * std::max(0.25, K / 10.0) * tiles_total;
         auto block = [&](int sct) { return (double)tiles_total / sct + fixed; };
         auto last = [&](double rounds) { return std::max(std::ceil(rounds - 1e-9), rounds + 0.2); };

@@ -93,15 +93,15 @@ def test_interrupt_between_batches(hip, monkeypatch):
     pr = _interruptible_problem()
     m = pr["A"].shape[0]
     full = _calc(hip, pr, 10)
-    monkeypatch.setenv("RM_BATCH_USERS", "1024")
+    monkeypatch.setenv("RM_BATCH_USERS", "256")          # 160 batches: the call outlasts the timer by a wide margin
     outs = [np.full(m, -7.0, np.float32) for _ in range(10)]
-    t = threading.Timer(0.05, hip.request_interrupt)
+    t = threading.Timer(0.03, hip.request_interrupt)
     t.start()
     with pytest.raises(RuntimeError, match="procedure was interrupted"):
         _calc(hip, pr, 10, outs=outs)
     t.join()
     done = int((outs[0] != -7.0).sum() if not np.isnan(outs[0]).any() else (~(outs[0] == -7.0)).sum())
-    assert 1024 <= done < m and done % 1024 == 0, "finished users: %d of %d" % (done, m)
+    assert 256 <= done < m and done % 256 == 0, "finished users: %d of %d" % (done, m)
     for name, g, w in zip(hip.METRIC_ORDER, outs, full):
         assert_same_bits(g[:done], w[:done], name + " of the users finished before the interrupt")
         assert (g[done:] == -7.0).all(), name + ": users after the interrupt must be untouched"
@@ -115,9 +115,9 @@ def test_sigint_during_a_call_becomes_keyboard_interrupt(hip, monkeypatch):
     """a real SIGINT: the library's handler takes it during the call, then restores Python's handler and re-raises the
     signal, so that the caller sees KeyboardInterrupt (reference :166-173 + recometrics/wrapper.pyx `except +`)"""
     pr = _interruptible_problem()
-    monkeypatch.setenv("RM_BATCH_USERS", "1024")
+    monkeypatch.setenv("RM_BATCH_USERS", "256")           # 160 batches: the signal arrives while the call is running
     before = signal.getsignal(signal.SIGINT)
-    t = threading.Timer(0.05, lambda: os.kill(os.getpid(), signal.SIGINT))
+    t = threading.Timer(0.03, lambda: os.kill(os.getpid(), signal.SIGINT))
     t.start()
     with pytest.raises((KeyboardInterrupt, RuntimeError)) as ei:
         _calc(hip, pr, 10)
