@@ -241,6 +241,7 @@ void k_sweep(SweepArgs a)
     float thr = primary ? neg_inf_f() : nan_sentinel_f();        // NaN threshold: "v >= thr" never true
 #endif
     float vmax = neg_inf_f(), vmin = pos_inf_f();
+    bool track_min = true;                                      // wave-uniform (see the validity scan of the epilogue)
     unsigned long long nanmask = 0;
     int ntc = 0, nte = 0, nt = IDX_EMPTY, nt2 = IDX_EMPTY;     // train cursor: next item and the one after (prefetched)
 
@@ -543,9 +544,17 @@ void k_sweep(SweepArgs a)
         float qmax[4] = {hw_max3(v[0], v[1], hw_max(v[2], v[3])), hw_max3(v[4], v[5], hw_max(v[6], v[7])),
                          hw_max3(v[8], v[9], hw_max(v[10], v[11])), hw_max3(v[12], v[13], hw_max(v[14], v[15]))};
         float tmax = hw_max3(qmax[0], qmax[1], hw_max(qmax[2], qmax[3]));
-        const float tmin = hw_min3(hw_min3(v[0], v[1], v[2]), hw_min3(v[3], v[4], v[5]), hw_min3(v[6], v[7], v[8]));
-        const float tmin2 = hw_min3(hw_min3(v[9], v[10], v[11]), hw_min3(v[12], v[13], v[14]), v[15]);
-        vmax = hw_max(vmax, tmax); vmin = hw_min3(vmin, tmin, tmin2);
+        vmax = hw_max(vmax, tmax);
+        // The minimum is only ever compared with the maximum (all candidates equal, :524) and tested for infinity (:522).  When
+        // the host has proved every score finite, it is tracked until every lane of the wave has seen two different scores
+        // -- from then on "min < max" is settled for good and the eight instructions per tile are skipped (what is reported
+        // is the minimum of the tiles seen until then: still below the maximum, which is all k_finalize asks of it).
+        if (track_min) {
+            const float tmin = hw_min3(hw_min3(v[0], v[1], v[2]), hw_min3(v[3], v[4], v[5]), hw_min3(v[6], v[7], v[8]));
+            const float tmin2 = hw_min3(hw_min3(v[9], v[10], v[11]), hw_min3(v[12], v[13], v[14]), v[15]);
+            vmin = hw_min3(vmin, tmin, tmin2);
+            if (!a.check_nan) track_min = __any(slot_ok && !(vmax > vmin));
+        }
         // tie noise (reference :531-534: added AFTER the validity scan, in real_t): wave-uniform branch, exact passes only
         if (a.noise_E) {
             if (noise_lane) {
