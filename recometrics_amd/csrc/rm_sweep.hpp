@@ -750,7 +750,9 @@ void k_sweep(SweepArgs a)
 #ifndef RM_ABL_NO_ARRIVE_WAIT
             __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                              // arrive half: the next unit's DMA share has landed
 #endif
-            if (lane == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // (a bare ds_add: the builtin goes through the compiler's wave-aggregation of atomics, a dozen instructions per tile;
+            // the wave's LDS operations are issued in order, so the arrival cannot overtake its operand reads)
+            if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"((unsigned)(__UINTPTR_TYPE__)arrive), "v"(1u) : "memory");
 #endif
 #ifndef RM_ABL_NO_EPI
             if (c == NC - 1) do_epi(acc, t0 + i, thr_seen, tile_bits);

@@ -462,7 +462,7 @@ void k_sweep64(Sweep64Args a)
                 chi = __builtin_amdgcn_mfma_f64_16x16x4f64(b1.y, u.y, chi, 0, 0, 0);
             }
             __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                              // arrive half: the next unit's DMA share has landed
-            if (lane == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"((unsigned)(__UINTPTR_TYPE__)arrive), "v"(1u) : "memory");     // (see the fp32 sweep)
             if (c == NC - 1) do_epi(clo, chi, t0 + i, thr_seen);
         }
         thr_seen = thr_next;
