@@ -5,7 +5,7 @@ R=$(pwd)
 python bench.py > $O/r2_bench_default.json 2> $O/bench_default.err
 python bench.py --workload NS --no-extra > $O/r2_bench_NS.json 2> $O/bench_NS.err
 python bench.py --workload C3 --no-extra > $O/r2_bench_C3.json 2> $O/bench_C3.err
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_def -o p -- python3 $R/bench.py --no-cpu > /dev/null 2> $R/$O/prof_default.err; find /tmp/prof_def -name "*kernel_stats.csv" -exec cp {} $R/$O/r2_bench_default_kernel_stats.csv \; )
+bash scratch/profile_stats.sh   # kernel stats of the timed launches only (gpurun_out/r2_stats)
 bash scratch/pmc_traffic.sh C2 138493 $O/traffic_C2 > $O/traffic_C2.log 2>&1
 bash scratch/pmc_sq.sh C2 138493 $O/sq_C2 > /dev/null 2>&1
 bash scratch/pmc_sq.sh NS 32768 $O/sq_NS > /dev/null 2>&1
