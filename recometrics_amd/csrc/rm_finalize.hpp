@@ -246,7 +246,7 @@ __global__ __launch_bounds__(SELECT_THREADS) void k_select_topk(FinalArgs<T, S> 
     __shared__ unsigned hist[256];
     __shared__ unsigned long long sh_prefix;
     __shared__ int sh_remaining, sh_gt, sh_wsum[SELECT_THREADS / WAVE], sh_taken;
-    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slot = a.stream_slot0 + row;
     const int u = a.slot_user[slot];
     const int n = a.n, K = a.K;
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(SELECT_THREADS) void k_select_topk(FinalArgs<T, S> 
 template <class T, class S>
 __global__ void k_auc_streamed(FinalArgs<T, S> a, int row0, int row1)
 {
-    const int w = row0 + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    const int w = row0 + __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     if (w >= row1) return;
     const int slot = a.stream_slot0 + w;
     const int u = a.slot_user[slot];
@@ -387,7 +387,7 @@ __global__ void k_auc_streamed(FinalArgs<T, S> a, int row0, int row1)
 template <class T, class S>
 __global__ void k_top_values(FinalArgs<T, S> a)
 {
-    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;     // (a wave's index: uniform, and known to be)
     if (w >= a.n_heavy) return;
     const int u = a.heavy_users[w];
     const int te0 = a.test_p[u], npos = a.test_p[u + 1] - te0;

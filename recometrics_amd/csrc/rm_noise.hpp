@@ -37,7 +37,7 @@ __global__ __launch_bounds__(MT_WAVES * WAVE) void k_mt_draws(const int *row_use
                                                                 const int *train_p, int n, int per_item, unsigned *draws, long long ld)
 {
     __shared__ unsigned state[MT_WAVES][MT_N];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int row = blockIdx.x * MT_WAVES + wv;
     if (row >= n_rows) return;
     const int u = row_user ? row_user[row] : row;

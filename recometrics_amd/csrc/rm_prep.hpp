@@ -100,7 +100,7 @@ __global__ void k_classify(ClassifyArgs a)
 __global__ __launch_bounds__(1024) void k_scan_tiles(const int *in, int *out, int count, int *tile_total)
 {
     __shared__ int wsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = blockIdx.x * 1024 + tid;
     const int v = i < count ? in[i] : 0;
     int x = v;
@@ -124,7 +124,7 @@ __global__ void k_scan_exclusive(const int *in, int *out, int count, int *total_
 {
     __shared__ int wsum[16];
     __shared__ int carry_s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid == 0) carry_s = 0;
     __syncthreads();
     for (int base = 0; base < count; base += 1024) {
@@ -324,7 +324,7 @@ constexpr int TRAIN_BITS_WAVES = 4;
 __global__ __launch_bounds__(TRAIN_BITS_WAVES * WAVE) void k_train_bits(int m, int n, int words, const int *train_p, const int *train_i, unsigned *bits)
 {
     extern __shared__ unsigned tb_lds[];                      // [TRAIN_BITS_WAVES][words]
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     unsigned *row = tb_lds + (size_t)wv * words;
     for (int u = blockIdx.x * TRAIN_BITS_WAVES + wv; u < m; u += gridDim.x * TRAIN_BITS_WAVES) {
         for (int w = lane; w < words; w += WAVE) row[w] = (w << 5) >= n ? 0xffffffffu : (((w << 5) + 32 > n) ? (0xffffffffu << (n & 31)) : 0u);
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(POSS_WAVES * WAVE) void k_pos_scores(PosArgs<T> a, 
     constexpr int RPI = WAVE / CH;                              // rows covered by one load instruction
     constexpr int LD = CH + 1;                                  // padded row stride in LDS (conflict-free row walks)
     __shared__ T rows[POSS_WAVES][WAVE][LD];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int w = blockIdx.x * POSS_WAVES + wv;
     if (w >= n_slots) return;
     const int u = slot_user[w], c0 = slot_chunk[w];
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(POSS_WAVES * WAVE) void k_pos_scores(PosArgs<T> a, 
 template <class T>
 __global__ void k_pos_place(PosArgs<T> a, const int *slot_user, const int *slot_chunk, int n_slots)
 {
-    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;     // (a wave's index: uniform, and known to be)
     if (w >= n_slots) return;
     const int u = slot_user[w], c0 = slot_chunk[w];
     if (a.flags[u] & UF_ONLY_NDCG) return;
