@@ -457,8 +457,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     }
 
     Entry<T> *merged = (Entry<T> *)ws.get("merged", sizeof(Entry<T>) * (size_t)m * K);
-    // the argument block of the finalisation kernels is filled in as the pieces come into being: the ranks of the streamed
-    // users are taken on a second stream while the sweep of the other users is still running
+    // the argument block of the finalisation kernels is filled in as the pieces come into being
     long long *rank_sorted = nullptr;
     if (c.pos_rank) rank_sorted = (long long *)ws.get("rank_sorted", sizeof(long long) * (size_t)std::max<long long>(c.nnz_test, 1));
     if (rank_sorted) HIP_CHECK(hipMemsetAsync(rank_sorted, 0, sizeof(long long) * (size_t)std::max<long long>(c.nnz_test, 1), stream));
@@ -474,7 +473,6 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     fa.n_slots = n_slots; fa.slot_user = slot_user; fa.slot_chunk = slot_chunk;
     fa.stream_slot0 = stream_slot0;
     if (want_auc && n_slots > 0) fa.auc_part = (AucPart *)ws.get("auc_part", sizeof(AucPart) * (size_t)n_slots);
-    int stream_rows_done = 0; bool ranked_beside = false;  // rows [stream_rows_done, n_stream) were ranked beside the sweep
     const int stream_parts = (int)cdiv(n, STREAM_RANK_THREADS * STREAM_RANK_ITEMS);
     const int stream_ipt = ((int)cdiv(n, (long long)stream_parts * STREAM_RANK_THREADS) + 7) / 8 * 8;     // equal pieces of the row
     auto rank_streamed_rows = [&](int r0, int r1, hipStream_t st) {
@@ -596,11 +594,9 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             // blocks, the side launch ran AFTER the main one instead of beside it: 61 ms of tail.  gpurun_out r2q.)
             dispatch_sweep(want_auc, false, list_in_lds, nsub, NG, dim3(n_blocks), lds_total, stream, sa);
         }
-        if (!ranked_beside) {
-            HIP_CHECK(hipEventRecord(g_ev[2], stream));
-            g_timings[4] = u_split > 0 ? 2 : 1; g_timings[5] = n_splits; g_timings[6] = n_blocks; g_timings[7] = (double)lds_total;
-            cx.timed_slots = n_slots;
-        }
+        HIP_CHECK(hipEventRecord(g_ev[2], stream));
+        g_timings[4] = u_split > 0 ? 2 : 1; g_timings[5] = n_splits; g_timings[6] = n_blocks; g_timings[7] = (double)lds_total;
+        cx.timed_slots = n_slots;
         cx.total_slots = n_slots;
     } else {
         HIP_CHECK(hipEventRecord(g_ev[1], stream));
@@ -629,7 +625,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     if (n_slots > 0) {
         if (want_auc) {
             fa.spos_score = spos_score; fa.spos_item = spos_item; fa.shist = shist;
-            if (n_stream > 0) rank_streamed_rows(0, ranked_beside ? stream_rows_done : n_stream, stream);
+            if (n_stream > 0) rank_streamed_rows(0, n_stream, stream);
             if (stream_slot0 > 0) hipLaunchKernelGGL((k_auc_slots<T, T>), dim3(cdiv(stream_slot0, 256)), dim3(256), 0, stream, fa);
         }
         const size_t fin_lds = finalize_lds_bytes<T>(K, n_part);

@@ -10,8 +10,9 @@
 //                  quantity of the epilogue (K-th best threshold, min, max, train cursor, AUC partial sum) is then ONE
 //                  VGPR, and the per-user LDS tables (sorted positives, rank histogram, top-K list) are laid out
 //                  [row][32 users] so that lane u always hits bank u: conflict-free whatever the data.
-//   block          512 threads = 8 wavefronts = 4 user groups x 2 item sub-tiles (128 users x 64 items per step).
-//                  Wavefronts w and w+4 share a SIMD and a user group.  An f32-input MFMA chain does not co-execute
+//   block          4 user groups x NSUB item sub-tiles of 32 = 4 NSUB wavefronts (NSUB = 2: 512 threads, 128 users x 64
+//                  items per step; NSUB = 3 up to 64 factors).  Wavefronts w, w+4 (, w+8) share a SIMD and a user group;
+//                  the top-K list of a group is one LDS list shared by them.  An f32-input MFMA chain does not co-execute
 //                  with VALU / LDS work of the SIMD partner (scratch/coexec2.hip: time = sum), so the epilogue's
 //                  instructions add to the MFMA time and the lever is the epilogue's instruction count.
 //   operands       user factors live in registers for the whole sweep (NG float4 per lane, up to 128 factors; beyond
@@ -19,7 +20,10 @@
 //                  k_pack_items) stream HBM -> LDS by LDS-DMA (inline asm), double buffered.
 //   synchronisation  a split barrier on an LDS arrival counter instead of s_barrier per tile: arrive after the tile's
 //                  last MFMA, wait before the next tile touches the buffers, the whole epilogue in between -- per
-//                  sub-tile (the four waves that stage and read the same 32 items), not per block.
+//                  sub-tile (the four waves that stage and read the same 32 items), not per block; the sub-tile that is
+//                  behind gets the higher issue priority (s_setprio), so that all reach the end of the range together.
+//   grid           two levels (rm_launch.hpp): whole rounds of blocks with n_splits item ranges, then the cheapest user
+//                  blocks cut into tail_splits smaller ranges that fill the last round.
 //   diagnostics    the RM_ABL_* macros compile single stages out (wrong results, timing only): they are how the cost
 //                  breakdown in DESIGN.md was measured and are never defined in a product build.
 #pragma once
