@@ -708,7 +708,7 @@ void k_sweep(SweepArgs a)
         return (primary && !DUMP) ? __hip_atomic_load(a.thr_shared + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #endif
     };
-    unsigned thr_seen = 0u;
+    unsigned thr_seen = load_thr();                             // (the seeded bound counts from the first tile on)
 #ifdef RM_STATS
     const unsigned long long prof_t1 = __builtin_readcyclecounter();
 #endif

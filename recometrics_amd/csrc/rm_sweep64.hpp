@@ -423,7 +423,8 @@ void k_sweep64(Sweep64Args a)
     if (ntiles > 0) stage(t0, 0, 0);
     __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);      // builtin: the compiler's wait-count bookkeeping sees the drain
     __syncthreads();
-    unsigned long long thr_seen = 0ull;           // shared K-th-best bound, read one tile ahead (drained by the closing wait)
+    // shared K-th-best bound, read one tile ahead (drained by the closing wait); the seeded bound counts from the first tile on
+    unsigned long long thr_seen = (primary && !DUMP) ? __hip_atomic_load(a.thr_shared + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     for (int i = 0; i < ntiles; i++) {
         const unsigned long long thr_next = (primary && !DUMP) ? __hip_atomic_load(a.thr_shared + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         // resident user factors are indexed af[c * NGC + gl]: the chunk loop must then be unrolled; when each chunk's
