@@ -165,6 +165,9 @@ def cpu_baseline(host, K, n_users_total, budget_s, dtype=np.float32):
     t_probe = run(probe)
     nu = int(min(n_users_total, max(probe, probe * budget_s / max(t_probe, 1e-6))))
     t = run(nu) if nu > probe else t_probe
+    if t < 0.6 * budget_s and nu < n_users_total:          # the small probe overestimates the per-user cost (thread start-up): once more
+        nu = int(min(n_users_total, nu * budget_s / max(t, 1e-6)))
+        t = run(nu)
     how = "the reference built by oracle/Makefile with -march=x86-64-v3 (its default user build is -march=native)" if kind == "reference" else "oracle/ restatement"
     return {"value": nu / t, "unit": "users/s", "cores": ncores, "kind": kind,
             "sample": "%d of %d users of the same workload, all metrics, K=%d, %d threads, %.1f s; %s" % (nu, n_users_total, K, ncores, t, how)}
