@@ -651,10 +651,14 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
 // fp32: the noise only changes scores below 2^-15 in magnitude; a first pass evaluates everybody on the plain scores and
 // flags the users who have such a score among their test items or their top-K -- the only ones whose ranking the noise
 // can touch -- and only those are evaluated again, exactly.
+std::atomic<unsigned long long> g_call_counter{1};       // tags of calls: the packed item image survives between the passes / batches of one
+
 template <class T>
-void run_call(const Call<T> &c0, hipStream_t stream, Ctx &cx)
+void run_call(const Call<T> &c_in, hipStream_t stream, Ctx &cx)
 {
-    if (!c0.noise || getenv("RM_NOISE_OFF")) { run<T>(c0, stream, cx); return; }     // RM_NOISE_OFF: A/B timing only
+    if (!c_in.noise || getenv("RM_NOISE_OFF")) { run<T>(c_in, stream, cx); return; }     // RM_NOISE_OFF: A/B timing only
+    Call<T> c0 = c_in;
+    if (c0.items_tag == 0) c0.items_tag = g_call_counter.fetch_add(1);                   // (a device-pointer call: its passes share B)
     Workspace &ws = cx.ws;
     const int m = c0.m, n = c0.n;
     const int per = sizeof(T) == 4 ? 1 : 2;
@@ -783,7 +787,6 @@ struct SharedItems {
     const void *src = nullptr; int src_device = 0;
 };
 
-std::atomic<unsigned long long> g_call_counter{1};
 
 // Users [u0, u1) of a host call on the current device: stage the inputs of the range into HBM, evaluate them in batches
 // small enough to look at the interrupt flag a few times per second, copy each batch's outputs straight into the caller's
