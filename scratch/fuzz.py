@@ -31,6 +31,10 @@ for it in range(cases):
     pr = make_problem(m, n, k, dtype, mean_c=mean_c, seed=int(rng.integers(1 << 30)))
     if kw["noise"] and rng.random() < 0.5:          # cold items: blocks of exactly tied scores that only the noise orders
         pr["B"] = pr["B"].copy(); pr["B"][rng.random(n) < 0.2] = 0
+    if os.environ.get("FUZZ_TIES") and not kw["noise"]:   # exact ties without noise (deviation D4: item order): cold items and duplicated items
+        pr["B"] = pr["B"].copy(); pr["B"][rng.random(n) < 0.15] = 0
+        dup = rng.random(n) < 0.2
+        pr["B"][dup] = pr["B"][rng.integers(0, n, int(dup.sum()))]
     try:
         want = oracle.calc(pr["A"], pr["B"], pr["train"], pr["test"], K, dtype=dtype, nthreads=8, **kw)
         got = hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], K, dtype=dtype, **kw)
