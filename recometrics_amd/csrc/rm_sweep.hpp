@@ -148,7 +148,7 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
             if (df[r] == 0.f) {
                 const int item = sb + mfma32_row(r, h);
                 unsigned t = at[r] - pos_addr;                       // row t holds a positive with exactly this score
-                while (pos_item_g[t >> 2] > item) {
+                while (*(const int *)((const char *)pos_item_g + t) > item) {        // (the id table has the score table's [row][32 users] layout)
                     t += 128;
                     if (!(t < (unsigned)(((1 << J) - 1) * 128) && *(LdsF32Ptr)(pos_addr + t) == v[r])) break;
                 }
