@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="N > 1: weak = every GPU evaluates a full-size shard; strong = the workload's users are split over the GPUs")
-    ap.add_argument("--parity-users", type=int, default=64, help="users of the timed outputs compared with the oracle (0 = skip)")
+    ap.add_argument("--parity-users", type=int, default=2048, help="users of the timed outputs compared with the reference (0 = skip)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-pointer (PCIe-inclusive) measurement")
     return ap.parse_args()
 
@@ -93,29 +93,76 @@ def load_traffic(workload, users):
         return None
 
 
-def parity_check(prob, torch, n_users):
-    """verify parity on the same inputs in the same run before accepting a number -- the first `n_users`
-    users of the timed outputs against the oracle (metrics within 1e-5, identical NaN pattern)."""
-    from oracle import oracle as orc
-    nu = int(min(n_users, prob.m))
-    host = prob.host
+def stratified_users(host, n_users, seed=0):
+    """A sample of users that covers the code paths the timed launch takes: the heaviest test rows (streamed users: more than
+    63 test items), users without train items (cold start), users without test items (skipped), the first and the last user
+    block of the launch order, and a random remainder.  Sorted, unique."""
+    trp, tep = host["train"][0], host["test"][0]
+    m = len(tep) - 1
+    if n_users >= m:
+        return np.arange(m)
+    ntest, ntrain = np.diff(tep), np.diff(trp)
+    q = max(1, n_users // 8)
+    rng = np.random.default_rng(seed)
+    pick = [np.argsort(-ntest, kind="stable")[:q],                               # heaviest rows
+            np.flatnonzero(ntest > 63)[:q], np.flatnonzero(ntrain == 0)[:q], np.flatnonzero(ntest == 0)[:q],
+            np.flatnonzero((ntest > 31) & (ntest <= 63))[:q],                       # deepest LDS tables
+            np.arange(min(q, m)), np.arange(max(0, m - q), m)]
+    got = np.unique(np.concatenate(pick))
+    rest = np.setdiff1d(np.arange(m), got)
+    extra = rng.choice(rest, size=max(0, min(rest.shape[0], n_users - got.shape[0])), replace=False)
+    return np.unique(np.concatenate([got, extra]))
+
+
+def sub_problem(host, users):
+    """Rows `users` of the host copy of the workload as a problem of its own (CSR rows gathered, pointers rebuilt)."""
     trp, tri = host["train"]
     tep, tei, tev = host["test"]
-    sub_tr = (trp[:nu + 1], tri[:trp[nu]] if trp[nu] else np.zeros(1, np.int32))
-    sub_te = (tep[:nu + 1], tei[:tep[nu]], tev[:tep[nu]])
-    want = orc.Oracle().calc(host["A"][:nu], host["B"], sub_tr, sub_te, prob.K, nthreads=min(64, os.cpu_count() or 1),
-                             noise=False, dtype=prob.dtype)
-    got = prob.out[:, :nu].cpu().numpy()
+
+    def gather(p, *arrs):
+        cnt = (p[users + 1] - p[users]).astype(np.int64)
+        newp = np.zeros(users.shape[0] + 1, np.int64)
+        np.cumsum(cnt, out=newp[1:])
+        idx = np.repeat(p[users].astype(np.int64) - newp[:-1], cnt) + np.arange(newp[-1])
+        return (newp.astype(np.int32),) + tuple(a[idx] for a in arrs)
+    ntrp, ntri = gather(trp, tri)
+    ntep, ntei, ntev = gather(tep, tei, tev)
+    if ntri.shape[0] == 0:
+        ntri = np.zeros(1, np.int32)
+    return host["A"][users], host["B"], (ntrp, ntri), (ntep, ntei, ntev)
+
+
+def parity_check(prob, out, n_users, noise=False, seed=1):
+    """verify parity on the same inputs in the same run before accepting a number -- a stratified sample of
+    the users of the timed outputs (`out`: the [10, m] metric block on the device) against the REAL reference compiled by
+    oracle/Makefile (oracle/_ref, canonical build) when it is present, else against the restatement: metrics within 1e-5,
+    identical NaN pattern.  With `noise` the reference draws its mt19937(seed + user) tie noise per ORIGINAL user index, so
+    the sample is evaluated user by user range: contiguous runs keep their indices through `user0`-free calls only when they
+    start at 0 -- the noise check therefore uses the first users plus nothing else."""
+    from oracle import oracle as orc
+    host = prob.host
+    users = np.arange(min(n_users, prob.m)) if noise else stratified_users(host, n_users)
+    A, B, tr, te = sub_problem(host, users)
+    impl, kind = (orc.Reference(), "reference") if orc.reference_available() else (orc.Oracle(), "port")
+    want = impl.calc(A, B, tr, te, prob.K, nthreads=min(256, os.cpu_count() or 1), noise=noise, seed=seed, dtype=prob.dtype)
+    got = out[:, torch_index(out, users)].cpu().numpy()
+    info = {"users": int(users.shape[0]), "checker": kind, "streamed_users": int((np.diff(te[0]) > 63).sum()),
+            "cold_users": int((np.diff(tr[0]) == 0).sum()), "sample": "first users" if noise else "stratified"}
     worst = 0.0
     for i, name in enumerate(orc.METRICS):
         w, g = want[orc.NAMES[name]], got[i]
         if not (np.isnan(w) == np.isnan(g)).all():
-            return {"users": nu, "ok": False, "what": "NaN pattern of %s" % name}
+            return dict(info, ok=False, what="NaN pattern of %s" % name)
         d = float(np.nanmax(np.abs(w.astype(np.float64) - g.astype(np.float64)), initial=0.0))
         worst = max(worst, d)
         if d > 1e-5:
-            return {"users": nu, "ok": False, "what": "%s differs by %g" % (name, d)}
-    return {"users": nu, "ok": True, "max_abs_diff": worst}
+            return dict(info, ok=False, what="%s differs by %g" % (name, d))
+    return dict(info, ok=True, max_abs_diff=worst)
+
+
+def torch_index(out, users):
+    import torch
+    return torch.from_numpy(users.astype(np.int64)).to(out.device)
 
 
 def e2e_host(binding, prob, reps=3):
@@ -246,6 +293,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend, rank=rank, world_size=world)
+    # what a SCALE record can be checked against: the ranks the collective library really has (0 = no process group)
+    rccl_ranks = dist.get_world_size() if (world > 1 and dist.is_initialized()) else 0
+    comm_backend = dist.get_backend() if (world > 1 and dist.is_initialized()) else None
     torch.cuda.set_device(local_rank)
     binding.load()
     binding.set_device(local_rank)
@@ -281,7 +331,8 @@ def main():
     achieved_tf = flops_per_launch / (sweep_ms * 1e-3) / 1e12
     line = {
         "metric": "users/sec evaluated (all metrics, K=%d)" % K, "value": users_per_s, "unit": "users/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "n_gpus": world, "rccl_ranks": rccl_ranks, "comm_backend": comm_backend,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": dname, "data": "synthetic",
         "config": {"workload": "%s: %d users/GPU x %d items, %d factors %s, K=%d, all 10 metrics, noise off"
                                % (args.workload, m, n, k, dname, K),
@@ -299,7 +350,7 @@ def main():
     failed = False
     if rank == 0 and args.parity_users > 0:
         try:
-            pc = parity_check(prob, torch, args.parity_users)
+            pc = parity_check(prob, prob.out, args.parity_users)
         except Exception as e:      # noqa: BLE001
             pc = {"users": 0, "ok": False, "what": repr(e)}
         line["parity_checked"] = pc["users"] if pc["ok"] else 0
@@ -326,6 +377,9 @@ def main():
             dtn = (time.perf_counter() - t0) / 3
             line["noise_on"] = {"users_per_s": m / dtn, "ms_per_step": dtn * 1e3,
                                 "what": "same workload with break_ties_with_noise=True (the API default), seed 1; never `value`"}
+            if args.parity_users > 0:
+                line["noise_on"]["parity"] = parity_check(prob, scratch_out, min(args.parity_users, 1024), noise=True, seed=1)
+                failed = failed or not line["noise_on"]["parity"]["ok"]
             del scratch_out
         except Exception as e:      # noqa: BLE001
             line["noise_on"] = {"error": repr(e)}
@@ -337,17 +391,22 @@ def main():
             m2 = 32768
             del prob.A, prob.B
             p2 = DeviceProblem(torch, dev, m2, n2, k2, c2, s2, K2)
-            dt2, sw2, pr2, fi2, _ = measure(torch, dist, binding, p2, 2, 1, 1, None)
+            ns_steps, ns_warmup = 5, 2
+            dt2, sw2, pr2, fi2, _ = measure(torch, dist, binding, p2, ns_steps, ns_warmup, 1, None)
             tm2 = binding.timings()
             sh2 = (tm2.get("timed_slots") or 0) / tm2["total_slots"] if tm2.get("total_slots") else 1.0
             tf2 = 2.0 * n2 * k2 * m2 * sh2 / (sw2 * 1e-3) / 1e12
             line["north_star_shape"] = {
                 "workload": "NS: %d users x %d items, %d factors fp32, K=%d, all metrics" % (m2, n2, k2, K2),
-                "users_per_s": m2 * 2 / dt2, "sweep_ms": sw2, "prep_ms": pr2, "finalize_ms": fi2,
+                "users_per_s": m2 * ns_steps / dt2, "steps": ns_steps, "warmup": ns_warmup, "ms_per_step": dt2 / ns_steps * 1e3,
+                "sweep_ms": sw2, "prep_ms": pr2, "finalize_ms": fi2,
                 "mfma_TFLOPs": tf2, "mfma_frac": tf2 / PEAK_FP32_MFMA_TFLOPS,
                 "main_launch_share_of_users": sh2,
                 "hbm_equiv_GBs": n2 * k2 * 4.0 * m2 * sh2 / (sw2 * 1e-3) / 1e9,
                 "hbm_equiv_frac": n2 * k2 * 4.0 * m2 * sh2 / (sw2 * 1e-3) / 1e9 / PEAK_HBM_GBS}
+            if args.parity_users > 0:
+                line["north_star_shape"]["parity"] = parity_check(p2, p2.out, min(args.parity_users, 512))
+                failed = failed or not line["north_star_shape"]["parity"]["ok"]
             del p2
         except Exception as e:      # noqa: BLE001
             line["north_star_shape"] = {"error": repr(e)}

@@ -15,8 +15,13 @@
  * pre-allocated by the binding ([m] or row-major [m x k_metrics] when `cumulative`); a NULL output pointer means
  * "metric not requested"; inputs are never modified; users that cannot be evaluated get NaN in every requested
  * output, so outputs need no initialisation.  CSR is 0-based int32 with sorted, unique indices inside a row.
- * `nthreads` and `seed` are accepted for signature compatibility: the device path has no host thread pool, and
- * the tie-breaking noise stream (reference :531-534) is not emulated ("tie noise").
+ * `nthreads` is accepted for signature compatibility (the device path has no host thread pool).  `seed` is USED:
+ * with `break_ties_with_noise` the reference's tie-breaking noise -- std::mt19937(seed + user) through libstdc++'s
+ * uniform_real_distribution, reference :528-534 -- is reproduced bit for bit (rm_noise.hpp; DESIGN.md, "tie noise"),
+ * so pass the same seed the reference would get.
+ * m == 0 returns RM_OK and writes nothing (the reference's loop over users does not run).  Xtest_csr_i may be NULL
+ * when Xtest_csr_p[m] == 0.  Deviation: NDCG requested with Xtest_csr == NULL is RM_ERR_INVALID (the reference
+ * dereferences the null pointer in its normalisation, :870-874).
  *
  * No torch / HIP types appear in any signature: pointers, sizes and scalars only.
  */
@@ -32,7 +37,7 @@ extern "C" {
 
 /* status codes */
 #define RM_OK 0
-#define RM_ERR_INVALID 1     /* bad argument (null pointer, non-positive size, k_metrics > n ...) */
+#define RM_ERR_INVALID 1     /* bad argument (null pointer, negative size, n or k == 0, k_metrics > n ...) */
 #define RM_ERR_HIP 2         /* HIP runtime failure (message has the hipError string) */
 #define RM_ERR_NOMEM 3       /* device or host allocation failed (the reference throws std::bad_alloc) */
 #define RM_ERR_UNSUPPORTED 4 /* shape outside what the kernels are built for (message says which) */

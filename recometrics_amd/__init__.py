@@ -141,9 +141,10 @@ def calc_reco_metrics(
     entry ``"K"``.  Users that cannot be evaluated get NaN.
 
     Differences from the CPU reference, all documented in DESIGN.md: ``nthreads`` is accepted and ignored;
-    ``break_ties_with_noise`` keeps its effect on the validity checks but exact score ties are broken by item id
-    instead of by the reference's mt19937 noise stream; ``hit`` / ``rr`` requested alone are computed (the reference
-    leaves them uninitialised) and ``pr_auc`` without ``roc_auc`` is computed from the full ranking.
+    ``break_ties_with_noise`` adds the reference's own noise (``std::mt19937(seed + user)``, reproduced bit for bit on
+    the device), scores that are still exactly equal afterwards are ordered by item id; ``hit`` / ``rr`` requested
+    alone are computed (the reference leaves them uninitialised) and ``pr_auc`` without ``roc_auc`` is computed from
+    the full ranking.
     """
     from scipy.sparse import csr_array, issparse
 

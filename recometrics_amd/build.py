@@ -80,7 +80,9 @@ def build_cython(force=False):
     if not force and os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(CY_SRC), os.path.getmtime(os.path.join(root, "include", "recometrics_hip.h"))):
         return out
     csrc = os.path.join(os.path.dirname(CY_SRC), "_cy.c")
-    res = subprocess.run([shutil.which("cython") or "cython", "-3", CY_SRC, "-o", csrc], capture_output=True, text=True)
+    if not shutil.which("cython"):
+        raise RuntimeError("cython executable not found")
+    res = subprocess.run([shutil.which("cython"), "-3", CY_SRC, "-o", csrc], capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("cython failed:\n" + res.stdout + res.stderr)
     cmd = [shutil.which("gcc") or "gcc", "-O2", "-fPIC", "-shared", "-w", csrc, "-o", out,
@@ -93,7 +95,28 @@ def build_cython(force=False):
     return out
 
 
+R_SHIM_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "r", "src")
+
+
+def build_r_shim(force=False):
+    """Compiles r/src/rm_r_shim.c (the R-independent half of the Rcpp glue, r/src/Rwrapper_hip.cpp) into r/src/librm_r_shim.so,
+    linked against csrc/librecometrics_hip.so -- the object an R package would link, minus Rcpp.  Plain gcc, no R needed."""
+    build()
+    src, out = os.path.join(R_SHIM_DIR, "rm_r_shim.c"), os.path.join(R_SHIM_DIR, "librm_r_shim.so")
+    root = os.path.dirname(os.path.dirname(CSRC))
+    deps = [src, os.path.join(R_SHIM_DIR, "rm_r_shim.h"), os.path.join(root, "include", "recometrics_hip.h")]
+    if not force and os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(d) for d in deps):
+        return out
+    cmd = [shutil.which("gcc") or "gcc", "-O2", "-std=c11", "-Wall", "-Wextra", "-Werror", "-fPIC", "-shared", src, "-o", out,
+           "-I" + os.path.join(root, "include"), "-L" + CSRC, "-lrecometrics_hip", "-Wl,-rpath," + CSRC]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("compiling the R shim failed:\n" + res.stdout + res.stderr)
+    return out
+
+
 if __name__ == "__main__":
     import sys
     print(build(force=True, verbose="-v" in sys.argv))
     print(build_cython(force=True))
+    print(build_r_shim(force=True))

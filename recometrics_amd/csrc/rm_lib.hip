@@ -81,6 +81,8 @@ struct Ctx {
     hipEvent_t side_ev[2] = {nullptr, nullptr};
     hipEvent_t done = nullptr;               // end of the device work of the most recent call on this context
     hipStream_t own_stream = nullptr;        // stream of a shard worker (multi-device calls)
+    hipStream_t up_stream = nullptr;         // host-pointer calls: uploads of the NEXT user batch run beside the current batch's kernels
+    hipEvent_t up_ev[2] = {nullptr, nullptr};
     double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int timed_slots = 0, total_slots = 0;     // slots (user lanes) of the sweep launch the "sweep" timing brackets / of the call
     double acc[4] = {0, 0, 0, 0};            // prep / sweep / finalize / total ms of the batches already read back (host entry)
@@ -123,6 +125,7 @@ template <class T> struct Call {          // one calc_metrics call; every pointe
     const T *noise_E; long long noise_ld;          // per-item noise rows; null = scores as they are
     int *noise_flag;                               // optional [m] out (fp32 first pass): users the noise can change
     bool same_train_rows = false;                  // a later pass of the same call over the same users' rows: dense train rows may be reused
+    long long eval_users = -1;                     // users this pass evaluates when fewer than m (only_users given); -1 = all m
 };
 
 inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
@@ -226,12 +229,20 @@ constexpr size_t SYNC_BYTES = 32;          // end of the sweep's LDS: arrival co
 
 // HBM the score rows of streamed users (and of every user when k_metrics > 256) may take: a third of what is free now, or
 // RM_STREAM_BUDGET_MB (tests)
-inline long long stream_budget_bytes()
+// (what the workspace already holds of exactly these buffers counts as free: a later batch of the same size must get the
+// same answer as the first one, whose rows are still cached -- otherwise its budget shrinks and an equal-sized batch fails)
+inline long long free_plus_owned(const Workspace &ws, std::initializer_list<const char *> names)
 {
-    if (const char *e = getenv("RM_STREAM_BUDGET_MB")) return atoll(e) << 20;
     size_t fr = 0, tot = 0;
     HIP_CHECK(hipMemGetInfo(&fr, &tot));
-    return (long long)(fr / 3);
+    long long owned = 0;
+    for (const char *nm : names) { auto it = ws.bufs.find(nm); if (it != ws.bufs.end()) owned += (long long)it->second.second; }
+    return (long long)fr + owned;
+}
+inline long long stream_budget_bytes(const Workspace &ws)
+{
+    if (const char *e = getenv("RM_STREAM_BUDGET_MB")) return atoll(e) << 20;
+    return free_plus_owned(ws, {"stream_scores", "sel_hi", "sel_lo"}) / 3;
 }
 
 // Dense train rows for the fp32 sweep when they are small (m * n / 8 bytes <= 1 GiB, e.g. 463 MB at BASELINE C2): with ~100
@@ -307,10 +318,12 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     // k_select_topk picks its top-K from the stored row -- any k_metrics <= n, at one score row of HBM per user
     const bool ext_topk = K > 256 || getenv("RM_DEBUG_EXT_TOPK") != nullptr;
     if (want_auc || ext_topk) {
-        const long long cap = stream_budget_bytes() / (stream_ld_max * (long long)sizeof(T));
+        const long long cap = stream_budget_bytes(ws) / (stream_ld_max * (long long)sizeof(T));
+        // (a pass over a subset of the users -- the exact second pass of the fp32 tie noise -- stores rows for that subset only)
+        const long long m_rows = c.eval_users >= 0 ? std::min<long long>(c.eval_users, m) : m;
         if (ext_topk) {
-            if (m > cap) throw RmError{RM_ERR_NOMEM, "k_metrics > 256 keeps one score row (" + std::to_string(stream_ld_max * (long long)sizeof(T)) +
-                                       " B) per user in device memory: " + std::to_string(m) + " users do not fit, at most " + std::to_string(cap) + " per call"};
+            if (m_rows > cap) throw RmError{RM_ERR_NOMEM, "k_metrics > 256 keeps one score row (" + std::to_string(stream_ld_max * (long long)sizeof(T)) +
+                                       " B) per user in device memory: " + std::to_string(m_rows) + " users do not fit, at most " + std::to_string(cap) + " per call"};
             ca.force_stream = 1;
         } else if (cap > 0) {
             hipLaunchKernelGGL(k_count_long, dim3(cdiv(m, 1024)), dim3(1024), 0, stream, m, c.test_p, plan, c.only_users);
@@ -667,7 +680,7 @@ void run_call(const Call<T> &c_in, hipStream_t stream, Ctx &cx)
     const long long row_bytes = e_ld * (long long)sizeof(T) + d_ld * 4;
     long long budget;
     if (const char *e = getenv("RM_NOISE_BUDGET_MB")) budget = atoll(e) << 20;
-    else { size_t fr = 0, tot = 0; HIP_CHECK(hipMemGetInfo(&fr, &tot)); budget = (long long)(fr / 3); }
+    else budget = free_plus_owned(ws, {"noise_draws", "noise_rows"}) / 3;
     const long long cap = std::max<long long>(1, std::min<long long>(budget / row_bytes, 1 << 20));
     auto make_rows = [&](const int *row_user, int rows, const int *train_p, long long user0, unsigned *&D, T *&E) {
         D = (unsigned *)ws.get("noise_draws", sizeof(unsigned) * (size_t)rows * (size_t)d_ld);
@@ -718,6 +731,7 @@ void run_call(const Call<T> &c_in, hipStream_t stream, Ctx &cx)
         Call<T> c = c0;
         c.only_users = only; c.noise_row = noise_row; c.noise_row0 = (int)r0; c.noise_E = E; c.noise_ld = e_ld; c.noise_flag = nullptr;
         c.same_train_rows = true;
+        c.eval_users = rows;
         run<T>(c, stream, cx);
     }
 }
@@ -785,12 +799,38 @@ struct SharedItems {
     std::mutex mu; std::condition_variable cv;
     bool ready = false, failed = false;
     const void *src = nullptr; int src_device = 0;
+    // shards that have not finished (or given up on) their device-to-device copy of `src` yet: shard 0 keeps its context --
+    // and with it the buffer `src` points to -- locked until this is 0, so that no later call can overwrite or free the
+    // buffer under a slow shard
+    int copies_pending = 0;
+    void copy_done() { std::lock_guard<std::mutex> lk(mu); copies_pending--; cv.notify_all(); }
 };
 
+// direct device-to-device copies (xGMI on a multi-GPU node): enabled once per ordered pair, by the copying side
+inline void enable_peer_access(int dst_device, int src_device)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, bool> done;
+    if (dst_device == src_device) return;
+    std::lock_guard<std::mutex> lk(mu);
+    bool &d = done[std::make_pair(dst_device, src_device)];
+    if (d) return;
+    d = true;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, dst_device, src_device) == hipSuccess && can) {
+        const hipError_t e = hipDeviceEnablePeerAccess(src_device, 0);          // (the current device is dst_device)
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();   // not fatal: hipMemcpyPeer stages through the host
+        else (void)hipGetLastError();
+    }
+}
 
-// Users [u0, u1) of a host call on the current device: stage the inputs of the range into HBM, evaluate them in batches
-// small enough to look at the interrupt flag a few times per second, copy each batch's outputs straight into the caller's
-// arrays.  `shared` (sharded calls) says where the item factors come from.
+
+// Users [u0, u1) of a host call on the current device.  The inputs are staged into HBM batch by batch and the batches are
+// pipelined: while the kernels of batch i run on the call's stream, the rows of batch i + 1 (user factors, train / test CSR
+// rows) are uploaded on a second stream into their places in the range's device arrays -- a batch only ever reads its own
+// rows, so nothing is double-buffered.  The first batch is small (its upload is the only one nothing hides) and the batches
+// double in size from there; they are also what the interrupt flag is looked at between (reference :488-489).  Each batch's
+// outputs go straight into the caller's arrays.  `shared` (sharded calls) says where the item factors come from.
 template <class T>
 void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t stream, SharedItems *shared, int shard, unsigned long long tag)
 {
@@ -799,33 +839,62 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     const int m = u1 - u0, n = h.n, k = h.k, K = h.K;
     cx.acc[0] = cx.acc[1] = cx.acc[2] = cx.acc[3] = 0; cx.ev_recorded = false;
     g_last_ctx = &cx;
+    // whatever happens below, the other shards must neither wait for item factors that never come nor copy from a buffer
+    // that is being reused: shard 0 publishes (possibly a failure) and then waits for every copy; the others report theirs
+    struct SharedGuard {
+        SharedItems *sh; int shard; bool published = false, reported = false;
+        ~SharedGuard()
+        {
+            if (!sh) return;
+            if (shard == 0) {
+                std::unique_lock<std::mutex> sl(sh->mu);
+                if (!published) { sh->ready = true; sh->failed = true; sh->cv.notify_all(); }
+                sh->cv.wait(sl, [&] { return sh->copies_pending <= 0; });
+            } else if (!reported) sh->copy_done();
+        }
+    } guard{shared, shard};
+    if (!cx.up_stream) {
+        HIP_CHECK(hipStreamCreateWithFlags(&cx.up_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&cx.up_ev[i], hipEventDisableTiming));
+    }
+    hipStream_t up = cx.up_stream;
+    if (cx.ev_valid) HIP_CHECK(hipStreamWaitEvent(up, cx.done, 0));   // the previous call on this context may still read the buffers
     // item factors, dense rows of k
     T *dB = (T *)ws.get("in_B", sizeof(T) * (size_t)n * k);
-    if (!shared || shard == 0) {
-        hipError_t e = hipMemcpy2DAsync(dB, sizeof(T) * k, h.B, sizeof(T) * h.ldb, sizeof(T) * k, n, hipMemcpyHostToDevice, stream);
-        if (shared) {
-            if (e == hipSuccess) e = hipStreamSynchronize(stream);
-            std::lock_guard<std::mutex> sl(shared->mu);
-            shared->ready = true; shared->failed = e != hipSuccess; shared->src = dB; shared->src_device = cx.device;
-            shared->cv.notify_all();
+    auto upload_items = [&]() {
+        if (!shared || shard == 0) {
+            hipError_t e = hipMemcpy2DAsync(dB, sizeof(T) * k, h.B, sizeof(T) * h.ldb, sizeof(T) * k, n, hipMemcpyHostToDevice, up);
+            if (shared) {
+                if (e == hipSuccess) e = hipStreamSynchronize(up);
+                std::lock_guard<std::mutex> sl(shared->mu);
+                shared->ready = true; shared->failed = e != hipSuccess; shared->src = dB; shared->src_device = cx.device;
+                guard.published = true;
+                shared->cv.notify_all();
+            }
+            HIP_CHECK(e);
+        } else {
+            {
+                std::unique_lock<std::mutex> sl(shared->mu);
+                shared->cv.wait(sl, [&] { return shared->ready; });
+                if (shared->failed) throw RmError{RM_ERR_HIP, "upload of the item factors failed on the first device"};
+            }
+            enable_peer_access(cx.device, shared->src_device);
+            HIP_CHECK(hipMemcpyPeerAsync(dB, cx.device, shared->src, shared->src_device, sizeof(T) * (size_t)n * k, up));
+            HIP_CHECK(hipStreamSynchronize(up));                      // the source buffer is shard 0's: tell it when we are done with it
+            guard.reported = true;
+            shared->copy_done();
         }
-        HIP_CHECK(e);
-    } else {
-        std::unique_lock<std::mutex> sl(shared->mu);
-        shared->cv.wait(sl, [&] { return shared->ready; });
-        if (shared->failed) throw RmError{RM_ERR_HIP, "upload of the item factors failed on the first device"};
-        HIP_CHECK(hipMemcpyPeerAsync(dB, cx.device, shared->src, shared->src_device, sizeof(T) * (size_t)n * k, stream));
-    }
-    if (m <= 0) { HIP_CHECK(hipStreamSynchronize(stream)); return; }
+    };
+    if (m <= 0) { upload_items(); HIP_CHECK(hipStreamSynchronize(up)); return; }
     // this range's users: factors, CSR rows with the index pointers rebased to the range
     const long long tr0 = h.trp[u0], te0 = h.tep[u0];
     const long long nnz_tr = (long long)h.trp[u1] - tr0, nnz_te = (long long)h.tep[u1] - te0;
     T *dA = (T *)ws.get("in_A", sizeof(T) * (size_t)m * k);
-    HIP_CHECK(hipMemcpy2DAsync(dA, sizeof(T) * k, h.A + (size_t)u0 * h.lda, sizeof(T) * h.lda, sizeof(T) * k, m, hipMemcpyHostToDevice, stream));
     int *dtrp = (int *)ws.get("in_trp", sizeof(int) * (size_t)(m + 1));
     int *dtep = (int *)ws.get("in_tep", sizeof(int) * (size_t)(m + 1));
     int *dtri = (int *)ws.get("in_tri", sizeof(int) * (size_t)std::max<long long>(nnz_tr, 1));
     int *dtei = (int *)ws.get("in_tei", sizeof(int) * (size_t)std::max<long long>(nnz_te, 1));
+    T *dtev = h.tev ? (T *)ws.get("in_tev", sizeof(T) * (size_t)std::max<long long>(nnz_te, 1)) : nullptr;
     std::vector<int> rb;                                              // rebased index pointers (only when the range does not start at 0)
     const int *trp = h.trp + u0, *tep = h.tep + u0;
     if (tr0 || te0) {
@@ -833,16 +902,8 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
         for (int i = 0; i <= m; i++) { rb[i] = h.trp[u0 + i] - (int)tr0; rb[m + 1 + i] = h.tep[u0 + i] - (int)te0; }
         trp = rb.data(); tep = rb.data() + m + 1;
     }
-    HIP_CHECK(hipMemcpyAsync(dtrp, trp, sizeof(int) * (size_t)(m + 1), hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipMemcpyAsync(dtep, tep, sizeof(int) * (size_t)(m + 1), hipMemcpyHostToDevice, stream));
-    if (nnz_tr > 0) HIP_CHECK(hipMemcpyAsync(dtri, h.tri + tr0, sizeof(int) * (size_t)nnz_tr, hipMemcpyHostToDevice, stream));
-    if (nnz_te > 0) HIP_CHECK(hipMemcpyAsync(dtei, h.tei + te0, sizeof(int) * (size_t)nnz_te, hipMemcpyHostToDevice, stream));
-    T *dtev = nullptr;
-    if (h.tev) {
-        dtev = (T *)ws.get("in_tev", sizeof(T) * (size_t)std::max<long long>(nnz_te, 1));
-        if (nnz_te > 0) HIP_CHECK(hipMemcpyAsync(dtev, h.tev + te0, sizeof(T) * (size_t)nnz_te, hipMemcpyHostToDevice, stream));
-    }
-    HIP_CHECK(hipStreamSynchronize(stream));                         // `rb` goes out of use; uploads are complete
+    HIP_CHECK(hipMemcpyAsync(dtrp, trp, sizeof(int) * (size_t)(m + 1), hipMemcpyHostToDevice, up));
+    HIP_CHECK(hipMemcpyAsync(dtep, tep, sizeof(int) * (size_t)(m + 1), hipMemcpyHostToDevice, up));
     const size_t per = h.cumulative ? (size_t)K : 1;                 // values per user of the eight top-K metrics
     static const char *onames[10] = {"o_p", "o_tp", "o_r", "o_ap", "o_tap", "o_ndcg", "o_hit", "o_rr", "o_roc", "o_pr"};
     T *dout[10];
@@ -854,21 +915,48 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
         d_pos_rank = (long long *)ws.get("o_pos_rank", sizeof(long long) * (size_t)std::max<long long>(nnz_te, 1));
         d_status = (int *)ws.get("o_status", sizeof(int) * (size_t)m);
     }
-    // batch size: ~0.4 s of device work at the rate the sweep sustains (2 n k flop per user), whole user blocks
+    // largest batch: ~0.4 s of device work at the rate the sweep sustains (2 n k flop per user), whole user blocks
     const double rate = std::is_same<T, float>::value ? 6.0e13 : 2.5e13;
     double bu = 0.4 * rate / (2.0 * (double)n * (double)k);
-    if (const char *e = getenv("RM_BATCH_USERS")) bu = atof(e);      // tests
+    const char *forced = getenv("RM_BATCH_USERS");                   // tests: equal batches of this size
+    if (forced) bu = atof(forced);
     long long batch = (long long)std::min<double>(std::max(bu, 1024.0), 2.0e9);
     batch = (batch + 1023) / 1024 * 1024;
     if (K > 256) {                                                   // one score row per user of the batch (run(): ext_topk),
         const long long row = (((long long)n + 191) / 192 * 192) * (long long)sizeof(T);    // with a margin for what run() allocates first
-        batch = std::max<long long>(1, std::min<long long>(batch, stream_budget_bytes() * 3 / 4 / row));
+        batch = std::max<long long>(1, std::min<long long>(batch, stream_budget_bytes(ws) * 3 / 4 / row));
     }
-    SignalGuard *sg = nullptr;                                       // the caller's guard polls; here only the flag is read
-    (void)sg;
-    for (long long b0 = 0; b0 < m; b0 += batch) {
-        const int b1 = (int)std::min<long long>(m, b0 + batch), mb = b1 - (int)b0;
+    // batch boundaries: a ramp m/16, m/8, m/4, ... (whole kilo-users, capped by `batch`) when the range is large enough for the
+    // pipeline to matter; the compute of a batch takes longer than the upload of the next one twice its size
+    std::vector<long long> cuts{0};
+    {
+        long long next = (forced || m <= 16384) ? batch : std::min<long long>(batch, std::max<long long>(8192, ((long long)m / 16 + 1023) / 1024 * 1024));
+        while (cuts.back() < m) {
+            long long b1 = std::min<long long>(m, cuts.back() + next);
+            if (m - b1 < next / 4 && m - cuts.back() <= batch) b1 = m;             // no crumb at the end
+            cuts.push_back(b1);
+            if (!forced) next = std::min<long long>(batch, next * 2);
+        }
+    }
+    const int n_batches = (int)cuts.size() - 1;
+    auto upload_users = [&](int bi) {                                 // rows [cuts[bi], cuts[bi + 1]) into their places, on `up`
+        const long long b0 = cuts[bi], b1 = cuts[bi + 1];
+        HIP_CHECK(hipMemcpy2DAsync(dA + (size_t)b0 * k, sizeof(T) * k, h.A + ((size_t)u0 + b0) * h.lda, sizeof(T) * h.lda, sizeof(T) * k, (size_t)(b1 - b0),
+                                   hipMemcpyHostToDevice, up));
+        const long long r0 = trp[b0], r1 = trp[b1], e0 = tep[b0], e1 = tep[b1];      // range-relative entries of the batch
+        if (r1 > r0) HIP_CHECK(hipMemcpyAsync(dtri + r0, h.tri + tr0 + r0, sizeof(int) * (size_t)(r1 - r0), hipMemcpyHostToDevice, up));
+        if (e1 > e0) HIP_CHECK(hipMemcpyAsync(dtei + e0, h.tei + te0 + e0, sizeof(int) * (size_t)(e1 - e0), hipMemcpyHostToDevice, up));
+        if (dtev && e1 > e0) HIP_CHECK(hipMemcpyAsync(dtev + e0, h.tev + te0 + e0, sizeof(T) * (size_t)(e1 - e0), hipMemcpyHostToDevice, up));
+        HIP_CHECK(hipEventRecord(cx.up_ev[bi & 1], up));
+    };
+    // shard 0 sends the item factors first (the other shards are waiting for them); the others send their own rows first
+    if (!shared || shard == 0) { upload_items(); upload_users(0); }
+    else { upload_users(0); upload_items(); HIP_CHECK(hipEventRecord(cx.up_ev[0], up)); }
+    for (int bi = 0; bi < n_batches; bi++) {
+        const long long b0 = cuts[bi];
+        const int b1 = (int)cuts[bi + 1], mb = b1 - (int)b0;
         if (g_interrupt) break;                                      // reference :488-489: the remaining users are skipped
+        HIP_CHECK(hipStreamWaitEvent(stream, cx.up_ev[bi & 1], 0));
         Call<T> c{};
         c.A = dA + (size_t)b0 * k; c.lda = k; c.B = dB; c.ldb = k; c.m = mb; c.n = n; c.k = k;
         c.train_p = dtrp + b0; c.train_i = dtri; c.nnz_train = nnz_tr;
@@ -881,7 +969,9 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
         }
         c.items_tag = tag;
         c.seed = h.seed; c.user0 = (long long)u0 + b0;
-        run_call<T>(c, stream, cx);
+        run_call<T>(c, stream, cx);                                  // enqueued (one short plan read-back inside)
+        // the next batch's rows travel while this batch's sweep runs (the copies below block the host, not the device)
+        if (bi + 1 < n_batches && !g_interrupt) upload_users(bi + 1);
         for (int i = 0; i < 10; i++) {
             const size_t w = i >= 8 ? 1 : per;
             if (h.outs[i]) HIP_CHECK(hipMemcpyAsync(h.outs[i] + ((size_t)u0 + b0) * w, c.out[i], sizeof(T) * (size_t)mb * w, hipMemcpyDeviceToHost, stream));
@@ -894,7 +984,7 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
             if (e1 > e0) HIP_CHECK(hipMemcpyAsync(h.pos_rank + te0 + e0, c.pos_rank + e0, sizeof(long long) * (size_t)(e1 - e0), hipMemcpyDeviceToHost, stream));
         }
         HIP_CHECK(hipStreamSynchronize(stream));
-        if (b1 < m || b0 > 0) {                                       // more than one batch: add up the stage timings
+        if (n_batches > 1) {                                          // more than one batch: add up the stage timings
             float ta = 0, tb = 0, tc = 0, td = 0;
             (void)hipEventElapsedTime(&ta, cx.ev[0], cx.ev[1]); (void)hipEventElapsedTime(&tb, cx.ev[1], cx.ev[2]);
             (void)hipEventElapsedTime(&tc, cx.ev[2], cx.ev[3]); (void)hipEventElapsedTime(&td, cx.ev[0], cx.ev[3]);
@@ -902,12 +992,16 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
             cx.ev_recorded = false;
         }
     }
+    HIP_CHECK(hipStreamSynchronize(up));                              // `rb` and the caller's arrays go out of use (also after an interrupt)
 }
 
+// (m == 0 is not an error: the reference's loop over users, src/recometrics.hpp:428-437, simply does not run; the entry
+// points return RM_OK before they get here.  `tei` may be null when there is no test entry at all -- every user is then NaN,
+// as in the reference -- which is what a binding hands over for an empty index array.)
 template <class T>
-void validate(const T *A, const T *B, int m, int n, int k, const int *trp, const int *tep, const int *tei, int K, size_t lda, size_t ldb)
+void validate(const T *A, const T *B, int m, int n, int k, const int *trp, const int *tep, const int *tei, long long nnz_test, int K, size_t lda, size_t ldb)
 {
-    if (!A || !B || !trp || !tep || !tei) throw RmError{RM_ERR_INVALID, "null input pointer"};
+    if (!A || !B || !trp || !tep || (!tei && nnz_test > 0)) throw RmError{RM_ERR_INVALID, "null input pointer"};
     if (m <= 0 || n <= 0 || k <= 0) throw RmError{RM_ERR_INVALID, "m, n, k must be positive"};
     if (K <= 0) throw RmError{RM_ERR_INVALID, "k_metrics must be positive"};
     if (lda < (size_t)k || ldb < (size_t)k) throw RmError{RM_ERR_INVALID, "leading dimension smaller than k"};
@@ -918,8 +1012,12 @@ void validate(const T *A, const T *B, int m, int n, int k, const int *trp, const
 template <class T>
 void run_host(const HostCall<T> &h)
 {
-    validate(h.A, h.B, h.m, h.n, h.k, h.trp, h.tep, h.tei, h.K, h.lda, h.ldb);
+    if (h.m == 0) return;                                            // reference :428-437: no user, nothing written
+    if (h.m < 0 || !h.tep) throw RmError{RM_ERR_INVALID, h.m < 0 ? "m, n, k must be positive" : "null input pointer"};
+    validate(h.A, h.B, h.m, h.n, h.k, h.trp, h.tep, h.tei, (long long)h.tep[h.m], h.K, h.lda, h.ldb);
     if (h.trp[h.m] > 0 && !h.tri) throw RmError{RM_ERR_INVALID, "null train indices"};
+    // (deviation D8: the reference's walk would use gain 0 for a null Xtest_csr, :620, but its normalisation dereferences
+    // the pointer, :870-874 -- a crash there, an error here)
     if (h.outs[5] && !h.tev) throw RmError{RM_ERR_INVALID, "NDCG requested without test values"};
     std::vector<int> devs;
     { std::lock_guard<std::mutex> lk(g_dev_mu); devs = g_devices; }
@@ -936,8 +1034,10 @@ void run_host(const HostCall<T> &h)
     }
     const int G = (int)devs.size();
     SharedItems shared;
+    shared.copies_pending = G - 1;
     std::vector<RmError> errs((size_t)G, RmError{RM_OK, ""});
     std::vector<std::thread> workers;
+    std::vector<char> reached((size_t)G, 0);                          // shard g got as far as run_host_range (whose guard then owns the hand-shake)
     Ctx *first = nullptr;
     std::mutex first_mu;
     for (int g = 0; g < G; g++) {
@@ -948,13 +1048,18 @@ void run_host(const HostCall<T> &h)
                 if (g == 0) { std::lock_guard<std::mutex> lk(first_mu); first = &cx; }
                 if (!cx.own_stream) HIP_CHECK(hipStreamCreateWithFlags(&cx.own_stream, hipStreamNonBlocking));
                 const int u0 = (int)((long long)h.m * g / G), u1 = (int)((long long)h.m * (g + 1) / G);
+                reached[g] = 1;
                 run_host_range<T>(h, u0, u1, cx, cx.own_stream, &shared, g, tag);
             } catch (const RmError &e) { errs[g] = e; }
             catch (const std::bad_alloc &) { errs[g] = RmError{RM_ERR_NOMEM, "host allocation failed"}; }
             catch (const std::exception &e) { errs[g] = RmError{RM_ERR_HIP, e.what()}; }
-            if (g == 0 && errs[g].code != RM_OK) {                    // never leave the other shards waiting for the item factors
+            // (a shard that failed before it reached run_host_range's guard -- hipSetDevice, stream creation -- has to do the
+            // guard's job here: shard 0 publishes the failure, the others give up their copy)
+            if (errs[g].code != RM_OK) {
                 std::lock_guard<std::mutex> sl(shared.mu);
-                if (!shared.ready) { shared.ready = true; shared.failed = true; shared.cv.notify_all(); }
+                if (g == 0) { if (!shared.ready) { shared.ready = true; shared.failed = true; } }
+                else if (!reached[g]) shared.copies_pending--;
+                shared.cv.notify_all();
             }
         });
     }
@@ -1041,7 +1146,8 @@ extern "C" int rm_calc_metrics_dev_##SUFFIX(                                    
     uint64_t seed, void *stream)                                                                                        \
 {                                                                                                                       \
     return guarded([&] {                                                                                                \
-        validate(A, B, m, n, k, Xtrain_csr_p, Xtest_csr_p, Xtest_csr_i, k_metrics, lda, ldb);                           \
+        if (m == 0) return;                                                                                             \
+        validate(A, B, m, n, k, Xtrain_csr_p, Xtest_csr_p, Xtest_csr_i, (long long)nnz_test, k_metrics, lda, ldb);      \
         if (ndcg_at_k && !Xtest_csr) throw RmError{RM_ERR_INVALID, "NDCG requested without test values"};               \
         Call<T> c{};                                                                                                    \
         c.A = A; c.lda = lda; c.B = B; c.ldb = ldb; c.m = m; c.n = n; c.k = k;                                          \

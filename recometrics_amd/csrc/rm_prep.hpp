@@ -312,7 +312,13 @@ __global__ void k_seed_thresholds(int n_slots, int stream_slot0, int K, int gu, 
     int nvalid = P;                                               // positives masked by the train row sort to the top as +inf
     while (nvalid > 0) { const T x = tab[(long long)(nvalid - 1) * stride]; if (isinf(x) && x > 0) nvalid--; else break; }
     if (nvalid < K) return;
-    const T kth = tab[(long long)(nvalid - K) * stride];
+    // the K-th best DISTINCT score of the test row: a non-canonical CSR row may list an item twice (the reference only sorts
+    // the rows, recometrics/__init__.py:478-486), and K entries are then fewer than K candidates -- entries with equal scores
+    // count once, which can only lower the bound
+    int i = nvalid - 1, distinct = 1;
+    T kth = tab[(long long)i * stride];
+    while (distinct < K && i > 0) { const T x = tab[(long long)(--i) * stride]; if (x != kth) { kth = x; distinct++; } }
+    if (distinct < K) return;
     if (kth == kth) thr_shared[slot] = ord_key(kth);
 }
 

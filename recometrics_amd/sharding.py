@@ -21,15 +21,16 @@ def slice_csr(indptr, indices, data, lo, hi):
     return p, np.ascontiguousarray(indices[a:b]), (None if data is None else np.ascontiguousarray(data[a:b]))
 
 
-def all_gather_rows(local, m, world, dist=None, group=None):
+def all_gather_rows(local, m, world, dist=None, group=None, always=False):
     """`local`: torch tensor [m_local, ...] holding this rank's user rows -> tensor [m, ...] on every rank.
 
     Shards are padded to ceil(m / world) rows so that a single all_gather_into_tensor (one RCCL ring over xGMI) moves
-    everything; the padding is dropped when the ranges are re-assembled."""
+    everything; the padding is dropped when the ranges are re-assembled.  With one rank there is nothing to exchange and
+    the collective is skipped unless `always` (the one-GPU test of the RCCL path)."""
     import torch
     if dist is None:
         import torch.distributed as dist  # noqa: PLC0415
-    if world == 1:
+    if world == 1 and not always:
         return local
     cap = -(-m // world)
     rank = dist.get_rank(group)

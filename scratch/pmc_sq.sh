@@ -7,7 +7,8 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
-           "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_BRANCH SQ_ACTIVE_INST_FLAT"; do
+           "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_BRANCH SQ_ACTIVE_INST_FLAT" \
+           "SQ_VALU_MFMA_COEXEC_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU"; do
   i=$((i+1))
   rocprofv3 --pmc $grp --output-format csv -d $R/$OUT/p$i -- python3 $R/scratch/ns.py $WL $USERS 1 > $R/$OUT.p$i.log 2>&1 || echo "pass $i failed"
 done
@@ -22,7 +23,7 @@ for f in glob.glob("%s/p*/*/*counter_collection.csv" % out):
             agg[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
     if agg:
         last = sorted(agg, key=int)[-1]
-        res.update(agg[last])
+        for k_, v_ in agg[last].items(): res.setdefault(k_, v_)      # (the first pass that has a counter names it)
 json.dump(res, open("%s/sq.json" % out, "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY

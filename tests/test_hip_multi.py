@@ -242,3 +242,77 @@ def test_cython_binding_equals_the_ctypes_binding(hip, oracle=None):
                 assert_same_bits(g, w, "cython vs ctypes: %s" % name)
     with pytest.raises(ValueError, match="k_metrics"):
         _cy.calc_metrics(pr["A"], 24, pr["B"], 24, trp, tri, tep, tei, tev, 0, ALL, False, False, True, 2, 1, 1, 1)
+
+
+def test_rccl_all_gather_of_the_metric_block_with_one_rank():
+    """backend "nccl" IS RCCL on ROCm: with the one GPU of the test box, build a world of one rank, evaluate a shard with the
+    HIP binding and push its metric block through sharding.all_gather_rows on the DEVICE -- the library loads, the
+    communicator is built and the collective runs, which is everything a multi-GPU run adds to the tested path except
+    the second device."""
+    code = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from recometrics_amd import _binding, sharding
+from recometrics_amd.synth import make_problem
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%%d" %% int(os.environ["PORT"]), world_size=1, rank=0, device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+_binding.load(); _binding.set_device(0)
+pr = make_problem(300, 2000, 32, np.float32, mean_c=40, seed=3)
+trp, tri = pr["train"]; tep, tei, tev = pr["test"]
+want = {name: True for name in _binding.METRIC_ORDER}
+outs = _binding.calc_metrics(pr["A"], 32, pr["B"], 32, trp, tri, tep, tei, tev, 10, want, False, False, True, 2, 1, 1, 1)
+block = torch.from_numpy(np.stack(outs, axis=1)).to("cuda:0")
+full = sharding.all_gather_rows(block, 300, 1, dist=dist, always=True)
+torch.cuda.synchronize()
+assert full.is_cuda and full.shape == block.shape
+a, b = full.cpu().numpy(), block.cpu().numpy()
+assert ((a == b) | (np.isnan(a) & np.isnan(b))).all()
+t = torch.ones(4, device="cuda:0"); dist.all_reduce(t); torch.cuda.synchronize(); assert float(t.sum()) == 4.0
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_OK", torch.cuda.nccl.version())
+""" % ROOT
+    env = dict(os.environ, PORT=str(29500 + os.getpid() % 2000), HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0 and "RCCL_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+
+
+@pytest.mark.parametrize("noise", [False, True])
+def test_k_metrics_beyond_the_lists_in_user_batches(hip, monkeypatch, noise):
+    """k_metrics > 256 keeps one score row per user of a batch in HBM: several batches of one host call (and, with the tie
+    noise, the exact second pass over the flagged users) must all fit the budget that sized the first one -- the rows of an
+    earlier batch are still cached in the workspace and count as available.  No RM_STREAM_BUDGET_MB: the real budget."""
+    from recometrics_amd.synth import make_problem
+    pr = make_problem(3000, 2500, 24, np.float32, mean_c=50, seed=14)
+    pr["B"] = pr["B"].copy()
+    pr["B"][np.random.default_rng(2).random(2500) < 0.1] = 0              # zero scores: users the noise can reorder
+    trp, tri = pr["train"]; tep, tei, tev = pr["test"]
+
+    def call():
+        return hip.calc_metrics(pr["A"], 24, pr["B"], 24, trp, tri, tep, tei, tev, 300, ALL, True, noise, True, 2, 1, 1, 5)
+    want = call()
+    monkeypatch.setenv("RM_BATCH_USERS", "1024")
+    got = call()
+    for name, g, w in zip(hip.METRIC_ORDER, got, want):
+        assert_same_bits(g, w, name + " (K = 300, three batches, noise=%s)" % noise)
+
+
+def test_pipelined_uploads_equal_one_batch(hip, monkeypatch):
+    """large user ranges are uploaded and evaluated as a ramp of batches (m/16, m/8, ...: the rows of batch i + 1 travel while
+    batch i computes); every output equals the single-batch call bit for bit, also with the API-default tie noise and through
+    rm_rank_*"""
+    from recometrics_amd.synth import make_problem
+    pr = make_problem(40000, 1200, 16, np.float32, mean_c=30, seed=15)     # > 16,384 users: ramp 8192, 16384, 15424
+    trp, tri = pr["train"]; tep, tei, tev = pr["test"]
+    for noise in (False, True):
+        got = hip.calc_metrics(pr["A"], 16, pr["B"], 16, trp, tri, tep, tei, tev, 5, ALL, False, noise, True, 2, 1, 1, 3)
+        monkeypatch.setenv("RM_BATCH_USERS", "65536")                      # one batch
+        want = hip.calc_metrics(pr["A"], 16, pr["B"], 16, trp, tri, tep, tei, tev, 5, ALL, False, noise, True, 2, 1, 1, 3)
+        monkeypatch.delenv("RM_BATCH_USERS")
+        for name, g, w in zip(hip.METRIC_ORDER, got, want):
+            assert_same_bits(g, w, name + " (ramp of batches, noise=%s)" % noise)
+    rk = hip.rank(pr["A"], pr["B"], trp, tri, tep, tei, 5)
+    monkeypatch.setenv("RM_BATCH_USERS", "65536")
+    rk1 = hip.rank(pr["A"], pr["B"], trp, tri, tep, tei, 5)
+    for key in rk:
+        assert (rk[key] == rk1[key]).all() or key == "topk_score", key

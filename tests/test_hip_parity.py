@@ -102,6 +102,23 @@ def test_golden_fixtures(hip, case):
                 assert_same_bits(g, w, "%s v%d %s %s (bitwise, noise on)" % (case, vi, kw, name))
 
 
+_REF = []
+
+
+def _reference():
+    """the real reference as a second checker, when its compiled library is present (it is on the GPU box: oracle/_ref travels)"""
+    if not _REF:
+        from oracle.oracle import Reference, reference_available
+        _REF.append(Reference() if reference_available() else None)
+    return _REF[0]
+
+
+def test_the_compiled_reference_is_the_second_checker():
+    """oracle/_ref/librecometrics_ref.so is built in the build container and travels with the snapshot; without it the
+    tests below would silently fall back to the restatement alone"""
+    assert _reference() is not None, "oracle/_ref/librecometrics_ref.so is missing on this box"
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def _check_against_oracle(hip, oracle, pr, k, dtype=np.float32, **kw):
     want_rank = oracle.rank(pr["A"], pr["B"], pr["train"], pr["test"], k, dtype=dtype, nthreads=NT)
@@ -112,9 +129,19 @@ def _check_against_oracle(hip, oracle, pr, k, dtype=np.float32, **kw):
     assert (got_rank["topk_idx"] == want_rank["topk_idx"]).all(), "top-K index lists differ"
     assert_same_bits(got_rank["topk_score"], want_rank["topk_score"], "top-K scores")
     assert (got_rank["pos_rank"] == want_rank["pos_rank"]).all(), "positive ranks differ"
+    ref = _reference()
     for cumulative in (False, True):
         want = oracle.calc(pr["A"], pr["B"], pr["train"], pr["test"], k, cumulative=cumulative, dtype=dtype, nthreads=NT, **kw)
         got = hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], k, cumulative=cumulative, dtype=dtype, **kw)
+        if ref is not None:
+            # not only the restatement: the REAL reference (oracle/_ref, compiled from /root/reference by oracle/Makefile; the
+            # library travels to the GPU box) on the same inputs.  Noise off: exact ties are ordered by item id here and by
+            # libstdc++'s sort there (deviation D4) -- the synthetic factors have none.
+            real = ref.calc(pr["A"], pr["B"], pr["train"], pr["test"], k, cumulative=cumulative, dtype=dtype, nthreads=NT, **kw)
+            for name in real:
+                assert_close(got[name], real[name], TOL, "%s cumulative=%s vs the compiled reference" % (name, cumulative))
+                if name != "ROC_AUC":
+                    assert_same_bits(want[name], real[name], "%s cumulative=%s: restatement vs the compiled reference" % (name, cumulative))
         # PR_AUC of a user with more than 63 test items is assembled from per-chunk partial sums (finalize):
         # same terms, different association than the reference's single running sum -> a few ulp(fp64), checked at 1e-12
         # (only when such users take one sweep slot per chunk, RM_STREAM_BUDGET_MB=0; by default their ranks come from
@@ -461,6 +488,37 @@ def test_full_size_properties(hip, oracle):
         assert not set(rk["topk_idx"][u]).intersection(tri[trp[u]:trp[u + 1]])
 
 
+@pytest.mark.parametrize("noise", [False, True])
+def test_baseline_c2_at_its_full_user_count(hip, noise):
+    """BASELINE C2 as quoted -- all 138,493 users x 26,744 items x 64 factors, K = 10, all ten metrics -- through the
+    host-pointer entry: the m-driven machinery (a grid of 1,256 sweep blocks in several rounds with a two-level tail, 26 k
+    streamed users = 2.8 GB of score rows addressed beyond 2^31 bytes, user batches) at full size, checked against the
+    REAL reference (oracle/_ref) on a stratified sample of 2,560 users: heaviest test rows, streamed users, the deepest
+    LDS tables, cold and skipped users, the first and last user blocks, a random remainder.  noise=True is the API default
+    (the reference's mt19937(seed + user) stream: the first 1,536 users keep their indices, so the same seed applies)."""
+    import bench
+    from oracle.oracle import NAMES, Oracle, Reference, reference_available
+    from recometrics_amd.synth import CONFIGS, make_factors, make_interactions
+    m, n, k, dtype, K, mean_c, seed = CONFIGS["C2"]
+    _, B = make_factors(1, n, k, dtype, seed)
+    A, _ = make_factors(m, 1, k, dtype, seed + 1)
+    trp, tri, tep, tei, tev = make_interactions(m, n, mean_c, dtype, seed)
+    host = dict(A=A, B=B, train=(trp, tri), test=(tep, tei, tev))
+    want_flags = {name: True for name in hip.METRIC_ORDER}
+    outs = hip.calc_metrics(A, k, B, k, trp, tri, tep, tei, tev, K, want_flags, False, noise, True, 2, 1, 1, 77)
+    users = np.arange(1536) if noise else bench.stratified_users(host, 2560)
+    assert noise or ((np.diff(tep)[users] > 63).sum() >= 300 and users[-1] == m - 1)
+    sA, sB, str_, ste = bench.sub_problem(host, users)
+    impl = Reference() if reference_available() else Oracle()
+    want = impl.calc(sA, sB, str_, ste, K, nthreads=min(256, os.cpu_count() or 1), noise=noise, seed=77, dtype=dtype)
+    for name, arr in zip(hip.METRIC_ORDER, outs):
+        assert_close(arr[users], want[NAMES[name]], TOL, "C2 full size, noise=%s: %s" % (noise, name))
+        if name != "roc":
+            assert_same_bits(arr[users], want[NAMES[name]], "C2 full size, noise=%s: %s (bitwise)" % (noise, name))
+    roc = outs[hip.METRIC_ORDER.index("roc")]
+    assert abs(np.nanmean(roc) - 0.5) < 0.005 and np.isnan(roc).sum() == (np.diff(tep) == 0).sum()
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # BASELINE shapes at their full ITEM counts (user-sliced: users are independent, so a slice of the users exercises
 # exactly the n-driven machinery -- item splits and the merge of partial lists, > 2^32-byte offsets into the packed
@@ -511,3 +569,76 @@ def test_baseline_c5_item_count(hip, oracle):
     """C5: 500,000 items x 256 factors fp64, K = 50 (streamed factor axis, fp64 append buffers), 96 users"""
     pr = _big_problem(96, 500_000, 256, np.float64, 50, 105, heavy=(70,))
     _check_against_oracle(hip, oracle, pr, 50, dtype=np.float64)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# boundary behaviour (reference src/recometrics.hpp:359-436, recometrics/wrapper.pyx:226-323)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_zero_users_is_a_no_op(hip, dtype):
+    """m == 0: the reference's loop over users does not run and the call returns normally (:428-437)"""
+    A = np.zeros((0, 8), dtype)
+    B = np.ones((50, 8), dtype)
+    zp = np.zeros(1, np.int32)
+    outs = hip.calc_metrics(A, 8, B, 8, zp, np.zeros(0, np.int32), zp, np.zeros(0, np.int32), np.zeros(0, dtype), 5,
+                            {name: True for name in hip.METRIC_ORDER}, False, True, True, 2, 1, 1, 1)
+    assert all(o.size == 0 for o in outs)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_empty_test_matrix_with_null_indices(hip, oracle, dtype):
+    """no test entry at all: the bindings hand over NULL for the empty index / value arrays; every user is NaN"""
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((40, 8)).astype(dtype)
+    B = rng.standard_normal((300, 8)).astype(dtype)
+    trp = np.arange(0, 41 * 3, 3, dtype=np.int32)
+    tri = np.tile(np.array([1, 5, 9], np.int32), 40)
+    tep = np.zeros(41, np.int32)
+    want = {name: name != "ndcg" for name in hip.METRIC_ORDER}
+    outs = hip.calc_metrics(A, 8, B, 8, trp, tri, tep, np.zeros(0, np.int32), np.zeros(0, dtype), 5, want, False, False, True, 2, 1, 1, 1)
+    for name, o in zip(hip.METRIC_ORDER, outs):
+        if want[name]:
+            assert np.isnan(o).all(), name
+    ref = oracle.calc(A, B, (trp, tri), (tep, np.zeros(0, np.int32), np.zeros(0, dtype)), 5, dtype=dtype,
+                      metrics=tuple(nm for nm in hip.METRIC_ORDER if nm != "ndcg"))
+    assert all(np.isnan(v).all() for v in ref.values())
+    from recometrics_amd import build as rb
+    import importlib.util, os as _os
+    if _os.path.exists(rb.cython_module_path()):
+        from recometrics_amd import _cy
+        outs2 = _cy.calc_metrics(A, 8, B, 8, trp, tri, tep, np.zeros(0, np.int32), np.zeros(0, dtype), 5, want, False, False, True, 2, 1, 1, 1)
+        for name, o in zip(hip.METRIC_ORDER, outs2):
+            if want[name]:
+                assert np.isnan(o).all(), "cython binding: " + name
+
+
+def test_ndcg_without_test_values_is_an_error(hip):
+    """deviation D8: the reference dereferences the null pointer (:870-874); here RM_ERR_INVALID"""
+    A = np.ones((4, 4), np.float32)
+    B = np.ones((30, 4), np.float32)
+    p = np.arange(5, dtype=np.int32)
+    i = np.arange(4, dtype=np.int32)
+    want = {name: name == "ndcg" for name in hip.METRIC_ORDER}
+    with pytest.raises(ValueError):
+        hip.calc_metrics(A, 4, B, 4, np.zeros(5, np.int32), np.zeros(0, np.int32), p, i, np.zeros(0, np.float32), 3, want, False, False, True, 2, 1, 1, 1)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_repeated_test_columns_fill_the_top_k(hip, oracle, dtype):
+    """a non-canonical test row (an item listed twice; the reference only sorts the rows): the seeded K-th-best bound must count
+    candidates, not entries -- the ordered top-K lists stay complete and equal the oracle's"""
+    from recometrics_amd.synth import make_problem
+    pr = make_problem(200, 400, 8, dtype, mean_c=60, seed=9)
+    tep, tei, tev = pr["test"]
+    rows_i, rows_v, newp = [], [], [0]
+    for u in range(200):
+        it = tei[tep[u]:tep[u + 1]]
+        rep = np.sort(np.concatenate([it, it, it[:3]]))               # every test item two or three times
+        rows_i.append(rep); rows_v.append(np.ones(rep.shape[0], dtype)); newp.append(newp[-1] + rep.shape[0])
+    test = (np.array(newp, np.int32), np.concatenate(rows_i).astype(np.int32), np.concatenate(rows_v))
+    trp, tri = pr["train"]
+    for K in (5, 12):
+        want = oracle.rank(pr["A"], pr["B"], pr["train"], test, K, dtype=dtype, nthreads=NT)
+        got = hip.rank(np.ascontiguousarray(pr["A"], dtype), np.ascontiguousarray(pr["B"], dtype), trp, tri, test[0], test[1], K)
+        assert (got["topk_idx"] >= 0).all(), "incomplete top-K list"
+        assert (got["topk_idx"] == want["topk_idx"]).all()
+        assert_same_bits(got["topk_score"], want["topk_score"], "top-K scores")

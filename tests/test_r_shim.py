@@ -1,0 +1,126 @@
+"""The Rcpp glue of the R package (r/src/Rwrapper_hip.cpp) cannot be executed here -- the image has no R -- but everything in
+it that is not an Rcpp type lives in r/src/rm_r_shim.c, and this file drives that shim through ctypes with exactly the
+buffers Rcpp would hand over (reference src/Rwrapper.cpp:61-410): factor matrices COLUMN-major [k, m] / [k, n], float32
+data as the bits of int32 storage (package `float`), test values always double, outputs [k_metrics, m] column-major when
+cumulative; doubles come back with R's NA_real_ where a user cannot be evaluated (src/recometrics.hpp:75-80, _FOR_R)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from _util import assert_same_bits
+
+NA_REAL_BITS = 0x7FF00000000007A2          # R_NaReal: high word 0x7FF00000, low word 1954 (R's arithmetic.c)
+ORDER = ("p", "tp", "r", "ap", "tap", "ndcg", "hit", "rr", "roc", "pr")
+
+
+def _shim():
+    from recometrics_amd import build as rb
+    lib = C.CDLL(rb.build_r_shim())
+    vp, i32, u64, ci = C.c_void_p, C.c_int32, C.c_uint64, C.c_int
+    sig = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, ci, ci, C.POINTER(vp), ci, i32, i32, i32, u64]
+    lib.rm_r_calc_metrics_f64.argtypes = sig
+    lib.rm_r_calc_metrics_f32.argtypes = sig
+    lib.rm_r_calc_metrics_f64.restype = lib.rm_r_calc_metrics_f32.restype = ci
+    lib.rm_r_nan_to_na.argtypes = [vp, C.c_size_t]
+    lib.rm_r_nan_to_na.restype = None
+    return lib
+
+
+def test_shim_builds_and_maps_nan_to_na_real():
+    """CPU: the shim compiles with -Wall -Wextra -Werror against include/recometrics_hip.h, links the library, and its
+    NaN -> NA_real_ pass writes R's exact bit pattern (any NaN, either sign, payload or not) and leaves numbers alone"""
+    lib = _shim()
+    x = np.array([1.5, np.nan, -np.inf, 0.0, -np.nan, np.inf], np.float64)
+    x.view(np.uint64)[4] = 0xFFF8000000000123          # a negative NaN with a payload
+    lib.rm_r_nan_to_na(x.ctypes.data_as(C.c_void_p), x.shape[0])
+    bits = x.view(np.uint64)
+    assert bits[1] == NA_REAL_BITS and bits[4] == NA_REAL_BITS
+    assert x[0] == 1.5 and x[2] == -np.inf and x[3] == 0.0 and x[5] == np.inf
+    glue = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "r", "src", "Rwrapper_hip.cpp")).read()
+    for name in ("rm_r_calc_metrics_f64", "rm_r_calc_metrics_f32", "rm_r_nan_to_na", "rm_last_error", "rm_has_openmp"):
+        assert name in glue                              # the glue calls what is tested here
+        assert hasattr(lib, name) or name.startswith("rm_last") or name.startswith("rm_has")
+
+
+def _call(lib, dtype, pr, K, cumulative, want, noise=False, seed=1):
+    """Hand the shim what Rcpp hands it."""
+    m, k = pr["A"].shape
+    n = pr["B"].shape[0]
+    At = np.asfortranarray(pr["A"].astype(dtype).T)               # R: t(A), a [k, m] column-major matrix
+    Bt = np.asfortranarray(pr["B"].astype(dtype).T)
+    assert At.flags.f_contiguous and At.shape == (k, m)
+    if dtype == np.float32:                                       # float::fl(A)@Data: INTEGER storage
+        At_store, Bt_store = At.view(np.int32), Bt.view(np.int32)
+        store = np.int32
+    else:
+        At_store, Bt_store, store = At, Bt, np.float64
+    trp, tri = pr["train"]
+    tep, tei, tev = pr["test"]
+    tev64 = tev.astype(np.float64)                                # X_test@x is a double vector in either path
+    outs, ptrs = {}, (C.c_void_p * 10)()
+    for i, name in enumerate(ORDER):
+        if not want.get(name):
+            ptrs[i] = None
+            continue
+        shape = (K, m) if (cumulative and i < 8) else (m,)
+        outs[name] = np.full(shape, -7, dtype=store, order="F")  # Rcpp: Matrix(k_metrics, m) / Vector(m)
+        ptrs[i] = outs[name].ctypes.data
+    fn = lib.rm_r_calc_metrics_f32 if dtype == np.float32 else lib.rm_r_calc_metrics_f64
+    rc = fn(At_store.ctypes.data, Bt_store.ctypes.data, m, n, k, trp.ctypes.data, tri.ctypes.data if tri.size else None,
+            tep.ctypes.data, tei.ctypes.data, tev64.ctypes.data, K, int(cumulative), int(noise), ptrs, 1, 2, 1, 1, seed)
+    assert rc == 0, rc
+    res = {}
+    for name, arr in outs.items():
+        val = arr.view(np.float32) if dtype == np.float32 else arr
+        res[name] = val.T if val.ndim == 2 else val              # R: t(matrix(res, nrow = k))  ->  [m, k]
+    return res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("cumulative", [False, True])
+def test_the_call_rcpp_makes_equals_the_python_binding(dtype, cumulative):
+    from recometrics_amd import _binding as hip
+    from recometrics_amd.synth import make_problem
+    lib = _shim()
+    pr = make_problem(333, 1500, 24, dtype, mean_c=30, seed=8)
+    tep = pr["test"][0].copy()
+    # users 5..9 lose their test rows: not evaluated -> NaN here, NA_real_ through the double path of the shim
+    cut = tep[10] - tep[5]
+    tep[6:10] = tep[5]; tep[10:] -= cut
+    tei = np.concatenate([pr["test"][1][:pr["test"][0][5]], pr["test"][1][pr["test"][0][10]:]])
+    tev = np.concatenate([pr["test"][2][:pr["test"][0][5]], pr["test"][2][pr["test"][0][10]:]])
+    pr["test"] = (tep, tei, tev)
+    want = {name: True for name in ORDER}
+    K = 6
+    for noise in (False, True):
+        got = _call(lib, dtype, pr, K, cumulative, want, noise=noise, seed=11)
+        ref = hip.calc_metrics(np.ascontiguousarray(pr["A"], dtype), 24, np.ascontiguousarray(pr["B"], dtype), 24, pr["train"][0], pr["train"][1],
+                               tep, tei, tev.astype(dtype), K, want, cumulative, noise, True, 2, 1, 1, 11)
+        for name, r in zip(ORDER, ref):
+            g = np.ascontiguousarray(got[name])
+            assert g.shape == r.shape, (name, g.shape, r.shape)
+            assert_same_bits(g, r, "%s through the R shim (noise=%s)" % (name, noise))      # NaN == NaN whatever the payload
+            nan = np.isnan(r)
+            assert nan.reshape(333, -1)[5:10].all(), name
+            if dtype == np.float64:
+                assert (g.view(np.uint64)[nan] == NA_REAL_BITS).all(), name + ": NaN must be NA_real_ for R"
+            else:
+                assert (g.view(np.uint32)[nan] != 0).all()
+
+
+@pytest.mark.gpu
+def test_float_path_reads_the_test_values_only_for_ndcg():
+    """Rwrapper.cpp:245-249: without NDCG the float path never converts (or reads) Xtest_csr"""
+    from recometrics_amd.synth import make_problem
+    lib = _shim()
+    pr = make_problem(64, 500, 8, np.float32, mean_c=20, seed=2)
+    want = {name: name in ("p", "ap", "roc") for name in ORDER}
+    a = _call(lib, np.float32, pr, 5, False, want)
+    pr2 = dict(pr)
+    pr2["test"] = (pr["test"][0], pr["test"][1], np.full_like(pr["test"][2], np.nan))
+    b = _call(lib, np.float32, pr2, 5, False, want)
+    for name in a:
+        assert_same_bits(a[name], b[name], name)

@@ -1,4 +1,5 @@
-"""CPU-only: rm_split_* (recometrics_amd/csrc/rm_split.cpp) against fixtures captured from the real reference's
+"""Host-only code, run on the CPU here and once more on the GPU box (the `gpu`-marked twin at the end: the same checks through
+the library that ships there): rm_split_* (recometrics_amd/csrc/rm_split.cpp) against fixtures captured from the real reference's
 split functions (tests/golden/make_golden_split.py), bit for bit; plus the invariants of the reference's own
 tests/testthat/test-split.R:7-93 (X_train + X_test == X[users_test], row counts, error on impossible criteria)."""
 import glob
@@ -57,3 +58,11 @@ def test_split_invariants_like_the_reference_tests():
         split_reco_train_test(X, split_type="separated", min_pos_test=60, seed=5)
     with pytest.raises(ValueError):
         split_reco_train_test(X, split_type="separated", min_items_pool=70)
+
+
+@pytest.mark.gpu
+def test_split_through_the_shipped_library_on_the_gpu_box():
+    """N3 is host code, but it lives in the library that travels to the GPU box: run the fixture and invariant checks there once."""
+    for path in sorted(glob.glob(os.path.join(HERE, "golden", "split", "*.npz"))):
+        test_split_matches_reference_fixture(path)
+    test_split_invariants_like_the_reference_tests()
