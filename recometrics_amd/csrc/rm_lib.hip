@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <csignal>
 #include <map>
@@ -83,6 +84,16 @@ struct Ctx {
     hipStream_t own_stream = nullptr;        // stream of a shard worker (multi-device calls)
     hipStream_t up_stream = nullptr;         // host-pointer calls: uploads of the NEXT user batch run beside the current batch's kernels
     hipEvent_t up_ev[2] = {nullptr, nullptr};
+    void *pinned = nullptr; size_t pinned_bytes = 0;   // page-locked staging for the metric block of a batch (one D2H copy instead of ten)
+    void *pinned_get(size_t bytes)
+    {
+        if (pinned_bytes < bytes) {
+            if (pinned) { (void)hipHostFree(pinned); pinned = nullptr; pinned_bytes = 0; }
+            if (hipHostMalloc(&pinned, bytes + bytes / 8, hipHostMallocDefault) != hipSuccess) { pinned = nullptr; throw RmError{RM_ERR_NOMEM, "hipHostMalloc of the output staging buffer failed"}; }
+            pinned_bytes = bytes + bytes / 8;
+        }
+        return pinned;
+    }
     double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int timed_slots = 0, total_slots = 0;     // slots (user lanes) of the sweep launch the "sweep" timing brackets / of the call
     double acc[4] = {0, 0, 0, 0};            // prep / sweep / finalize / total ms of the batches already read back (host entry)
@@ -863,7 +874,10 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     T *dB = (T *)ws.get("in_B", sizeof(T) * (size_t)n * k);
     auto upload_items = [&]() {
         if (!shared || shard == 0) {
-            hipError_t e = hipMemcpy2DAsync(dB, sizeof(T) * k, h.B, sizeof(T) * h.ldb, sizeof(T) * k, n, hipMemcpyHostToDevice, up);
+            // (dense rows: ONE plain copy -- a 2-D copy of pageable memory goes through a staging buffer and a second,
+            // device-side pass: 1.1 ms more for BASELINE C2's A and B)
+            hipError_t e = h.ldb == (size_t)k ? hipMemcpyAsync(dB, h.B, sizeof(T) * (size_t)n * k, hipMemcpyHostToDevice, up)
+                                              : hipMemcpy2DAsync(dB, sizeof(T) * k, h.B, sizeof(T) * h.ldb, sizeof(T) * k, n, hipMemcpyHostToDevice, up);
             if (shared) {
                 if (e == hipSuccess) e = hipStreamSynchronize(up);
                 std::lock_guard<std::mutex> sl(shared->mu);
@@ -905,9 +919,8 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     HIP_CHECK(hipMemcpyAsync(dtrp, trp, sizeof(int) * (size_t)(m + 1), hipMemcpyHostToDevice, up));
     HIP_CHECK(hipMemcpyAsync(dtep, tep, sizeof(int) * (size_t)(m + 1), hipMemcpyHostToDevice, up));
     const size_t per = h.cumulative ? (size_t)K : 1;                 // values per user of the eight top-K metrics
-    static const char *onames[10] = {"o_p", "o_tp", "o_r", "o_ap", "o_tap", "o_ndcg", "o_hit", "o_rr", "o_roc", "o_pr"};
-    T *dout[10];
-    for (int i = 0; i < 10; i++) dout[i] = h.outs[i] ? (T *)ws.get(onames[i], sizeof(T) * (size_t)m * (i >= 8 ? 1 : per)) : nullptr;
+    size_t out_w = 0;                                               // values per user over all requested metrics
+    for (int i = 0; i < 10; i++) if (h.outs[i]) out_w += i >= 8 ? 1 : per;
     int *d_topk_idx = nullptr, *d_status = nullptr; T *d_topk_score = nullptr; long long *d_pos_rank = nullptr;
     if (h.topk_idx) {
         d_topk_idx = (int *)ws.get("o_topk_idx", sizeof(int) * (size_t)m * K);
@@ -926,32 +939,46 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
         const long long row = (((long long)n + 191) / 192 * 192) * (long long)sizeof(T);    // with a margin for what run() allocates first
         batch = std::max<long long>(1, std::min<long long>(batch, stream_budget_bytes(ws) * 3 / 4 / row));
     }
-    // batch boundaries: a ramp m/16, m/8, m/4, ... (whole kilo-users, capped by `batch`) when the range is large enough for the
-    // pipeline to matter; the compute of a batch takes longer than the upload of the next one twice its size
+    // batch boundaries: a first batch of a quarter of the users (whole kilo-users) when the range is large enough for the
+    // pipeline to matter -- its upload is the only one nothing hides, and every further batch costs ~0.4 ms of launches and a
+    // plan read-back (measured at BASELINE C2: profiles/r3_host_entry.txt) --, then batches of `batch` users
     std::vector<long long> cuts{0};
     {
-        long long next = (forced || m <= 16384) ? batch : std::min<long long>(batch, std::max<long long>(8192, ((long long)m / 16 + 1023) / 1024 * 1024));
+        long long next = (forced || m <= 16384) ? batch : std::min<long long>(batch, std::max<long long>(8192, ((long long)m / 4 + 1023) / 1024 * 1024));
         while (cuts.back() < m) {
             long long b1 = std::min<long long>(m, cuts.back() + next);
-            if (m - b1 < next / 4 && m - cuts.back() <= batch) b1 = m;             // no crumb at the end
+            if (m - b1 < 2048 && m - cuts.back() <= batch) b1 = m;                  // no crumb at the end
             cuts.push_back(b1);
-            if (!forced) next = std::min<long long>(batch, next * 2);
+            next = batch;
         }
     }
     const int n_batches = (int)cuts.size() - 1;
+    long long mb_max = 0;
+    for (int bi = 0; bi < n_batches; bi++) mb_max = std::max(mb_max, cuts[bi + 1] - cuts[bi]);
+    // the metric block of a batch: [metric][users of the batch x width], one device buffer, one D2H copy into page-locked
+    // staging, scattered into the caller's arrays by the host (ten pageable copies cost 35-140 us EACH in host time)
+    T *dblock = (T *)ws.get("o_block", sizeof(T) * std::max<size_t>(out_w * (size_t)mb_max, 1));
+    T *hblock = out_w ? (T *)cx.pinned_get(sizeof(T) * out_w * (size_t)mb_max) : nullptr;
     auto upload_users = [&](int bi) {                                 // rows [cuts[bi], cuts[bi + 1]) into their places, on `up`
         const long long b0 = cuts[bi], b1 = cuts[bi + 1];
-        HIP_CHECK(hipMemcpy2DAsync(dA + (size_t)b0 * k, sizeof(T) * k, h.A + ((size_t)u0 + b0) * h.lda, sizeof(T) * h.lda, sizeof(T) * k, (size_t)(b1 - b0),
-                                   hipMemcpyHostToDevice, up));
+        if (h.lda == (size_t)k) HIP_CHECK(hipMemcpyAsync(dA + (size_t)b0 * k, h.A + ((size_t)u0 + b0) * k, sizeof(T) * (size_t)(b1 - b0) * k, hipMemcpyHostToDevice, up));
+        else HIP_CHECK(hipMemcpy2DAsync(dA + (size_t)b0 * k, sizeof(T) * k, h.A + ((size_t)u0 + b0) * h.lda, sizeof(T) * h.lda, sizeof(T) * k, (size_t)(b1 - b0),
+                                        hipMemcpyHostToDevice, up));
         const long long r0 = trp[b0], r1 = trp[b1], e0 = tep[b0], e1 = tep[b1];      // range-relative entries of the batch
         if (r1 > r0) HIP_CHECK(hipMemcpyAsync(dtri + r0, h.tri + tr0 + r0, sizeof(int) * (size_t)(r1 - r0), hipMemcpyHostToDevice, up));
         if (e1 > e0) HIP_CHECK(hipMemcpyAsync(dtei + e0, h.tei + te0 + e0, sizeof(int) * (size_t)(e1 - e0), hipMemcpyHostToDevice, up));
         if (dtev && e1 > e0) HIP_CHECK(hipMemcpyAsync(dtev + e0, h.tev + te0 + e0, sizeof(T) * (size_t)(e1 - e0), hipMemcpyHostToDevice, up));
         HIP_CHECK(hipEventRecord(cx.up_ev[bi & 1], up));
     };
+    // RM_HOST_TRACE (timing studies only): host-side time stamps of the pipeline, printed at the end of the call
+    const bool trace = getenv("RM_HOST_TRACE") != nullptr;
+    std::vector<std::pair<const char *, double>> stamps;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto stamp = [&](const char *what) { if (trace) stamps.emplace_back(what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count()); };
     // shard 0 sends the item factors first (the other shards are waiting for them); the others send their own rows first
-    if (!shared || shard == 0) { upload_items(); upload_users(0); }
+    if (!shared || shard == 0) { upload_items(); stamp("items enqueued"); upload_users(0); }
     else { upload_users(0); upload_items(); HIP_CHECK(hipEventRecord(cx.up_ev[0], up)); }
+    stamp("batch 0 rows enqueued");
     for (int bi = 0; bi < n_batches; bi++) {
         const long long b0 = cuts[bi];
         const int b1 = (int)cuts[bi + 1], mb = b1 - (int)b0;
@@ -962,7 +989,8 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
         c.train_p = dtrp + b0; c.train_i = dtri; c.nnz_train = nnz_tr;
         c.test_p = dtep + b0; c.test_i = dtei; c.test_v = dtev; c.nnz_test = nnz_te;
         c.K = K; c.cumulative = h.cumulative; c.noise = h.noise; c.cold = h.cold; c.min_items_pool = h.mip; c.min_pos_test = h.mpt;
-        for (int i = 0; i < 10; i++) c.out[i] = dout[i] ? dout[i] + (size_t)b0 * (i >= 8 ? 1 : per) : nullptr;
+        size_t boff[10], bo = 0;
+        for (int i = 0; i < 10; i++) { boff[i] = bo; c.out[i] = h.outs[i] ? dblock + bo : nullptr; if (h.outs[i]) bo += (size_t)mb * (i >= 8 ? 1 : per); }
         if (h.topk_idx) {
             c.topk_idx = d_topk_idx + (size_t)b0 * K; c.topk_score = d_topk_score + (size_t)b0 * K;
             c.pos_rank = d_pos_rank; c.status = d_status + b0;
@@ -970,12 +998,11 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
         c.items_tag = tag;
         c.seed = h.seed; c.user0 = (long long)u0 + b0;
         run_call<T>(c, stream, cx);                                  // enqueued (one short plan read-back inside)
+        stamp("batch enqueued");
         // the next batch's rows travel while this batch's sweep runs (the copies below block the host, not the device)
         if (bi + 1 < n_batches && !g_interrupt) upload_users(bi + 1);
-        for (int i = 0; i < 10; i++) {
-            const size_t w = i >= 8 ? 1 : per;
-            if (h.outs[i]) HIP_CHECK(hipMemcpyAsync(h.outs[i] + ((size_t)u0 + b0) * w, c.out[i], sizeof(T) * (size_t)mb * w, hipMemcpyDeviceToHost, stream));
-        }
+        stamp("next rows enqueued");
+        if (bo) HIP_CHECK(hipMemcpyAsync(hblock, dblock, sizeof(T) * bo, hipMemcpyDeviceToHost, stream));
         if (h.topk_idx) {
             HIP_CHECK(hipMemcpyAsync(h.topk_idx + ((size_t)u0 + b0) * K, c.topk_idx, sizeof(int) * (size_t)mb * K, hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipMemcpyAsync(h.topk_score + ((size_t)u0 + b0) * K, c.topk_score, sizeof(T) * (size_t)mb * K, hipMemcpyDeviceToHost, stream));
@@ -984,6 +1011,12 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
             if (e1 > e0) HIP_CHECK(hipMemcpyAsync(h.pos_rank + te0 + e0, c.pos_rank + e0, sizeof(long long) * (size_t)(e1 - e0), hipMemcpyDeviceToHost, stream));
         }
         HIP_CHECK(hipStreamSynchronize(stream));
+        stamp("batch done");
+        for (int i = 0; i < 10; i++) {
+            const size_t w = i >= 8 ? 1 : per;
+            if (h.outs[i]) std::memcpy(h.outs[i] + ((size_t)u0 + b0) * w, hblock + boff[i], sizeof(T) * (size_t)mb * w);
+        }
+        stamp("outputs scattered");
         if (n_batches > 1) {                                          // more than one batch: add up the stage timings
             float ta = 0, tb = 0, tc = 0, td = 0;
             (void)hipEventElapsedTime(&ta, cx.ev[0], cx.ev[1]); (void)hipEventElapsedTime(&tb, cx.ev[1], cx.ev[2]);
@@ -993,6 +1026,11 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
         }
     }
     HIP_CHECK(hipStreamSynchronize(up));                              // `rb` and the caller's arrays go out of use (also after an interrupt)
+    if (trace) {
+        std::string line = "rm host trace (" + std::to_string(n_batches) + " batches, ms):";
+        for (auto &st : stamps) { char buf[96]; snprintf(buf, sizeof buf, " [%s %.3f]", st.first, st.second); line += buf; }
+        fprintf(stderr, "%s\n", line.c_str());
+    }
 }
 
 // (m == 0 is not an error: the reference's loop over users, src/recometrics.hpp:428-437, simply does not run; the entry

@@ -315,9 +315,14 @@ __global__ void k_seed_thresholds(int n_slots, int stream_slot0, int K, int gu, 
     // the K-th best DISTINCT score of the test row: a non-canonical CSR row may list an item twice (the reference only sorts
     // the rows, recometrics/__init__.py:478-486), and K entries are then fewer than K candidates -- entries with equal scores
     // count once, which can only lower the bound
+    // (k_pos_place ranks the entries by (score, item): two entries of the same item share a rank and a row, and the row behind
+    // them keeps its +inf filling -- such holes are not scores)
     int i = nvalid - 1, distinct = 1;
     T kth = tab[(long long)i * stride];
-    while (distinct < K && i > 0) { const T x = tab[(long long)(--i) * stride]; if (x != kth) { kth = x; distinct++; } }
+    while (distinct < K && i > 0) {
+        const T x = tab[(long long)(--i) * stride];
+        if (x != kth && !(isinf(x) && x > 0)) { kth = x; distinct++; }
+    }
     if (distinct < K) return;
     if (kth == kth) thr_shared[slot] = ord_key(kth);
 }

@@ -129,13 +129,11 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
     float nx[16];
     #pragma unroll
     for (int r = 0; r < 16; r++) nx[r] = *(LdsF32Ptr)(at[r]);
-    float df[16];                                              // two differences per instruction (v_pk_add_f32)
+    // (one v_sub_f32 each, through asm: left to itself the compiler pairs them into v_pk_add_f32, which issues at less than half
+    // the rate of two plain subtractions -- profiles/r3_coexec4_issue_rates.txt)
+    float df[16];
     #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const f32x2 d2 = f32x2{nx[r], nx[r + 1]} - f32x2{v[r], v[r + 1]};
-        df[r] = d2.x; df[r + 1] = d2.y;
-    }
+    for (int r = 0; r < 16; r++) asm("v_sub_f32 %0, %1, %2" : "=v"(df[r]) : "v"(nx[r]), "v"(v[r]));
     // Every positive meets ITSELF here (its own item is a candidate with exactly its score): at 27k items three tiles out of
     // four hold one, so the "rare" path is the common one at small item counts and its bookkeeping counts (10 % of the C2 sweep
     // before this form): the minima of the five register triples are kept, a triple is only looked into when one of its
@@ -453,7 +451,9 @@ void k_sweep(SweepArgs a)
             // instructions carry the NaN through -- masking costs the one v_bfe that replaces the zero, not a v_bfe and a
             // v_or per score after the fact (16 fewer vector instructions per tile; unmasked chains still start at +0).
             if (a.train_bits) {
-                const int mb = (int)(tile_bits >> (4 * h));
+                // (`tile_bits` arrives shifted by the lane half already -- see the loads: a shift here lands in the register
+                // the allocator has just freed, accumulator 0, and costs sixteen moves to get out of the way again)
+                const int mb = (int)tile_bits;
                 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[r] = __int_as_float(__builtin_amdgcn_sbfe(mb, (r & 3) + 8 * (r >> 2), 1));
             } else {
@@ -522,7 +522,7 @@ void k_sweep(SweepArgs a)
 #endif
         if (a.train_bits) {                                       // masked in the accumulators already (do_mfma)
             if (a.check_nan) {
-                const int mb = (int)(tile_bits >> (4 * h));
+                const int mb = (int)tile_bits;
                 #pragma unroll
                 for (int r = 0; r < 16; r++) nanmask |= __ballot(!__builtin_amdgcn_sbfe(mb, (r & 3) + 8 * (r >> 2), 1) && (v[r] != v[r]));
             }
@@ -707,7 +707,8 @@ void k_sweep(SweepArgs a)
     LdsU32Ptr arrive = (LdsU32Ptr)(smem + a.sync_off) + sub;            // (words 4..7 of the area: the groups' list locks)
     if (tid < 4) ((LdsU32Ptr)(smem + a.sync_off))[tid] = 0u;
     if (ntiles > 0) stage(t0 * NC, 0);
-    unsigned tile_bits = (tb_row && ntiles > 0) ? a.train_bits[tb_idx] : 0u;           // first tile's word of the dense train row
+    // first tile's word of the dense train row, shifted so that bit (r & 3) + 8 (r >> 2) is accumulator r's item for this lane half
+    unsigned tile_bits = (tb_row && ntiles > 0) ? a.train_bits[tb_idx] >> (4 * h) : 0u;
     // vmcnt(0) through the builtin (not asm) so that the compiler's own wait-count bookkeeping sees the drain: every
     // load it issued before this point is known complete and needs no further wait inside the loop.
     __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);
@@ -759,7 +760,7 @@ void k_sweep(SweepArgs a)
             // the NEXT tile's word of the dense train row (the accumulators start from it): in flight during the MFMA phase,
             // drained by the wait at the arrive point
             unsigned bits_next = 0u;
-            if (c == NC - 1 && tb_row && i + 1 < ntiles) { tb_idx += NSUB; bits_next = a.train_bits[tb_idx]; }
+            if (c == NC - 1 && tb_row && i + 1 < ntiles) { tb_idx += NSUB; bits_next = a.train_bits[tb_idx] >> (4 * h); }
 #ifndef RM_ABL_NO_MFMA
             do_mfma(acc, unit & 1, c, tile_bits);
 #endif

@@ -82,9 +82,16 @@ def test_user_batches_equal_one_batch(hip, monkeypatch):
         assert (rk[key] == rk1[key]).all() or key == "topk_score", key
 
 
-def _interruptible_problem():
+def _interruptible_problem(copies=6):
+    """245,760 users (one synthetic problem of 40 k users stacked `copies` times): at 1,024 users per batch the call takes a
+    few hundred batches, ~0.1 s -- it outlasts the 30 ms timers below by a wide margin"""
     from recometrics_amd.synth import make_problem
-    return make_problem(40 * 1024, 20000, 64, np.float32, mean_c=40, seed=8)
+    pr = make_problem(40 * 1024, 20000, 64, np.float32, mean_c=40, seed=8)
+
+    def stack(p, *arrs):
+        ptr = np.concatenate([p[:1]] + [p[1:].astype(np.int64) + i * int(p[-1]) for i in range(copies)]).astype(np.int32)
+        return (ptr,) + tuple(np.tile(a, copies) for a in arrs)
+    return {"A": np.tile(pr["A"], (copies, 1)), "B": pr["B"], "train": stack(*pr["train"]), "test": stack(*pr["test"])}
 
 
 def test_interrupt_between_batches(hip, monkeypatch):
@@ -93,7 +100,7 @@ def test_interrupt_between_batches(hip, monkeypatch):
     pr = _interruptible_problem()
     m = pr["A"].shape[0]
     full = _calc(hip, pr, 10)
-    monkeypatch.setenv("RM_BATCH_USERS", "256")          # 160 batches: the call outlasts the timer by a wide margin
+    monkeypatch.setenv("RM_BATCH_USERS", "1024")         # 240 batches: the call outlasts the timer by a wide margin
     outs = [np.full(m, -7.0, np.float32) for _ in range(10)]
     t = threading.Timer(0.03, hip.request_interrupt)
     t.start()
@@ -101,7 +108,7 @@ def test_interrupt_between_batches(hip, monkeypatch):
         _calc(hip, pr, 10, outs=outs)
     t.join()
     done = int((outs[0] != -7.0).sum() if not np.isnan(outs[0]).any() else (~(outs[0] == -7.0)).sum())
-    assert 256 <= done < m and done % 256 == 0, "finished users: %d of %d" % (done, m)
+    assert 1024 <= done < m and done % 1024 == 0, "finished users: %d of %d" % (done, m)
     for name, g, w in zip(hip.METRIC_ORDER, outs, full):
         assert_same_bits(g[:done], w[:done], name + " of the users finished before the interrupt")
         assert (g[done:] == -7.0).all(), name + ": users after the interrupt must be untouched"
@@ -115,7 +122,7 @@ def test_sigint_during_a_call_becomes_keyboard_interrupt(hip, monkeypatch):
     """a real SIGINT: the library's handler takes it during the call, then restores Python's handler and re-raises the
     signal, so that the caller sees KeyboardInterrupt (reference :166-173 + recometrics/wrapper.pyx `except +`)"""
     pr = _interruptible_problem()
-    monkeypatch.setenv("RM_BATCH_USERS", "256")           # 160 batches: the signal arrives while the call is running
+    monkeypatch.setenv("RM_BATCH_USERS", "1024")          # 240 batches: the signal arrives while the call is running
     before = signal.getsignal(signal.SIGINT)
     t = threading.Timer(0.03, lambda: os.kill(os.getpid(), signal.SIGINT))
     t.start()

