@@ -34,8 +34,15 @@ def needs_build():
     return any(os.path.getmtime(p) > t for p in _deps())
 
 
+# the sweeps: no SLP vectorisation -- it pairs independent f32 adds into v_pk_add_f32, which issue at less than half the rate of
+# two plain instructions on gfx950 (profiles/r3_coexec4_issue_rates.txt)
+SWEEP_FLAGS = ["-fno-slp-vectorize"]
+
+
 def _compile(src, extra):
     obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+    if src.startswith("rm_sweep"):
+        extra = list(extra) + SWEEP_FLAGS
     if src.endswith(".cpp"):        # host-only translation unit
         cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
     else:

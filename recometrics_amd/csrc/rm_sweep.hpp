@@ -129,11 +129,17 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
     float nx[16];
     #pragma unroll
     for (int r = 0; r < 16; r++) nx[r] = *(LdsF32Ptr)(at[r]);
-    // (one v_sub_f32 each, through asm: left to itself the compiler pairs them into v_pk_add_f32, which issues at less than half
-    // the rate of two plain subtractions -- profiles/r3_coexec4_issue_rates.txt)
+    // (plain subtractions: the sweep's translation units are compiled with -fno-slp-vectorize -- paired into v_pk_add_f32 they
+    // issue at less than half the rate of two v_sub_f32, profiles/r3_coexec4_issue_rates.txt; written as asm statements
+    // instead, the scheduler serialises the sixteen LDS reads behind two registers)
     float df[16];
     #pragma unroll
-    for (int r = 0; r < 16; r++) asm("v_sub_f32 %0, %1, %2" : "=v"(df[r]) : "v"(nx[r]), "v"(v[r]));
+    for (int r = 0; r < 16; r++) {
+        // the sixteen reads are waited for in four groups (lgkmcnt 12 / 8 / 4 / 0), not one by one: a wait is an issue slot too
+        if (r == 0) __builtin_amdgcn_s_waitcnt(0xCC7F); else if (r == 4) __builtin_amdgcn_s_waitcnt(0xC87F);
+        else if (r == 8) __builtin_amdgcn_s_waitcnt(0xC47F); else if (r == 12) __builtin_amdgcn_s_waitcnt(0xC07F);
+        df[r] = nx[r] - v[r];
+    }
     // Every positive meets ITSELF here (its own item is a candidate with exactly its score): at 27k items three tiles out of
     // four hold one, so the "rare" path is the common one at small item counts and its bookkeeping counts (10 % of the C2 sweep
     // before this form): the minima of the five register triples are kept, a triple is only looked into when one of its
@@ -760,7 +766,7 @@ void k_sweep(SweepArgs a)
             // the NEXT tile's word of the dense train row (the accumulators start from it): in flight during the MFMA phase,
             // drained by the wait at the arrive point
             unsigned bits_next = 0u;
-            if (c == NC - 1 && tb_row && i + 1 < ntiles) { tb_idx += NSUB; bits_next = a.train_bits[tb_idx] >> (4 * h); }
+            if (c == NC - 1 && tb_row && i + 1 < ntiles) { tb_idx += NSUB; bits_next = a.train_bits[tb_idx]; }      // (shifted once it has landed, below)
 #ifndef RM_ABL_NO_MFMA
             do_mfma(acc, unit & 1, c, tile_bits);
 #endif
@@ -775,7 +781,7 @@ void k_sweep(SweepArgs a)
 #ifndef RM_ABL_NO_EPI
             if (c == NC - 1) do_epi(acc, t0 + i, thr_seen, tile_bits);
 #endif
-            if (c == NC - 1) tile_bits = bits_next;
+            if (c == NC - 1) tile_bits = bits_next >> (4 * h);
 #if defined(RM_FULL_BARRIER)
             __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                              // the DMA of the next unit has landed
             __syncthreads();

@@ -1,13 +1,14 @@
 #!/bin/bash
 # A/B timing: bash scratch/ab2.sh <out> "<wl users>;<wl users>..." <lib1> <lib2> ...   (min sweep ms over 4 steps, two rounds)
 out=$1; wls=$2; shift; shift
+libs=("$@")
 mkdir -p gpurun_out/$out
 for round in 1 2; do
-for lib in "$@"; do
+for lib in "${libs[@]}"; do
   IFS=';' read -ra W <<< "$wls"
   for wl in "${W[@]}"; do
     set -- $wl
-    RECOMETRICS_HIP_LIB=$PWD/$lib python3 scratch/ns.py $1 $2 4 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$lib', d['workload'], d['users'], round(d['sweep_ms'],3), round(d['frac'],4), round(d['users_per_s']))" >> gpurun_out/$out/ab.txt
+    RECOMETRICS_HIP_LIB=$PWD/$lib python3 scratch/ns.py $1 $2 4 2>>gpurun_out/$out/err.txt | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$lib', d['workload'], d['users'], round(d['sweep_ms'],3), round(d['frac'],4), round(d['users_per_s']))" >> gpurun_out/$out/ab.txt
   done
 done
 done
