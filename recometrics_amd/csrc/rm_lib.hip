@@ -100,6 +100,7 @@ struct Ctx {
     // what the packed item image (workspace buffer "Bp") currently holds, for batches of one host call that share B
     unsigned long long packed_tag = 0; int packed_tile = 0, packed_ng = 0; const void *packed_ptr = nullptr;
     const void *bits_ptr = nullptr; long long bits_words = 0; int bits_m = 0;      // dense train rows as last built (set_train_bits)
+    unsigned long long bits_tag = 0; const int *bits_train_p = nullptr;             // ... by which call (Call::items_tag) and for which rows
     unsigned long long packed_amax_b = 0; int packed_nonfinite_b = 0;
 };
 std::mutex g_ctx_mu;
@@ -265,7 +266,7 @@ template <class C> inline void set_train_bits(SweepArgs &sa, Ctx &cx, const C &c
     const long long words = (n_pad + 31) / 32;
     const size_t bytes = (size_t)m * (size_t)words * 4;
     sa.train_bits = nullptr; sa.train_words = 0;
-    if (bytes > ((size_t)1 << 30) || words > TRAIN_BITS_MAX_WORDS || getenv("RM_DEBUG_NO_TRAIN_BITS")) return;
+    if (bytes > ((size_t)1 << 30) || words > TRAIN_BITS_MAX_WORDS || getenv("RM_DEBUG_NO_TRAIN_BITS")) { cx.bits_tag = 0; return; }
     unsigned *bits = (unsigned *)ws.get("train_bits", bytes);
     // (the exact second pass of the tie noise evaluates a subset of the same users: the rows of the first pass are still there)
     const bool ready = c.same_train_rows && cx.bits_ptr == (const void *)bits && cx.bits_words == words && cx.bits_m == m;
@@ -275,6 +276,7 @@ template <class C> inline void set_train_bits(SweepArgs &sa, Ctx &cx, const C &c
                            m, n, (int)words, c.train_p, c.train_i, bits);
     }
     cx.bits_ptr = (const void *)bits; cx.bits_words = words; cx.bits_m = m;
+    cx.bits_tag = c.items_tag; cx.bits_train_p = c.train_p;
     sa.train_bits = bits; sa.train_words = (int)words;
 }
 template <class C> inline void set_train_bits(Sweep64Args &, Ctx &, const C &, int, int, long long, hipStream_t) {}
@@ -698,8 +700,14 @@ void run_call(const Call<T> &c_in, hipStream_t stream, Ctx &cx)
         E = (T *)ws.get("noise_rows", sizeof(T) * (size_t)rows * (size_t)e_ld);
         hipLaunchKernelGGL(k_mt_draws, dim3(cdiv(rows, MT_WAVES)), dim3(MT_WAVES * WAVE), 0, stream, row_user, rows, c0.seed, user0,
                            train_p, n, per, D, d_ld);
-        hipLaunchKernelGGL(k_noise_rows<T>, dim3(cdiv((long long)rows * e_ld, 256)), dim3(256), 0, stream, row_user, rows, train_p, c0.train_i, n,
-                           D, d_ld, E, e_ld);
+        // the dense train rows of this call's own first pass (fp32, small item counts), when they cover exactly these users
+        const bool dense = cx.bits_tag != 0 && cx.bits_tag == c0.items_tag && cx.bits_train_p == train_p && cx.bits_m == m && row_user != nullptr;
+        if (dense)
+            hipLaunchKernelGGL(k_noise_rows_bits<T>, dim3(rows), dim3(NOISE_ROWS_THREADS), sizeof(int) * (size_t)(cx.bits_words + 1), stream, row_user, rows,
+                               (const unsigned *)cx.bits_ptr, (int)cx.bits_words, n, D, d_ld, E, e_ld);
+        else
+            hipLaunchKernelGGL(k_noise_rows<T>, dim3(cdiv((long long)rows * e_ld, 256)), dim3(256), 0, stream, row_user, rows, train_p, c0.train_i, n,
+                               D, d_ld, E, e_ld);
     };
     if (sizeof(T) == 8) {
         const long long width = c0.cumulative ? c0.K : 1;

@@ -118,6 +118,53 @@ __global__ void k_noise_rows(const int *row_user, int n_rows, const int *train_p
     E[(size_t)row * (size_t)e_ld + item] = e;
 }
 
+// The same from the DENSE train rows the sweep uses at small item counts (SweepArgs::train_bits: bit i of word i >> 5 = item i is
+// a train item of the user, or lies beyond n): block per row, the number of train items in front of every 32-item word by a
+// block-wide scan of the words' popcounts in LDS, then candidate index = item - (that count + popcount of the lower bits of the
+// item's own word) -- no dependent walk through the CSR row per element (0.54 -> 0.1 ms for the 2,182 flagged users of
+// BASELINE C2).  words <= TRAIN_BITS_MAX_WORDS (rm_prep.hpp).
+constexpr int NOISE_ROWS_THREADS = 256;
+template <class T>
+__global__ __launch_bounds__(NOISE_ROWS_THREADS) void k_noise_rows_bits(const int *row_user, int n_rows, const unsigned *bits, int words, int n,
+                                                                        const unsigned *draws, long long d_ld, T *E, long long e_ld)
+{
+    extern __shared__ int nr_prefix[];                            // [words + 1] train items in front of word w
+    __shared__ int wave_total[NOISE_ROWS_THREADS / WAVE];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (row >= n_rows) return;
+    const int u = row_user ? row_user[row] : row;
+    const unsigned *brow = bits + (size_t)u * (size_t)words;
+    // scan in chunks of the block size: every thread takes one word per chunk
+    int carry = 0;
+    for (int w0 = 0; w0 < words; w0 += NOISE_ROWS_THREADS) {
+        const int w = w0 + tid;
+        const int c = w < words ? __popc(brow[w]) : 0;
+        int x = c;
+        #pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+        if (lane == WAVE - 1) wave_total[wv] = x;
+        __syncthreads();
+        int before = carry;
+        for (int i = 0; i < wv; i++) before += wave_total[i];
+        if (w < words) nr_prefix[w] = before + x - c;             // exclusive
+        int total = 0;
+        for (int i = 0; i < NOISE_ROWS_THREADS / WAVE; i++) total += wave_total[i];
+        carry += total;
+        __syncthreads();
+    }
+    const unsigned *d = draws + (size_t)row * (size_t)d_ld;
+    T *out = E + (size_t)row * (size_t)e_ld;
+    for (long long item = tid; item < e_ld; item += NOISE_ROWS_THREADS) {
+        T e = 0;
+        if (item < n) {
+            const int w = (int)(item >> 5), b = (int)(item & 31);
+            const unsigned word = brow[w];
+            if (!((word >> b) & 1u)) e = noise_from_draws<T>(d, item - (nr_prefix[w] + __popc(word & ((1u << b) - 1u))));
+        }
+        out[item] = e;
+    }
+}
+
 // tier 1 of the fp32 path: the users flagged in the first pass get rows (order irrelevant)
 __global__ void k_noise_assign_rows(int m, const int *flag, int *noise_row, int *row_user, int *counter)
 {

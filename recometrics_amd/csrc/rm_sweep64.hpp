@@ -155,8 +155,15 @@ void k_sweep64(Sweep64Args a)
     // user factors -> registers: [group][g][q][16 users][2 doubles].  Up to 128 factors (64 VGPRs) they stay resident
     // for the whole sweep; beyond that each 64-factor chunk is re-read from L2 when its turn comes.
     constexpr bool AF_RESIDENT = !NGT_RT && NGT <= 16;
+    // Streamed factor axis with an even, compile-time chunk count (256 and 512 factors): the user factors of a chunk arrive in two
+    // halves -- the first one was loaded a whole chunk ahead (two register sets in rotation), the second one is requested when the
+    // chunk begins and lands behind the first half's MFMAs (4 groups x 4 instructions x 64 cycles), so no matrix instruction waits
+    // for L2 any more (profiles/r2_pmc_sq_C5.json: 0.4 loads per MFMA, each chunk opened with an L2 round trip).  16 VGPRs more.
+    constexpr bool AF_HALF_AHEAD = !AF_RESIDENT && !NGT_RT && NGC == 8 && NC_CT % 2 == 0;
     constexpr int NAF = AF_RESIDENT ? NGT : NGC;
-    f64x2 af[NAF];
+    constexpr int HALF = NGC / 2;
+    f64x2 af[AF_HALF_AHEAD ? HALF : NAF];                        // half-ahead: the SECOND half of the current chunk
+    f64x2 afA[AF_HALF_AHEAD ? HALF : 1], afB[AF_HALF_AHEAD ? HALF : 1];      // first halves: current / next chunk, in rotation
     const f64x2 *af_src = a.Ap + ((size_t)(group_ok ? group : 0) * NGTV * 4 + q) * GU + ul;    // + g * 4 * GU
     if (AF_RESIDENT) {
         #pragma unroll
@@ -421,6 +428,10 @@ void k_sweep64(Sweep64Args a)
     LdsSyncPtr arrive = (LdsSyncPtr)(smem + a.sync_off) + sub;       // one domain per sub-tile: its four waves
     if (tid < 4) ((LdsSyncPtr)(smem + a.sync_off))[tid] = 0u;
     if (ntiles > 0) stage(t0, 0, 0);
+    if (AF_HALF_AHEAD) {                          // first half of chunk 0 (in front of the drain below: nothing is pending at the loop's entry)
+        #pragma unroll
+        for (int g = 0; g < HALF; g++) afA[g] = af_src[(size_t)g * 4 * GU];
+    }
     __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);      // builtin: the compiler's wait-count bookkeeping sees the drain
     __syncthreads();
     // shared K-th-best bound, read one tile ahead (drained by the closing wait); the seeded bound counts from the first tile on
@@ -429,6 +440,48 @@ void k_sweep64(Sweep64Args a)
         const unsigned long long thr_next = (primary && !DUMP) ? __hip_atomic_load(a.thr_shared + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         // resident user factors are indexed af[c * NGC + gl]: the chunk loop must then be unrolled; when each chunk's
         // factors are re-read the loop stays rolled (4x less code and register pressure at 256 factors)
+        if (AF_HALF_AHEAD) {
+            auto unit_body = [&](int c, f64x2 (&cur)[AF_HALF_AHEAD ? HALF : 1], f64x2 (&nxt)[AF_HALF_AHEAD ? HALF : 1]) __attribute__((always_inline)) {
+                const int unit = i * NC + c;
+                const int buf = unit & 1;
+                if (unit > 0) {
+                    const unsigned target = 4u * (unsigned)unit;
+                    while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+                }
+                // second half of this chunk first (it is needed 16 MFMAs from now), then the item tile of the next unit, then
+                // the first half of the next chunk (needed a whole chunk from now; after the last chunk: chunk 0 of the next tile)
+                #pragma unroll
+                for (int g = 0; g < HALF; g++) af[g] = af_src[(size_t)(c * NGC + HALF + g) * 4 * GU];
+                if (unit + 1 < nunits) {
+                    const int nu = unit + 1;
+                    stage(t0 + nu / NC, nu % NC, nu & 1);
+                }
+                const int cn = c + 1 == NC ? 0 : c + 1;
+                #pragma unroll
+                for (int g = 0; g < HALF; g++) nxt[g] = af_src[(size_t)(cn * NGC + g) * 4 * GU];
+                __builtin_amdgcn_sched_barrier(0);               // (all requests in flight before the first matrix instruction)
+                const f64x2 *bb = ldsB + buf * BUF_D2 + sub * NGC * 128 + q * 32 + ul;
+                if (c == 0) {
+                    #pragma unroll
+                    for (int r = 0; r < 4; r++) { clo[r] = 0.; chi[r] = 0.; }
+                }
+                #pragma unroll
+                for (int gl = 0; gl < NGC; gl++) {
+                    const f64x2 b0 = bb[gl * 128], b1 = bb[gl * 128 + 16];
+                    const f64x2 u = gl < HALF ? cur[gl < HALF ? gl : 0] : af[gl >= HALF ? gl - HALF : 0];
+                    clo = __builtin_amdgcn_mfma_f64_16x16x4f64(b0.x, u.x, clo, 0, 0, 0);
+                    chi = __builtin_amdgcn_mfma_f64_16x16x4f64(b1.x, u.x, chi, 0, 0, 0);
+                    clo = __builtin_amdgcn_mfma_f64_16x16x4f64(b0.y, u.y, clo, 0, 0, 0);
+                    chi = __builtin_amdgcn_mfma_f64_16x16x4f64(b1.y, u.y, chi, 0, 0, 0);
+                }
+                __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                          // arrive half: DMA share landed (and with it `nxt`)
+                if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"((unsigned)(__UINTPTR_TYPE__)arrive), "v"(1u) : "memory");
+                if (c == NC - 1) do_epi(clo, chi, t0 + i, thr_seen);
+            };
+            for (int c = 0; c < NC; c += 2) { unit_body(c, afA, afB); unit_body(c + 1, afB, afA); }
+            thr_seen = thr_next;
+            continue;
+        }
         #pragma unroll(AF_RESIDENT ? NC_CT : 1)
         for (int c = 0; c < NC; c++) {
             const int unit = i * NC + c;
