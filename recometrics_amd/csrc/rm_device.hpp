@@ -71,6 +71,7 @@ struct Plan {                                     // produced on device, read ba
     int nonfinite_b;                    // some factor of B is NaN / Inf
     int n_noise_flagged;                // fp32 + noise, first pass: users whose ranking the noise can change (rm_noise.hpp)
     int n_heavy;                        // evaluated users with more than HEAVY_NPOS test items (listed by k_classify)
+    int n_only_ndcg;                    // evaluated users whose train and test rows cover every item (no tables of positives)
     unsigned long long amax_a, amax_b;  // bit patterns of max|A|, max|B| as doubles (non-negative doubles order like u64)
 };
 

@@ -24,6 +24,7 @@ template <class T, class S> struct FinalArgs {     // T = real_t of inputs/outpu
     const int *flags, *user_nslots, *uslot_base, *slot_index;
     const int *gj; const long long *grow;
     const Entry<S> *pl; const PartialStat<S> *pst; const unsigned *hist; const S *pos_score;
+    const int *pos_item_tab;     // item ids of the tables of sorted positives (same shape as pos_score)
     AucPart *auc_part;           // [n_slots]
     T *heavy_topv;               // [m][min(K, FIN_TOPV)] largest test values (descending) of users with more than
     unsigned char *heavy_nan;    // [m]    ... HEAVY_NPOS test items, and whether any of their values is NaN (k_top_values)
@@ -106,6 +107,71 @@ __global__ void k_auc_slots(FinalArgs<T, S> a)
     }
     AucPart r; r.sum_ranks = sum_ranks; r.s1 = s1; r.s2 = s2; r.nvalid = nvalid; r.pad = 0;
     a.auc_part[slot] = r;
+}
+
+// ---- the users' own test items, when the sweep did not see them ---------------------------------------------------------
+// With dense train rows (small item counts) the rows mark the TEST items too (k_train_bits), so the sweep evaluates the
+// candidates that are NOT test items: no candidate ever meets its own entry in the table of sorted positives -- the exact tie
+// that three tiles out of four used to hold at 27k items, each one a trip through the tie rule (7 % of the sweep at BASELINE
+// C2).  This kernel puts the test items back, one thread per user (slot), before anything reads the sweep's results:
+//   * rank histogram: positive i (ascending (score, item desc) order = row i) outranks exactly the positives of the rows below
+//     it, so it counts in bin i like every other candidate with i positives below it;
+//   * validity statistics and top-K: the extra part `extra` of pst / pl = max / min / NaN of the test items' scores and their
+//     K best in (score desc, item asc) order; k_finalize merges parts, whoever wrote them.
+// Test items masked by the train row (+inf in the tables) are not candidates.  Only users with ONE slot reach this kernel
+// (table users with <= 63 test items and streamed users); the host keeps the old scheme when a call has chunked users.
+constexpr int MERGE_WAVES = 4;                            // slots per block of k_merge_positives (one wavefront each)
+template <class T, class S>
+__global__ __launch_bounds__(MERGE_WAVES * WAVE) void k_merge_positives(FinalArgs<T, S> a, unsigned *hist_rw, int extra)
+{
+    const int slot = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), lane = threadIdx.x & 63;
+    if (slot >= a.n_slots) return;
+    const int u = a.slot_user[slot];
+    const int K = a.K, NP = a.n_part;
+    Entry<S> *L = (Entry<S> *)a.pl + ((size_t)slot * NP + extra) * K;
+    S vmax = -(S)INFINITY, vmin = (S)INFINITY;
+    int has_nan = 0, filled = 0;                                    // `filled` is wave-uniform
+    if (!(a.flags[u] & UF_ONLY_NDCG)) {
+        const int te0 = a.test_p[u], npos = a.test_p[u + 1] - te0;
+        const bool streamed = slot >= a.stream_slot0;
+        const int g = slot / a.gu, ul = slot % a.gu;
+        const long long row0 = streamed ? 0 : (a.grow[g] + g) * a.gu + ul;
+        const long long stride = streamed ? 1 : a.gu;
+        const S *PS = streamed ? a.spos_score + te0 : a.pos_score + row0;
+        const int *PI = streamed ? a.spos_item + te0 : a.pos_item_tab + row0;
+        for (int top = npos - 1; top >= 0; top -= WAVE) {           // best rows first: lane 0 holds the best of the 64
+            const int i = top - lane;
+            const S x = i >= 0 ? PS[(long long)i * stride] : (S)INFINITY;
+            const bool masked = isinf(x) && x > 0;                  // masked by the train row (or beyond the row)
+            const bool isn = x != x;
+            const bool cand = !masked && !isn;
+            has_nan |= isn ? 1 : 0;
+            if (cand) {
+                vmax = x > vmax ? x : vmax;
+                vmin = x < vmin ? x : vmin;
+                if (streamed) { if (i >= 1) a.shist[te0 + i - 1] += 1u; }
+                else hist_rw[row0 + (long long)i * stride] += 1u;
+            }
+            if (filled < K) {                                       // (score desc, item asc) = descending row order
+                const unsigned long long mk = __ballot(cand);
+                const int pos = filled + __popcll(mk & ((1ull << lane) - 1ull));
+                if (cand && pos < K) { L[pos].s = x; L[pos].idx = PI[(long long)i * stride]; }
+                filled += __popcll(mk);
+            }
+        }
+    }
+    #pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const S om = __shfl_xor(vmax, d), on = __shfl_xor(vmin, d);
+        vmax = om > vmax ? om : vmax; vmin = on < vmin ? on : vmin;
+        has_nan |= __shfl_xor(has_nan, d);
+    }
+    for (int i = (filled < K ? filled : K) + lane; i < K; i += WAVE) { L[i].s = -(S)INFINITY; L[i].idx = IDX_EMPTY; }
+    if (lane == 0) {
+        PartialStat<S> ps;
+        ps.vmax = vmax; ps.vmin = vmin; ps.rocsum = 0; ps.has_nan = has_nan; ps.pad = 0;
+        ((PartialStat<S> *)a.pst)[(size_t)slot * NP + extra] = ps;
+    }
 }
 
 // ---- streamed users: ranks of the positives from the score row the sweep stored --------------------------------------

@@ -21,6 +21,7 @@ struct SweepArgs {
     // max(n_splits, tail_splits) is the split dimension of pl / pst (grid = (n_ublocks - tail_ublocks) * n_splits +
     // tail_ublocks * tail_splits)
     int tail_ublocks, tail_splits, part_splits;
+    int part_extra;                       // parts of pl / pst behind the sweep's own (1 = the user's test items, k_merge_positives)
     int jmax;                             // LDS sizing (all blocks)
     int list_in_lds;
     int check_nan;                        // 0 when the host proved all scores finite (skips the NaN scan)

@@ -101,6 +101,7 @@ struct Ctx {
     unsigned long long packed_tag = 0; int packed_tile = 0, packed_ng = 0; const void *packed_ptr = nullptr;
     const void *bits_ptr = nullptr; long long bits_words = 0; int bits_m = 0;      // dense train rows as last built (set_train_bits)
     unsigned long long bits_tag = 0; const int *bits_train_p = nullptr;             // ... by which call (Call::items_tag) and for which rows
+    bool bits_masked = false; const void *bits_pure_ptr = nullptr;                  // ... with the test items marked too; the train-only rows
     unsigned long long packed_amax_b = 0; int packed_nonfinite_b = 0;
 };
 std::mutex g_ctx_mu;
@@ -260,26 +261,37 @@ inline long long stream_budget_bytes(const Workspace &ws)
 // Dense train rows for the fp32 sweep when they are small (m * n / 8 bytes <= 1 GiB, e.g. 463 MB at BASELINE C2): with ~100
 // train items per user among 27k items, some lane of a wave has one in nearly every 32-item sub-tile, and the per-item walk of
 // the CSR cursor (compare, consume, reload, loop) was 9 % of the C2 sweep; one word per lane and tile replaces it.
-template <class C> inline void set_train_bits(SweepArgs &sa, Ctx &cx, const C &c, int m, int n, long long n_pad, hipStream_t stream)
+inline bool dense_rows_fit(int m, long long n_pad)
+{
+    const long long words = (n_pad + 31) / 32;
+    return (size_t)m * (size_t)words * 4 <= ((size_t)1 << 30) && words <= TRAIN_BITS_MAX_WORDS && !getenv("RM_DEBUG_NO_TRAIN_BITS");
+}
+// `mask_test`: the rows mark the users' TEST items as well (k_merge_positives puts them back after the sweep); `want_pure`: also
+// keep the rows of the train items alone (the tie noise of a later pass indexes its draws by them)
+template <class C> inline void set_train_bits(SweepArgs &sa, Ctx &cx, const C &c, int m, int n, long long n_pad, hipStream_t stream, bool mask_test, bool want_pure)
 {
     Workspace &ws = cx.ws;
     const long long words = (n_pad + 31) / 32;
     const size_t bytes = (size_t)m * (size_t)words * 4;
     sa.train_bits = nullptr; sa.train_words = 0;
-    if (bytes > ((size_t)1 << 30) || words > TRAIN_BITS_MAX_WORDS || getenv("RM_DEBUG_NO_TRAIN_BITS")) { cx.bits_tag = 0; return; }
+    if (!dense_rows_fit(m, n_pad)) { cx.bits_tag = 0; return; }
     unsigned *bits = (unsigned *)ws.get("train_bits", bytes);
+    unsigned *pure = (mask_test && want_pure) ? (unsigned *)ws.get("train_bits_pure", bytes) : nullptr;
     // (the exact second pass of the tie noise evaluates a subset of the same users: the rows of the first pass are still there)
-    const bool ready = c.same_train_rows && cx.bits_ptr == (const void *)bits && cx.bits_words == words && cx.bits_m == m;
+    const bool ready = c.same_train_rows && cx.bits_ptr == (const void *)bits && cx.bits_words == words && cx.bits_m == m && cx.bits_masked == mask_test;
     if (!ready) {
         const unsigned blocks = (unsigned)std::min<long long>(((long long)m + TRAIN_BITS_WAVES - 1) / TRAIN_BITS_WAVES, 256 * 8);
         hipLaunchKernelGGL(k_train_bits, dim3(blocks), dim3(TRAIN_BITS_WAVES * WAVE), sizeof(unsigned) * (size_t)TRAIN_BITS_WAVES * (size_t)words, stream,
-                           m, n, (int)words, c.train_p, c.train_i, bits);
+                           m, n, (int)words, c.train_p, c.train_i, mask_test ? c.test_p : nullptr, c.test_i, bits, pure);
+        cx.bits_pure_ptr = mask_test ? (const void *)pure : (const void *)bits;      // rows of the train items alone (null: none kept)
     }
-    cx.bits_ptr = (const void *)bits; cx.bits_words = words; cx.bits_m = m;
+    cx.bits_ptr = (const void *)bits; cx.bits_words = words; cx.bits_m = m; cx.bits_masked = mask_test;
     cx.bits_tag = c.items_tag; cx.bits_train_p = c.train_p;
     sa.train_bits = bits; sa.train_words = (int)words;
 }
-template <class C> inline void set_train_bits(Sweep64Args &, Ctx &, const C &, int, int, long long, hipStream_t) {}
+template <class C> inline void set_train_bits(Sweep64Args &, Ctx &, const C &, int, int, long long, hipStream_t, bool, bool) {}
+inline void set_part_extra(SweepArgs &sa, int extra) { sa.part_extra = extra; }
+inline void set_part_extra(Sweep64Args &, int) {}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // device pipeline (T = float: v_mfma_f32_32x32x2_f32 sweep; T = double: v_mfma_f64_16x16x4_f64 sweep)
@@ -457,7 +469,16 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         if (tail_ublocks == 0) tail_splits = 0;
     }
     const int part_splits = std::max(n_splits, tail_splits);
-    const int n_part = nsub * part_splits;
+    // fp32, small item counts (dense train rows), ROC / PR-AUC wanted: the rows mark the users' test items too, the sweep never
+    // meets a candidate that IS one of the user's positives (an exact tie, resolved by the tie rule three tiles out of four at
+    // 27k items), and k_merge_positives puts the test items back.  Not when a score can be non-finite (a test item masked by the
+    // train row is marked +inf in the tables), not with chunked long rows (more slots than users: their best positives are not in the primary slot),
+    // not beyond the lists (k_select_topk works on the stored rows).
+    const bool mask_test = std::is_same<T, float>::value && want_auc && !ext_topk && !check_nan && n_slots > 0 &&
+                           dense_rows_fit(m, (long long)tiles_total * tile_items) && hp.n_slots == hp.n_active && hp.n_only_ndcg == 0 &&
+                           nsub * part_splits + 1 <= MAX_PARTS && !getenv("RM_DEBUG_NO_TEST_MASK");
+    const int n_part = nsub * part_splits + (mask_test ? 1 : 0);
+    const int part_extra = mask_test ? 1 : 0;
     auto lds_need = [&](bool with_lists) { return lds_need_n(with_lists, nsub); };
     const bool list_in_lds = !ext_topk && lds_need(true) + SYNC_BYTES <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS");
     size_t lds_total = lds_need(list_in_lds);
@@ -545,6 +566,8 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
                 spos_item = (int *)ws.get("spos_item", sizeof(int) * nz);
                 shist = (unsigned *)ws.get("shist", sizeof(unsigned) * nz);
                 HIP_CHECK(hipMemsetAsync(shist, 0, sizeof(unsigned) * nz, stream));
+                // (+inf in every rank: entries that repeat an item -- a non-canonical CSR row -- share a rank and leave one unused)
+                hipLaunchKernelGGL(k_fill<T>, dim3(cdiv((long long)nz, 256)), dim3(256), 0, stream, spos_score, (T)INFINITY, (long long)nz);
                 pa.stream = 1; pa.spos_score = spos_score; pa.spos_item = spos_item;
                 const int nsc = hp.n_stream_chunks;
                 hipLaunchKernelGGL(k_pos_scores<T>, dim3(cdiv(nsc, POSS_WAVES)), dim3(POSS_WAVES * WAVE), 0, stream, pa, sc_user, sc_chunk, nsc);
@@ -577,7 +600,8 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         P::set_pending(sa, pend_cap, (int)pend_off);
         P::set_sync(sa, (int)sync_off);
         sa.stream_slot0 = stream_slot0; sa.stream_ld = stream_ld; sa.stream_scores = stream_scores;
-        set_train_bits(sa, cx, c, m, n, tiles_total * tile_items, stream);
+        set_train_bits(sa, cx, c, m, n, (long long)tiles_total * tile_items, stream, mask_test, c.noise_flag != nullptr);
+        set_part_extra(sa, part_extra);
         sa.noise_row = c.noise_row; sa.noise_row0 = c.noise_row0; sa.noise_E = c.noise_E; sa.noise_ld = c.noise_ld;
 
         HIP_CHECK(hipEventRecord(g_ev[1], stream));
@@ -631,7 +655,11 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     }
 
     // ---- finalize ----
-    fa.n_part = n_part; fa.pl = pl; fa.pst = pst; fa.hist = hist; fa.pos_score = pos_score;
+    fa.n_part = n_part; fa.pl = pl; fa.pst = pst; fa.hist = hist; fa.pos_score = pos_score; fa.pos_item_tab = pos_item;
+    if (mask_test) {
+        fa.stream_slot0 = stream_slot0; fa.spos_score = spos_score; fa.spos_item = spos_item; fa.shist = shist;
+        hipLaunchKernelGGL((k_merge_positives<T, T>), dim3(cdiv(n_slots, MERGE_WAVES)), dim3(MERGE_WAVES * WAVE), 0, stream, fa, hist, n_part - 1);
+    }
     hipLaunchKernelGGL((k_finalize_skipped<T, T>), dim3(cdiv(m, 256)), dim3(256), 0, stream, fa);
     if (fa.ndcg && hp.n_heavy > 0) {                            // ideal-DCG values of the users with very long test rows
         fa.heavy_topv = (T *)ws.get("heavy_topv", sizeof(T) * (size_t)m * std::min(K, FIN_TOPV));
@@ -701,10 +729,11 @@ void run_call(const Call<T> &c_in, hipStream_t stream, Ctx &cx)
         hipLaunchKernelGGL(k_mt_draws, dim3(cdiv(rows, MT_WAVES)), dim3(MT_WAVES * WAVE), 0, stream, row_user, rows, c0.seed, user0,
                            train_p, n, per, D, d_ld);
         // the dense train rows of this call's own first pass (fp32, small item counts), when they cover exactly these users
-        const bool dense = cx.bits_tag != 0 && cx.bits_tag == c0.items_tag && cx.bits_train_p == train_p && cx.bits_m == m && row_user != nullptr;
+        const bool dense = cx.bits_tag != 0 && cx.bits_tag == c0.items_tag && cx.bits_train_p == train_p && cx.bits_m == m && row_user != nullptr &&
+                           cx.bits_pure_ptr != nullptr;
         if (dense)
             hipLaunchKernelGGL(k_noise_rows_bits<T>, dim3(rows), dim3(NOISE_ROWS_THREADS), sizeof(int) * (size_t)(cx.bits_words + 1), stream, row_user, rows,
-                               (const unsigned *)cx.bits_ptr, (int)cx.bits_words, n, D, d_ld, E, e_ld);
+                               (const unsigned *)cx.bits_pure_ptr, (int)cx.bits_words, n, D, d_ld, E, e_ld);
         else
             hipLaunchKernelGGL(k_noise_rows<T>, dim3(cdiv((long long)rows * e_ld, 256)), dim3(256), 0, stream, row_user, rows, train_p, c0.train_i, n,
                                D, d_ld, E, e_ld);

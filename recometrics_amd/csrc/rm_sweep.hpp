@@ -83,6 +83,25 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
     unsigned at[16];                                           // address of row `base`
     constexpr int TOP = J >= 2 ? 2 : 0;                        // levels resolved from registers
     unsigned long long mk0, mk1, mk2;                          // lane masks in SGPR pairs, in rotation
+#ifdef RM_ABL_LUT
+    // timing model of a table-driven start (wrong results): 3 (4 at depth 6) vector instructions and one byte read per score
+    // stand in for all but the last ABL_LEVELS levels
+    constexpr int ABL_LEVELS = J >= 6 ? 3 : (J >= 4 ? 2 : J);
+    if (J >= 3) {
+        #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float x; unsigned qa, f;
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(x) : "v"(v[r]), "v"(piv_lo), "v"(piv_hi));
+            if (J >= 6) asm volatile("v_min_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(piv_root));
+            asm volatile("v_cvt_pk_u8_f32 %0, %1, 0, %2" : "=v"(qa) : "v"(x), "v"(pos_addr));
+            asm volatile("ds_read_u8 %0, %1" : "=v"(f) : "v"(qa));
+            at[r] = f;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        #pragma unroll
+        for (int r = 0; r < 16; r++) asm volatile("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(at[r]) : "v"(at[r] & 7u), "v"(pos_addr));
+    } else
+#endif
     if (TOP == 2) {
         constexpr unsigned Q = 128u << (J >= 2 ? J - 2 : 0);   // a quarter of the table
         const unsigned a1 = pos_addr | Q, a2 = pos_addr | (2 * Q), a3 = pos_addr | (3 * Q);
@@ -104,8 +123,13 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
         #pragma unroll
         for (int r = 0; r < 16; r++) at[r] = pos_addr;
     }
+#ifdef RM_ABL_LUT
+    constexpr int FIRST_ST = J >= 3 ? (1 << (ABL_LEVELS - 1)) : (J - TOP > 0 ? (1 << (J - TOP - 1)) : 0);
+#else
+    constexpr int FIRST_ST = J - TOP > 0 ? (1 << (J - TOP - 1)) : 0;
+#endif
     #pragma unroll
-    for (int st = (J - TOP > 0 ? (1 << (J - TOP - 1)) : 0); st >= 1; st >>= 1) {
+    for (int st = FIRST_ST; st >= 1; st >>= 1) {
         float pv[16];
         #pragma unroll
         for (int r = 0; r < 16; r++) pv[r] = *(LdsF32Ptr)(at[r] + (st - 1) * 128);
@@ -147,7 +171,11 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
     const float m0 = hw_absmin3(df[0], df[1], df[2]), m1 = hw_absmin3(df[3], df[4], df[5]), m2 = hw_absmin3(df[6], df[7], df[8]);
     const float m3 = hw_absmin3(df[9], df[10], df[11]), m4 = hw_absmin3(df[12], df[13], df[14]);
     const float dmin = hw_absmin3(hw_absmin3(m0, m1, m2), hw_absmin3(m3, m4, df[15]), df[15]);
+#ifdef RM_ABL_NOTIE
+    if (false) {
+#else
     if (__any(dmin == 0.f)) {
+#endif
         auto walk = [&](int r) {
             if (df[r] == 0.f) {
                 const int item = sb + mfma32_row(r, h);
@@ -805,7 +833,7 @@ void k_sweep(SweepArgs a)
 #endif
 
     // ---- write this wave's partial: top-K list, validity stats, AUC sum; flush the LDS histogram ----
-    const int n_part = a.part_splits * NSUB;
+    const int n_part = a.part_splits * NSUB + a.part_extra;
     const int part = split * NSUB + sub;
     {   // lanes u and u+32 hold two halves of the same user's stats
         const float omax = __shfl_xor(vmax, 32), omin = __shfl_xor(vmin, 32);

@@ -9,7 +9,7 @@ procs = []
 for spec in sys.argv[1:]:
     name, flags = spec.split("=", 1)
     obj = "scratch/libs/n3_%s.o" % name
-    procs.append((name, obj, subprocess.Popen([B._hipcc()] + B.FLAGS + flags.split(",") + ["-c", os.path.join(B.CSRC, "rm_sweep32_n3.hip"), "-o", obj])))
+    procs.append((name, obj, subprocess.Popen([B._hipcc()] + B.FLAGS + B.SWEEP_FLAGS + flags.split(",") + ["-c", os.path.join(B.CSRC, "rm_sweep32_n3.hip"), "-o", obj])))
 for name, obj, p in procs:
     assert p.wait() == 0, name
     subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-o", "scratch/libs/lib_abl_%s.so" % name, obj] + objs)

@@ -16,7 +16,7 @@ cd $R
 python3 - "$OUT" <<'PY'
 import csv, glob, json, sys, collections
 out = sys.argv[1]; res = {}
-for f in glob.glob("%s/p*/*/*counter_collection.csv" % out):
+for f in sorted(glob.glob("%s/p*/*/*counter_collection.csv" % out)):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(f)):
         if "k_sweep" in r["Kernel_Name"]:
