@@ -85,12 +85,15 @@ class DeviceProblem:
 def load_traffic(workload, users):
     """HBM bytes per sweep launch from the committed PMC run (scratch/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in
     separate rocprofv3 passes, FETCH_SIZE doubled per the gfx950 correction); None when no matching profile exists."""
-    path = os.path.join(ROOT, "profiles", "r2_traffic_%s.json" % workload)
-    try:
-        d = json.load(open(path))
-        return d["hbm_bytes"] if int(d.get("users", -1)) == int(users) else None
-    except Exception:      # noqa: BLE001
-        return None
+    for rnd in ("r3", "r2"):                                  # the newest committed profile of this workload and user count
+        path = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (rnd, workload))
+        try:
+            d = json.load(open(path))
+            if int(d.get("users", -1)) == int(users):
+                return d["hbm_bytes"]
+        except Exception:      # noqa: BLE001
+            pass
+    return None
 
 
 def stratified_users(host, n_users, seed=0):

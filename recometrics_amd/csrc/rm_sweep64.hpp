@@ -319,8 +319,19 @@ void k_sweep64(Sweep64Args a)
             #pragma unroll
             for (int r = 0; r < 8; r++) nanmask |= __ballot(v[r] != v[r]);
         }
-        #pragma unroll
-        for (int r = 0; r < 8; r++) { vmax = __builtin_fmax(vmax, v[r]); vmin = __builtin_fmin(vmin, v[r]); }
+        // (NaN-ignoring hardware max / min through asm: the generic fmax / fmin add a canonicalising v_max_f64 x, x, x per value,
+        // and an f64 vector instruction occupies the pipe twice as long as an f32 one)
+        {
+            double m01, m23, m45, m67, n01, n23, n45, n67;
+            asm("v_max_f64 %0, %1, %2" : "=v"(m01) : "v"(v[0]), "v"(v[1])); asm("v_max_f64 %0, %1, %2" : "=v"(m23) : "v"(v[2]), "v"(v[3]));
+            asm("v_max_f64 %0, %1, %2" : "=v"(m45) : "v"(v[4]), "v"(v[5])); asm("v_max_f64 %0, %1, %2" : "=v"(m67) : "v"(v[6]), "v"(v[7]));
+            asm("v_min_f64 %0, %1, %2" : "=v"(n01) : "v"(v[0]), "v"(v[1])); asm("v_min_f64 %0, %1, %2" : "=v"(n23) : "v"(v[2]), "v"(v[3]));
+            asm("v_min_f64 %0, %1, %2" : "=v"(n45) : "v"(v[4]), "v"(v[5])); asm("v_min_f64 %0, %1, %2" : "=v"(n67) : "v"(v[6]), "v"(v[7]));
+            asm("v_max_f64 %0, %1, %2" : "=v"(m01) : "v"(m01), "v"(m23)); asm("v_max_f64 %0, %1, %2" : "=v"(m45) : "v"(m45), "v"(m67));
+            asm("v_min_f64 %0, %1, %2" : "=v"(n01) : "v"(n01), "v"(n23)); asm("v_min_f64 %0, %1, %2" : "=v"(n45) : "v"(n45), "v"(n67));
+            asm("v_max_f64 %0, %1, %2" : "=v"(m01) : "v"(m01), "v"(m45)); asm("v_min_f64 %0, %1, %2" : "=v"(n01) : "v"(n01), "v"(n45));
+            asm("v_max_f64 %0, %1, %2" : "=v"(vmax) : "v"(vmax), "v"(m01)); asm("v_min_f64 %0, %1, %2" : "=v"(vmin) : "v"(vmin), "v"(n01));
+        }
         // tie noise (reference :531-534: added AFTER the validity scan, in real_t)
         if (a.noise_E && noise_lane) {
             #pragma unroll
