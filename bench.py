@@ -144,10 +144,16 @@ def parity_check(prob, out, n_users, noise=False, seed=1):
     start at 0 -- the noise check therefore uses the first users plus nothing else."""
     from oracle import oracle as orc
     host = prob.host
+    # a bounded amount of CPU work: the reference evaluates ~7e9 (item x factor) products per second on the box's cores
+    # (4,300 users/s at C2), so ~15 s allow 1e11 / (n k) users -- 2,048 at C2 and C3, ~800 at the north-star shape, ~90 at C4
+    n_users = int(max(64, min(n_users, 1.1e11 / (float(prob.n) * float(prob.k)))))
     users = np.arange(min(n_users, prob.m)) if noise else stratified_users(host, n_users)
     A, B, tr, te = sub_problem(host, users)
     impl, kind = (orc.Reference(), "reference") if orc.reference_available() else (orc.Oracle(), "port")
-    want = impl.calc(A, B, tr, te, prob.K, nthreads=min(256, os.cpu_count() or 1), noise=noise, seed=seed, dtype=prob.dtype)
+    # (the reference addresses its per-thread scratch as thread * n in int32, src/recometrics.hpp:499: at n = 10M more than 214
+    # threads overflow it)
+    nthreads = max(1, min(256, os.cpu_count() or 1, (2 ** 31 - 1) // int(B.shape[0])))
+    want = impl.calc(A, B, tr, te, prob.K, nthreads=nthreads, noise=noise, seed=seed, dtype=prob.dtype)
     got = out[:, torch_index(out, users)].cpu().numpy()
     info = {"users": int(users.shape[0]), "checker": kind, "streamed_users": int((np.diff(te[0]) > 63).sum()),
             "cold_users": int((np.diff(tr[0]) == 0).sum()), "sample": "first users" if noise else "stratified"}
@@ -210,7 +216,9 @@ def cpu_baseline(host, K, n_users_total, budget_s, dtype=np.float32):
         impl.calc(A[:nu], B, sub_tr, sub_te, K, nthreads=ncores, noise=False, dtype=dtype)
         return time.perf_counter() - t0
 
-    probe = min(n_users_total, max(ncores * 2, 64))
+    # (first sample sized for ~2 s at the rate the reference sustains on 256 threads, ~7e9 item x factor products per second: at
+    # n = 10M a fixed 2 x cores users would already take 100 s)
+    probe = int(min(n_users_total, max(8, min(max(ncores * 2, 64), 1.5e10 / (float(B.shape[0]) * float(B.shape[1]))))))
     run(min(probe, 32))                                    # page in
     t_probe = run(probe)
     nu = int(min(n_users_total, max(probe, probe * budget_s / max(t_probe, 1e-6))))

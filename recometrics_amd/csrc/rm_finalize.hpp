@@ -12,7 +12,7 @@ namespace rm {
 constexpr int MAX_PARTS = 128;
 constexpr int FIN_THREADS = 128;      // block size of k_finalize
 constexpr int FIN_TOPV = 64;          // sorted buffer of the largest test values (ideal DCG) per thread
-template <class T> inline size_t finalize_lds_bytes(int K, int n_part) { return (sizeof(T) * (size_t)(K < FIN_TOPV ? K : FIN_TOPV) + 2 * (size_t)n_part) * FIN_THREADS; }
+template <class T> inline size_t finalize_lds_bytes(int K, int n_part) { return (sizeof(T) * (size_t)(K < FIN_TOPV ? K : FIN_TOPV) + 4 * (size_t)n_part) * FIN_THREADS; }
 
 // per-slot result of the rank-histogram walk (k_auc_slots), combined per user by k_finalize
 struct AucPart { unsigned long long sum_ranks; double s1, s2; int nvalid, pad; };
@@ -540,12 +540,17 @@ __global__ void k_finalize(FinalArgs<T, S> a)
 
     // ---- merge the partial top-K lists (each descending) and the validity stats ----
     unsigned short *head = head_base + threadIdx.x;               // head[q * FIN_THREADS]: entries of partial list q consumed
+    unsigned short *alive = head_base + (size_t)NP * FIN_THREADS + threadIdx.x;     // alive[t * FIN_THREADS]: the parts that hold entries
     S vmax = -(S)INFINITY, vmin = (S)INFINITY; bool any_nan = false;
     const Entry<S> *PL = a.pl + (size_t)s0 * NP * K;
+    int n_alive = 0;
     for (int q = 0; q < NP; q++) {
         // a part without entries (the sub-tile waves that share a group's LDS list write it once; item ranges this user's
-        // block was not cut into) is exhausted from the start: the merge below never loads from it
-        head[q * FIN_THREADS] = (!a.ext_topk && PL[(size_t)q * K].idx == IDX_EMPTY) ? (unsigned short)K : (unsigned short)0;
+        // block was not cut into) is left out of the merge: with many item ranges (few users: the exact pass of the tie noise)
+        // two parts out of three are empty
+        const bool empty = !a.ext_topk && PL[(size_t)q * K].idx == IDX_EMPTY;
+        head[q * FIN_THREADS] = empty ? (unsigned short)K : (unsigned short)0;
+        if (!empty) alive[(n_alive++) * FIN_THREADS] = (unsigned short)q;
         const PartialStat<S> ps = a.pst[(size_t)s0 * NP + q];
         vmax = ps.vmax > vmax ? ps.vmax : vmax;
         vmin = ps.vmin < vmin ? ps.vmin : vmin;
@@ -553,7 +558,8 @@ __global__ void k_finalize(FinalArgs<T, S> a)
     }
     for (int i = 0; i < (a.ext_topk ? 0 : K); i++) {            // (ext_topk: k_select_topk has written M already)
         int best = -1; Entry<S> be; be.s = 0; be.idx = 0;
-        for (int q = 0; q < NP; q++) {
+        for (int t = 0; t < n_alive; t++) {
+            const int q = alive[t * FIN_THREADS];
             const int hq = head[q * FIN_THREADS];
             if (hq >= K) continue;
             const Entry<S> e = PL[(size_t)q * K + hq];

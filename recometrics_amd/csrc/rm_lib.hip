@@ -101,7 +101,7 @@ struct Ctx {
     unsigned long long packed_tag = 0; int packed_tile = 0, packed_ng = 0; const void *packed_ptr = nullptr;
     const void *bits_ptr = nullptr; long long bits_words = 0; int bits_m = 0;      // dense train rows as last built (set_train_bits)
     unsigned long long bits_tag = 0; const int *bits_train_p = nullptr;             // ... by which call (Call::items_tag) and for which rows
-    bool bits_masked = false; const void *bits_pure_ptr = nullptr;                  // ... with the test items marked too; the train-only rows
+    bool bits_masked = false;                                                       // ... with the test items marked too
     unsigned long long packed_amax_b = 0; int packed_nonfinite_b = 0;
 };
 std::mutex g_ctx_mu;
@@ -276,14 +276,14 @@ template <class C> inline void set_train_bits(SweepArgs &sa, Ctx &cx, const C &c
     sa.train_bits = nullptr; sa.train_words = 0;
     if (!dense_rows_fit(m, n_pad)) { cx.bits_tag = 0; return; }
     unsigned *bits = (unsigned *)ws.get("train_bits", bytes);
-    unsigned *pure = (mask_test && want_pure) ? (unsigned *)ws.get("train_bits_pure", bytes) : nullptr;
+    unsigned *pure = nullptr;                                      // (rm_noise.hpp clears the test items' bits in its own copy of a row)
+    (void)want_pure;
     // (the exact second pass of the tie noise evaluates a subset of the same users: the rows of the first pass are still there)
     const bool ready = c.same_train_rows && cx.bits_ptr == (const void *)bits && cx.bits_words == words && cx.bits_m == m && cx.bits_masked == mask_test;
     if (!ready) {
         const unsigned blocks = (unsigned)std::min<long long>(((long long)m + TRAIN_BITS_WAVES - 1) / TRAIN_BITS_WAVES, 256 * 8);
         hipLaunchKernelGGL(k_train_bits, dim3(blocks), dim3(TRAIN_BITS_WAVES * WAVE), sizeof(unsigned) * (size_t)TRAIN_BITS_WAVES * (size_t)words, stream,
                            m, n, (int)words, c.train_p, c.train_i, mask_test ? c.test_p : nullptr, c.test_i, bits, pure);
-        cx.bits_pure_ptr = mask_test ? (const void *)pure : (const void *)bits;      // rows of the train items alone (null: none kept)
     }
     cx.bits_ptr = (const void *)bits; cx.bits_words = words; cx.bits_m = m; cx.bits_masked = mask_test;
     cx.bits_tag = c.items_tag; cx.bits_train_p = c.train_p;
@@ -729,11 +729,11 @@ void run_call(const Call<T> &c_in, hipStream_t stream, Ctx &cx)
         hipLaunchKernelGGL(k_mt_draws, dim3(cdiv(rows, MT_WAVES)), dim3(MT_WAVES * WAVE), 0, stream, row_user, rows, c0.seed, user0,
                            train_p, n, per, D, d_ld);
         // the dense train rows of this call's own first pass (fp32, small item counts), when they cover exactly these users
-        const bool dense = cx.bits_tag != 0 && cx.bits_tag == c0.items_tag && cx.bits_train_p == train_p && cx.bits_m == m && row_user != nullptr &&
-                           cx.bits_pure_ptr != nullptr;
+        const bool dense = cx.bits_tag != 0 && cx.bits_tag == c0.items_tag && cx.bits_train_p == train_p && cx.bits_m == m && row_user != nullptr;
         if (dense)
-            hipLaunchKernelGGL(k_noise_rows_bits<T>, dim3(rows), dim3(NOISE_ROWS_THREADS), sizeof(int) * (size_t)(cx.bits_words + 1), stream, row_user, rows,
-                               (const unsigned *)cx.bits_pure_ptr, (int)cx.bits_words, n, D, d_ld, E, e_ld);
+            hipLaunchKernelGGL(k_noise_rows_bits<T>, dim3(rows), dim3(NOISE_ROWS_THREADS), sizeof(int) * (size_t)(2 * cx.bits_words + 1), stream, row_user, rows,
+                               (const unsigned *)cx.bits_ptr, (int)cx.bits_words, n, cx.bits_masked ? 1 : 0, train_p, c0.train_i, c0.test_p, c0.test_i,
+                               D, d_ld, E, e_ld);
         else
             hipLaunchKernelGGL(k_noise_rows<T>, dim3(cdiv((long long)rows * e_ld, 256)), dim3(256), 0, stream, row_user, rows, train_p, c0.train_i, n,
                                D, d_ld, E, e_ld);

@@ -124,21 +124,39 @@ __global__ void k_noise_rows(const int *row_user, int n_rows, const int *train_p
 // item's own word) -- no dependent walk through the CSR row per element (0.54 -> 0.1 ms for the 2,182 flagged users of
 // BASELINE C2).  words <= TRAIN_BITS_MAX_WORDS (rm_prep.hpp).
 constexpr int NOISE_ROWS_THREADS = 256;
+// `masked` != 0: the rows mark the users' test items too (k_train_bits with test rows); the copy of the row in LDS gets the bits
+// of the test items that are not train items cleared again -- the draws are indexed by the candidates, test items included.
 template <class T>
 __global__ __launch_bounds__(NOISE_ROWS_THREADS) void k_noise_rows_bits(const int *row_user, int n_rows, const unsigned *bits, int words, int n,
+                                                                        int masked, const int *train_p, const int *train_i, const int *test_p, const int *test_i,
                                                                         const unsigned *draws, long long d_ld, T *E, long long e_ld)
 {
-    extern __shared__ int nr_prefix[];                            // [words + 1] train items in front of word w
+    extern __shared__ int nr_lds[];                               // [words + 1] prefix counts, then [words] the row
     __shared__ int wave_total[NOISE_ROWS_THREADS / WAVE];
+    int *nr_prefix = nr_lds;
+    unsigned *lrow = (unsigned *)(nr_lds + words + 1);
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (row >= n_rows) return;
     const int u = row_user ? row_user[row] : row;
     const unsigned *brow = bits + (size_t)u * (size_t)words;
+    for (int w = tid; w < words; w += NOISE_ROWS_THREADS) lrow[w] = brow[w];
+    __syncthreads();
+    if (masked) {
+        const int *tr = train_i + train_p[u];
+        const int ntr = train_p[u + 1] - train_p[u];
+        for (int e = test_p[u] + tid; e < test_p[u + 1]; e += NOISE_ROWS_THREADS) {
+            const int item = test_i[e];
+            int lo = 0, hi = ntr;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (tr[mid] < item) lo = mid + 1; else hi = mid; }
+            if (!(lo < ntr && tr[lo] == item)) atomicAnd(&lrow[item >> 5], ~(1u << (item & 31)));
+        }
+        __syncthreads();
+    }
     // scan in chunks of the block size: every thread takes one word per chunk
     int carry = 0;
     for (int w0 = 0; w0 < words; w0 += NOISE_ROWS_THREADS) {
         const int w = w0 + tid;
-        const int c = w < words ? __popc(brow[w]) : 0;
+        const int c = w < words ? __popc(lrow[w]) : 0;
         int x = c;
         #pragma unroll
         for (int d = 1; d < WAVE; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
@@ -158,7 +176,7 @@ __global__ __launch_bounds__(NOISE_ROWS_THREADS) void k_noise_rows_bits(const in
         T e = 0;
         if (item < n) {
             const int w = (int)(item >> 5), b = (int)(item & 31);
-            const unsigned word = brow[w];
+            const unsigned word = lrow[w];
             if (!((word >> b) & 1u)) e = noise_from_draws<T>(d, item - (nr_prefix[w] + __popc(word & ((1u << b) - 1u))));
         }
         out[item] = e;
