@@ -84,6 +84,7 @@ struct Ctx {
     hipStream_t own_stream = nullptr;        // stream of a shard worker (multi-device calls)
     hipStream_t up_stream = nullptr;         // host-pointer calls: uploads of the NEXT user batch run beside the current batch's kernels
     hipEvent_t up_ev[2] = {nullptr, nullptr};
+    int *pinned_small = nullptr; hipEvent_t flags_ev = nullptr, pass_ev = nullptr;   // tie noise: flag count read-back, flags ready, exact pass done
     void *pinned = nullptr; size_t pinned_bytes = 0;   // page-locked staging for the metric block of a batch (one D2H copy instead of ten)
     void *pinned_get(size_t bytes)
     {
@@ -117,6 +118,18 @@ Ctx &context(int slot)
     if (!p) { p.reset(new Ctx()); p->device = dev; p->slot = slot; }
     return *p;
 }
+// the second context of a host-pointer call: its odd batches run there (own workspace, events, stream), so that a batch's
+// prep -- two dozen short launches and a plan read-back -- overlaps the sweep of the batch before it
+// (a third kind of context, NOISE_SLOT apart from its owner: the exact pass of the tie noise beside a first sweep -- also of a
+// batch that itself runs on a peer context)
+constexpr int PEER_SLOT = 1 << 12, NOISE_SLOT = 1 << 13;
+Ctx &peer_context(const Ctx &cx, int offset = PEER_SLOT)
+{
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    auto &p = g_ctx[std::make_pair(cx.device, cx.slot + offset)];
+    if (!p) { p.reset(new Ctx()); p->device = cx.device; p->slot = cx.slot + offset; }
+    return *p;
+}
 
 template <class T> struct Call {          // one calc_metrics call; every pointer is a DEVICE pointer
     const T *A; size_t lda; const T *B; size_t ldb;
@@ -139,6 +152,10 @@ template <class T> struct Call {          // one calc_metrics call; every pointe
     int *noise_flag;                               // optional [m] out (fp32 first pass): users the noise can change
     bool same_train_rows = false;                  // a later pass of the same call over the same users' rows: dense train rows may be reused
     long long eval_users = -1;                     // users this pass evaluates when fewer than m (only_users given); -1 = all m
+    // fp32 tie noise, first pass: right before the sweep is launched the flags set so far (users with a TEST item in the noise
+    // zone: all of them are known by then) are copied to `flag_snapshot`, their number to `*flag_count_host` (page-locked), and
+    // `flags_event` is recorded -- the exact pass of those users can start beside the sweep (run_call)
+    int *flag_snapshot = nullptr; int *flag_count_host = nullptr; hipEvent_t flags_event = nullptr;
 };
 
 inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
@@ -604,6 +621,11 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         set_part_extra(sa, part_extra);
         sa.noise_row = c.noise_row; sa.noise_row0 = c.noise_row0; sa.noise_E = c.noise_E; sa.noise_ld = c.noise_ld;
 
+        if (c.flag_snapshot) {
+            HIP_CHECK(hipMemcpyAsync(c.flag_snapshot, c.noise_flag, sizeof(int) * (size_t)m, hipMemcpyDeviceToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(c.flag_count_host, &plan->n_noise_flagged, sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipEventRecord(c.flags_event, stream));
+        }
         HIP_CHECK(hipEventRecord(g_ev[1], stream));
         // Depth split: when only the deepest user blocks force the lists out of LDS (the allocation is sized per launch,
         // the tables per block), the shallow blocks [0, u_split) get their own launch with LDS lists.  The two launches
@@ -649,6 +671,11 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         cx.timed_slots = n_slots;
         cx.total_slots = n_slots;
     } else {
+        if (c.flag_snapshot) {                                       // (no user to evaluate: nothing is flagged)
+            HIP_CHECK(hipMemsetAsync(c.flag_snapshot, 0, sizeof(int) * (size_t)m, stream));
+            *c.flag_count_host = 0;
+            HIP_CHECK(hipEventRecord(c.flags_event, stream));
+        }
         HIP_CHECK(hipEventRecord(g_ev[1], stream));
         HIP_CHECK(hipEventRecord(g_ev[2], stream));
         g_timings[4] = 0; g_timings[5] = 0; g_timings[6] = 0; g_timings[7] = 0;
@@ -723,9 +750,7 @@ void run_call(const Call<T> &c_in, hipStream_t stream, Ctx &cx)
     if (const char *e = getenv("RM_NOISE_BUDGET_MB")) budget = atoll(e) << 20;
     else budget = free_plus_owned(ws, {"noise_draws", "noise_rows"}) / 3;
     const long long cap = std::max<long long>(1, std::min<long long>(budget / row_bytes, 1 << 20));
-    auto make_rows = [&](const int *row_user, int rows, const int *train_p, long long user0, unsigned *&D, T *&E) {
-        D = (unsigned *)ws.get("noise_draws", sizeof(unsigned) * (size_t)rows * (size_t)d_ld);
-        E = (T *)ws.get("noise_rows", sizeof(T) * (size_t)rows * (size_t)e_ld);
+    auto make_rows_into = [&](const int *row_user, int rows, const int *train_p, long long user0, unsigned *D, T *E, hipStream_t stream) {
         hipLaunchKernelGGL(k_mt_draws, dim3(cdiv(rows, MT_WAVES)), dim3(MT_WAVES * WAVE), 0, stream, row_user, rows, c0.seed, user0,
                            train_p, n, per, D, d_ld);
         // the dense train rows of this call's own first pass (fp32, small item counts), when they cover exactly these users
@@ -737,6 +762,11 @@ void run_call(const Call<T> &c_in, hipStream_t stream, Ctx &cx)
         else
             hipLaunchKernelGGL(k_noise_rows<T>, dim3(cdiv((long long)rows * e_ld, 256)), dim3(256), 0, stream, row_user, rows, train_p, c0.train_i, n,
                                D, d_ld, E, e_ld);
+    };
+    auto make_rows = [&](const int *row_user, int rows, const int *train_p, long long user0, unsigned *&D, T *&E) {
+        D = (unsigned *)ws.get("noise_draws", sizeof(unsigned) * (size_t)rows * (size_t)d_ld);
+        E = (T *)ws.get("noise_rows", sizeof(T) * (size_t)rows * (size_t)e_ld);
+        make_rows_into(row_user, rows, train_p, user0, D, E, stream);
     };
     if (sizeof(T) == 8) {
         const long long width = c0.cumulative ? c0.K : 1;
@@ -758,19 +788,81 @@ void run_call(const Call<T> &c_in, hipStream_t stream, Ctx &cx)
     HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int) * (size_t)m, stream));
     Call<T> c1 = c0;
     c1.noise_flag = flag;
+    // Every user the noise can touch through a TEST item in the zone -- in practice all the flagged users -- is known once the
+    // positives are scored, before the first sweep starts: their exact pass (noise rows, a small sweep, two dozen short
+    // launches: 1.4 ms at BASELINE C2) runs on the PEER context and its stream BESIDE the first sweep, writes into buffers of its
+    // own, and a scatter behind both puts its results over the first pass's.  Users flagged only by the first pass's
+    // k_finalize (a top-K score in the zone) get the sequential exact pass below, as does everybody when the ranking outputs
+    // of rm_rank_* are wanted.
+    const bool beside = !c0.topk_idx && !c0.only_users && !getenv("RM_DEBUG_NOISE_SEQUENTIAL");
+    int *snap = nullptr;
+    if (beside) {
+        if (!cx.pinned_small) {
+            HIP_CHECK(hipHostMalloc((void **)&cx.pinned_small, 64, hipHostMallocDefault));
+            HIP_CHECK(hipEventCreateWithFlags(&cx.flags_ev, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&cx.pass_ev, hipEventDisableTiming));
+        }
+        snap = (int *)ws.get("noise_flag_snap", sizeof(int) * (size_t)m);
+        *cx.pinned_small = 0;
+        c1.flag_snapshot = snap; c1.flag_count_host = cx.pinned_small; c1.flags_event = cx.flags_ev;
+    }
     run<T>(c1, stream, cx);
     Plan *plan = (Plan *)ws.get("plan", sizeof(Plan));
+    int n_beside = 0;
+    std::unique_lock<std::mutex> peer_lock;
+    if (beside) {
+        HIP_CHECK(hipEventSynchronize(cx.flags_ev));                 // (early: the sweep has only just been launched)
+        const int n_early = *cx.pinned_small;
+        if (n_early > 0 && n_early <= cap) {
+            Ctx &pc = peer_context(cx, NOISE_SLOT);
+            peer_lock = std::unique_lock<std::mutex>(pc.mu);
+            if (!pc.own_stream) HIP_CHECK(hipStreamCreateWithFlags(&pc.own_stream, hipStreamNonBlocking));
+            hipStream_t ps = pc.own_stream;
+            Workspace &pw = pc.ws;
+            HIP_CHECK(hipStreamWaitEvent(ps, cx.flags_ev, 0));       // flags, their snapshot and the dense train rows are in place
+            int *noise_row = (int *)pw.get("noise_row", sizeof(int) * (size_t)m);
+            int *row_user = (int *)pw.get("noise_row_user", sizeof(int) * (size_t)n_early);
+            int *counter = (int *)pw.get("noise_counter", sizeof(int));
+            unsigned char *only = (unsigned char *)pw.get("noise_only", (size_t)m);
+            HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(int), ps));
+            hipLaunchKernelGGL(k_noise_assign_rows, dim3(cdiv(m, 256)), dim3(256), 0, ps, m, snap, (const int *)nullptr, noise_row, row_user, counter);
+            hipLaunchKernelGGL(k_noise_select, dim3(cdiv(m, 256)), dim3(256), 0, ps, m, noise_row, 0, n_early, only);
+            unsigned *D = (unsigned *)pw.get("noise_draws", sizeof(unsigned) * (size_t)n_early * (size_t)d_ld);
+            T *E = (T *)pw.get("noise_rows", sizeof(T) * (size_t)n_early * (size_t)e_ld);
+            make_rows_into(row_user, n_early, c0.train_p, c0.user0, D, E, ps);
+            Call<T> c = c0;
+            const long long width = c0.cumulative ? c0.K : 1;
+            static const char *tnames[10] = {"t_p", "t_tp", "t_r", "t_ap", "t_tap", "t_ndcg", "t_hit", "t_rr", "t_roc", "t_pr"};
+            ScatterArgs<T> sc{};
+            for (int i = 0; i < 10; i++) {
+                sc.width[i] = i >= 8 ? 1 : (int)width;
+                sc.dst[i] = c0.out[i];
+                c.out[i] = c0.out[i] ? (T *)pw.get(tnames[i], sizeof(T) * (size_t)m * (size_t)sc.width[i]) : nullptr;
+                sc.src[i] = c.out[i];
+            }
+            c.only_users = only; c.noise_row = noise_row; c.noise_row0 = 0; c.noise_E = E; c.noise_ld = e_ld; c.noise_flag = nullptr;
+            c.eval_users = n_early;
+            run<T>(c, ps, pc);
+            HIP_CHECK(hipEventRecord(cx.pass_ev, ps));
+            HIP_CHECK(hipStreamWaitEvent(stream, cx.pass_ev, 0));    // behind the first pass (stream order) AND the exact one
+            hipLaunchKernelGGL(k_noise_scatter<T>, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, snap, sc);
+            HIP_CHECK(hipEventRecord(cx.done, stream));              // (the context's "last work" now ends with the scatter)
+            n_beside = n_early;
+        }
+    }
     int n_flagged = 0;
     HIP_CHECK(hipMemcpyAsync(&n_flagged, &plan->n_noise_flagged, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     cx.timings[4] = 0;                                              // (reported below: users evaluated exactly)
+    n_flagged -= n_beside;                                          // what the first pass's k_finalize flagged on top (top-K in the zone)
     if (n_flagged <= 0) return;
     int *noise_row = (int *)ws.get("noise_row", sizeof(int) * (size_t)m);
     int *row_user = (int *)ws.get("noise_row_user", sizeof(int) * (size_t)n_flagged);
     int *counter = (int *)ws.get("noise_counter", sizeof(int));
     unsigned char *only = (unsigned char *)ws.get("noise_only", (size_t)m);
     HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(int), stream));
-    hipLaunchKernelGGL(k_noise_assign_rows, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, flag, noise_row, row_user, counter);
+    hipLaunchKernelGGL(k_noise_assign_rows, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, flag, n_beside > 0 ? (const int *)snap : (const int *)nullptr,
+                       noise_row, row_user, counter);
     for (long long r0 = 0; r0 < n_flagged; r0 += cap) {
         const int rows = (int)std::min<long long>(cap, n_flagged - r0);
         hipLaunchKernelGGL(k_noise_select, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, noise_row, (int)r0, (int)r0 + rows, only);
@@ -976,17 +1068,21 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
         const long long row = (((long long)n + 191) / 192 * 192) * (long long)sizeof(T);    // with a margin for what run() allocates first
         batch = std::max<long long>(1, std::min<long long>(batch, stream_budget_bytes(ws) * 3 / 4 / row));
     }
-    // batch boundaries: a first batch of a quarter of the users (whole kilo-users) when the range is large enough for the
-    // pipeline to matter -- its upload is the only one nothing hides, and every further batch costs ~0.4 ms of launches and a
-    // plan read-back (measured at BASELINE C2: profiles/r3_host_entry.txt) --, then batches of `batch` users
+    // batch boundaries: a first batch of an eighth of the users (whole kilo-users) when the range is large enough for the
+    // pipeline to matter -- its upload is the only one nothing hides --, then three times the batch before (its upload hides
+    // behind the batch before, whose kernels take ~2.5 x as long per user as the copy), at most `batch` users.  BASELINE C2:
+    // 17,408 + 52,224 + 68,861 users, 10.4 ms per call against 10.6 with (1/4, 3/4) and 11.7 without the second context
+    // (profiles/r3_host_entry.txt)
     std::vector<long long> cuts{0};
     {
-        long long next = (forced || m <= 16384) ? batch : std::min<long long>(batch, std::max<long long>(8192, ((long long)m / 4 + 1023) / 1024 * 1024));
+        const char *ramp = getenv("RM_DEBUG_RAMP");                 // A/B timing: another first fraction (default: an eighth)
+        const int r0 = ramp ? std::max(2, atoi(ramp)) : 8;
+        long long next = (forced || m <= 16384) ? batch : std::min<long long>(batch, std::max<long long>(8192, ((long long)m / r0 + 1023) / 1024 * 1024));
         while (cuts.back() < m) {
             long long b1 = std::min<long long>(m, cuts.back() + next);
             if (m - b1 < 2048 && m - cuts.back() <= batch) b1 = m;                  // no crumb at the end
             cuts.push_back(b1);
-            next = batch;
+            next = forced ? batch : std::min<long long>(batch, next * 3);
         }
     }
     const int n_batches = (int)cuts.size() - 1;
@@ -994,8 +1090,25 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     for (int bi = 0; bi < n_batches; bi++) mb_max = std::max(mb_max, cuts[bi + 1] - cuts[bi]);
     // the metric block of a batch: [metric][users of the batch x width], one device buffer, one D2H copy into page-locked
     // staging, scattered into the caller's arrays by the host (ten pageable copies cost 35-140 us EACH in host time)
-    T *dblock = (T *)ws.get("o_block", sizeof(T) * std::max<size_t>(out_w * (size_t)mb_max, 1));
-    T *hblock = out_w ? (T *)cx.pinned_get(sizeof(T) * out_w * (size_t)mb_max) : nullptr;
+    // Batches alternate between this context and its peer (own workspace, events and stream): batch i + 1 is planned and
+    // packed while batch i sweeps, and its sweep takes over the compute units as batch i's blocks drain.
+    Ctx *ctxs[2] = {&cx, &cx};
+    hipStream_t streams[2] = {stream, stream};
+    std::unique_lock<std::mutex> peer_lock;
+    if (n_batches > 1 && !getenv("RM_DEBUG_ONE_CONTEXT")) {
+        Ctx &pc = peer_context(cx);
+        peer_lock = std::unique_lock<std::mutex>(pc.mu);
+        if (!pc.own_stream) HIP_CHECK(hipStreamCreateWithFlags(&pc.own_stream, hipStreamNonBlocking));
+        if (cx.ev_valid) HIP_CHECK(hipStreamWaitEvent(pc.own_stream, cx.done, 0));       // (buffers of the range may still be read by an earlier call)
+        ctxs[1] = &pc; streams[1] = pc.own_stream;
+    }
+    T *dblocks[2], *hblocks[2];
+    for (int i = 0; i < 2; i++) {
+        if (i == 1 && ctxs[1] == ctxs[0]) { dblocks[1] = dblocks[0]; hblocks[1] = hblocks[0]; break; }
+        dblocks[i] = (T *)ctxs[i]->ws.get("o_block", sizeof(T) * std::max<size_t>(out_w * (size_t)mb_max, 1));
+        hblocks[i] = out_w ? (T *)ctxs[i]->pinned_get(sizeof(T) * out_w * (size_t)mb_max) : nullptr;
+    }
+    const bool two_ctx = ctxs[1] != ctxs[0];
     auto upload_users = [&](int bi) {                                 // rows [cuts[bi], cuts[bi + 1]) into their places, on `up`
         const long long b0 = cuts[bi], b1 = cuts[bi + 1];
         if (h.lda == (size_t)k) HIP_CHECK(hipMemcpyAsync(dA + (size_t)b0 * k, h.A + ((size_t)u0 + b0) * k, sizeof(T) * (size_t)(b1 - b0) * k, hipMemcpyHostToDevice, up));
@@ -1016,52 +1129,74 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     if (!shared || shard == 0) { upload_items(); stamp("items enqueued"); upload_users(0); }
     else { upload_users(0); upload_items(); HIP_CHECK(hipEventRecord(cx.up_ev[0], up)); }
     stamp("batch 0 rows enqueued");
+    struct InFlight { bool on = false; long long b0 = 0; int mb = 0; size_t boff[10]; size_t bo = 0; int which = 0; } fl[2];
+    auto finish = [&](int which) {                                    // wait for the batch in flight on context `which`, hand its outputs over
+        InFlight &f = fl[which];
+        if (!f.on) return;
+        f.on = false;
+        HIP_CHECK(hipStreamSynchronize(streams[which]));
+        stamp("batch done");
+        for (int i = 0; i < 10; i++) {
+            const size_t w = i >= 8 ? 1 : per;
+            if (h.outs[i]) std::memcpy(h.outs[i] + ((size_t)u0 + f.b0) * w, hblocks[which] + f.boff[i], sizeof(T) * (size_t)f.mb * w);
+        }
+        stamp("outputs scattered");
+        if (n_batches > 1) {                                          // more than one batch: add up the stage timings
+            Ctx &c = *ctxs[which];
+            float ta = 0, tb = 0, tc = 0, td = 0;
+            (void)hipEventElapsedTime(&ta, c.ev[0], c.ev[1]); (void)hipEventElapsedTime(&tb, c.ev[1], c.ev[2]);
+            (void)hipEventElapsedTime(&tc, c.ev[2], c.ev[3]); (void)hipEventElapsedTime(&td, c.ev[0], c.ev[3]);
+            cx.acc[0] += ta; cx.acc[1] += tb; cx.acc[2] += tc; cx.acc[3] += td;
+            c.ev_recorded = false; cx.ev_recorded = false;
+        }
+    };
+    try {
     for (int bi = 0; bi < n_batches; bi++) {
         const long long b0 = cuts[bi];
         const int b1 = (int)cuts[bi + 1], mb = b1 - (int)b0;
         if (g_interrupt) break;                                      // reference :488-489: the remaining users are skipped
-        HIP_CHECK(hipStreamWaitEvent(stream, cx.up_ev[bi & 1], 0));
+        const int which = two_ctx ? (bi & 1) : 0;
+        Ctx &bc = *ctxs[which];
+        hipStream_t bs = streams[which];
+        finish(which);                                               // (the batch two back: its context and staging are free again)
+        HIP_CHECK(hipStreamWaitEvent(bs, cx.up_ev[bi & 1], 0));
         Call<T> c{};
         c.A = dA + (size_t)b0 * k; c.lda = k; c.B = dB; c.ldb = k; c.m = mb; c.n = n; c.k = k;
         c.train_p = dtrp + b0; c.train_i = dtri; c.nnz_train = nnz_tr;
         c.test_p = dtep + b0; c.test_i = dtei; c.test_v = dtev; c.nnz_test = nnz_te;
         c.K = K; c.cumulative = h.cumulative; c.noise = h.noise; c.cold = h.cold; c.min_items_pool = h.mip; c.min_pos_test = h.mpt;
-        size_t boff[10], bo = 0;
-        for (int i = 0; i < 10; i++) { boff[i] = bo; c.out[i] = h.outs[i] ? dblock + bo : nullptr; if (h.outs[i]) bo += (size_t)mb * (i >= 8 ? 1 : per); }
+        InFlight &f = fl[which];
+        f.b0 = b0; f.mb = mb; f.bo = 0; f.which = which;
+        for (int i = 0; i < 10; i++) { f.boff[i] = f.bo; c.out[i] = h.outs[i] ? dblocks[which] + f.bo : nullptr; if (h.outs[i]) f.bo += (size_t)mb * (i >= 8 ? 1 : per); }
         if (h.topk_idx) {
             c.topk_idx = d_topk_idx + (size_t)b0 * K; c.topk_score = d_topk_score + (size_t)b0 * K;
             c.pos_rank = d_pos_rank; c.status = d_status + b0;
         }
         c.items_tag = tag;
         c.seed = h.seed; c.user0 = (long long)u0 + b0;
-        run_call<T>(c, stream, cx);                                  // enqueued (one short plan read-back inside)
+        run_call<T>(c, bs, bc);                                      // enqueued (one short plan read-back inside)
+        f.on = true;
         stamp("batch enqueued");
+        if (f.bo) HIP_CHECK(hipMemcpyAsync(hblocks[which], dblocks[which], sizeof(T) * f.bo, hipMemcpyDeviceToHost, bs));
+        if (h.topk_idx) {
+            HIP_CHECK(hipMemcpyAsync(h.topk_idx + ((size_t)u0 + b0) * K, c.topk_idx, sizeof(int) * (size_t)mb * K, hipMemcpyDeviceToHost, bs));
+            HIP_CHECK(hipMemcpyAsync(h.topk_score + ((size_t)u0 + b0) * K, c.topk_score, sizeof(T) * (size_t)mb * K, hipMemcpyDeviceToHost, bs));
+            HIP_CHECK(hipMemcpyAsync(h.status + u0 + b0, c.status, sizeof(int) * (size_t)mb, hipMemcpyDeviceToHost, bs));
+            const long long e0 = tep[b0], e1 = tep[b1];             // this batch's test entries (range-relative)
+            if (e1 > e0) HIP_CHECK(hipMemcpyAsync(h.pos_rank + te0 + e0, c.pos_rank + e0, sizeof(long long) * (size_t)(e1 - e0), hipMemcpyDeviceToHost, bs));
+        }
         // the next batch's rows travel while this batch's sweep runs (the copies below block the host, not the device)
         if (bi + 1 < n_batches && !g_interrupt) upload_users(bi + 1);
         stamp("next rows enqueued");
-        if (bo) HIP_CHECK(hipMemcpyAsync(hblock, dblock, sizeof(T) * bo, hipMemcpyDeviceToHost, stream));
-        if (h.topk_idx) {
-            HIP_CHECK(hipMemcpyAsync(h.topk_idx + ((size_t)u0 + b0) * K, c.topk_idx, sizeof(int) * (size_t)mb * K, hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipMemcpyAsync(h.topk_score + ((size_t)u0 + b0) * K, c.topk_score, sizeof(T) * (size_t)mb * K, hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipMemcpyAsync(h.status + u0 + b0, c.status, sizeof(int) * (size_t)mb, hipMemcpyDeviceToHost, stream));
-            const long long e0 = tep[b0], e1 = tep[b1];             // this batch's test entries (range-relative)
-            if (e1 > e0) HIP_CHECK(hipMemcpyAsync(h.pos_rank + te0 + e0, c.pos_rank + e0, sizeof(long long) * (size_t)(e1 - e0), hipMemcpyDeviceToHost, stream));
-        }
-        HIP_CHECK(hipStreamSynchronize(stream));
-        stamp("batch done");
-        for (int i = 0; i < 10; i++) {
-            const size_t w = i >= 8 ? 1 : per;
-            if (h.outs[i]) std::memcpy(h.outs[i] + ((size_t)u0 + b0) * w, hblock + boff[i], sizeof(T) * (size_t)mb * w);
-        }
-        stamp("outputs scattered");
-        if (n_batches > 1) {                                          // more than one batch: add up the stage timings
-            float ta = 0, tb = 0, tc = 0, td = 0;
-            (void)hipEventElapsedTime(&ta, cx.ev[0], cx.ev[1]); (void)hipEventElapsedTime(&tb, cx.ev[1], cx.ev[2]);
-            (void)hipEventElapsedTime(&tc, cx.ev[2], cx.ev[3]); (void)hipEventElapsedTime(&td, cx.ev[0], cx.ev[3]);
-            cx.acc[0] += ta; cx.acc[1] += tb; cx.acc[2] += tc; cx.acc[3] += td;
-            cx.ev_recorded = false;
-        }
+        if (!two_ctx) finish(which);
     }
+    } catch (...) {
+        for (int i = 0; i < 2; i++) (void)hipStreamSynchronize(streams[i]);      // nothing may still write into staging that goes away
+        (void)hipStreamSynchronize(up);
+        throw;
+    }
+    finish(0); finish(1);
+    g_last_ctx = &cx;
     HIP_CHECK(hipStreamSynchronize(up));                              // `rb` and the caller's arrays go out of use (also after an interrupt)
     if (trace) {
         std::string line = "rm host trace (" + std::to_string(n_batches) + " batches, ms):";

@@ -184,13 +184,28 @@ __global__ __launch_bounds__(NOISE_ROWS_THREADS) void k_noise_rows_bits(const in
 }
 
 // tier 1 of the fp32 path: the users flagged in the first pass get rows (order irrelevant)
-__global__ void k_noise_assign_rows(int m, const int *flag, int *noise_row, int *row_user, int *counter)
+// (`skip`, optional: users that have been evaluated exactly already -- the exact pass beside the first sweep)
+__global__ void k_noise_assign_rows(int m, const int *flag, const int *skip, int *noise_row, int *row_user, int *counter)
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= m) return;
     int r = -1;
-    if (flag[u]) { r = atomicAdd(counter, 1); row_user[r] = u; }
+    if (flag[u] && !(skip && skip[u])) { r = atomicAdd(counter, 1); row_user[r] = u; }
     noise_row[u] = r;
+}
+// results of the exact pass that ran beside the first sweep (into buffers of its own) -> the caller's outputs, for its users
+template <class T> struct ScatterArgs { const T *src[10]; T *dst[10]; int width[10]; };
+template <class T>
+__global__ void k_noise_scatter(int m, const int *picked, ScatterArgs<T> a)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= m || !picked[u]) return;
+    #pragma unroll
+    for (int i = 0; i < 10; i++) {
+        if (!a.dst[i]) continue;
+        const size_t o = (size_t)u * a.width[i];
+        for (int j = 0; j < a.width[i]; j++) a.dst[i][o + j] = a.src[i][o + j];
+    }
 }
 __global__ void k_noise_select(int m, const int *noise_row, int r0, int r1, unsigned char *only)
 {

@@ -309,7 +309,7 @@ def test_pipelined_uploads_equal_one_batch(hip, monkeypatch):
     batch i computes); every output equals the single-batch call bit for bit, also with the API-default tie noise and through
     rm_rank_*"""
     from recometrics_amd.synth import make_problem
-    pr = make_problem(40000, 1200, 16, np.float32, mean_c=30, seed=15)     # > 16,384 users: ramp 8192, 16384, 15424
+    pr = make_problem(40000, 1200, 16, np.float32, mean_c=30, seed=15)     # > 16,384 users: 8,192 + 24,576 + 7,232, alternating between two contexts
     trp, tri = pr["train"]; tep, tei, tev = pr["test"]
     for noise in (False, True):
         got = hip.calc_metrics(pr["A"], 16, pr["B"], 16, trp, tri, tep, tei, tev, 5, ALL, False, noise, True, 2, 1, 1, 3)
