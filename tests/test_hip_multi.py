@@ -323,3 +323,27 @@ def test_pipelined_uploads_equal_one_batch(hip, monkeypatch):
     rk1 = hip.rank(pr["A"], pr["B"], trp, tri, tep, tei, 5)
     for key in rk:
         assert (rk[key] == rk1[key]).all() or key == "topk_score", key
+
+
+@pytest.mark.parametrize("env", [{"RM_DEBUG_NOISE_SEQUENTIAL": "1"}, {"RM_DEBUG_ONE_CONTEXT": "1"}, {"RM_DEBUG_NO_TEST_MASK": "1"}, {}])
+def test_noise_and_batch_pipelines_agree(hip, env, monkeypatch):
+    """the API default (tie noise on) through the host entry with > 16,384 users: the exact pass of the flagged users beside the
+    first sweep on a peer context, batches alternating between two contexts, test items masked by the dense rows -- against
+    the sequential exact pass, one context, the round-2 dense rows: bit for bit"""
+    from recometrics_amd.synth import make_problem
+    pr = make_problem(20000, 900, 12, np.float32, mean_c=40, seed=23)
+    pr["B"] = pr["B"].copy()
+    pr["B"][np.random.default_rng(4).random(900) < 0.05] = 0               # zero scores: users the noise reorders
+    trp, tri = pr["train"]; tep, tei, tev = pr["test"]
+
+    def call():
+        return hip.calc_metrics(pr["A"], 12, pr["B"], 12, trp, tri, tep, tei, tev, 8, ALL, True, True, True, 2, 1, 1, 2 ** 34 + 1)
+    monkeypatch.setenv("RM_DEBUG_NOISE_SEQUENTIAL", "1"); monkeypatch.setenv("RM_DEBUG_ONE_CONTEXT", "1"); monkeypatch.setenv("RM_DEBUG_NO_TEST_MASK", "1")
+    want = call()
+    for key in ("RM_DEBUG_NOISE_SEQUENTIAL", "RM_DEBUG_ONE_CONTEXT", "RM_DEBUG_NO_TEST_MASK"):
+        monkeypatch.delenv(key)
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    got = call()
+    for name, g, w in zip(hip.METRIC_ORDER, got, want):
+        assert_same_bits(g, w, "%s under %s" % (name, env))
