@@ -40,6 +40,7 @@ def parse():
                     help="N > 1: weak = every GPU evaluates a full-size shard; strong = the workload's users are split over the GPUs")
     ap.add_argument("--parity-users", type=int, default=2048, help="users of the timed outputs compared with the reference (0 = skip)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-pointer (PCIe-inclusive) measurement")
+    ap.add_argument("--e2e-child", action="store_true", help=argparse.SUPPRESS)      # internal: the host-pointer leg in a process of its own
     return ap.parse_args()
 
 
@@ -57,16 +58,23 @@ def respawn_under_torchrun(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+def host_problem(m, n, k, mean_c, seed, dtype=np.float32, shard=0):
+    """The synthetic workload as host arrays (the same for the device-resident problem and for the host-pointer leg)."""
+    from recometrics_amd.synth import make_factors, make_interactions
+    _, B = make_factors(1, n, k, dtype, seed)                            # item factors: the same replica on every rank
+    A, _ = make_factors(m, 1, k, dtype, seed + 1 + 1000 * shard)         # this rank's user shard
+    trp, tri, tep, tei, tev = make_interactions(m, n, mean_c, dtype, seed + 1000 * shard)
+    return dict(A=A, B=B, train=(trp, tri), test=(tep, tei, tev))
+
+
 class DeviceProblem:
     """Synthetic workload resident in HBM (torch tensors are only the memory owner; the hot path gets raw pointers)."""
 
     def __init__(self, torch, dev, m, n, k, mean_c, seed, K, dtype=np.float32, shard=0):
-        from recometrics_amd.synth import make_factors, make_interactions
         self.m, self.n, self.k, self.K, self.dtype = m, n, k, K, dtype
-        _, B = make_factors(1, n, k, dtype, seed)                        # item factors: the same replica on every rank
-        A, _ = make_factors(m, 1, k, dtype, seed + 1 + 1000 * shard)     # this rank's user shard
-        trp, tri, tep, tei, tev = make_interactions(m, n, mean_c, dtype, seed + 1000 * shard)
-        self.host = dict(A=A, B=B, train=(trp, tri), test=(tep, tei, tev))
+        self.host = host_problem(m, n, k, mean_c, seed, dtype, shard)
+        A, B = self.host["A"], self.host["B"]
+        (trp, tri), (tep, tei, tev) = self.host["train"], self.host["test"]
         t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
         self.A, self.B = t(A), t(B)
         self.trp, self.tri, self.tep, self.tei, self.tev = t(trp), t(tri if tri.size else np.zeros(1, np.int32)), t(tep), t(tei), t(tev)
@@ -174,24 +182,51 @@ def torch_index(out, users):
     return torch.from_numpy(users.astype(np.int64)).to(out.device)
 
 
-def e2e_host(binding, prob, reps=3):
+def e2e_host_measure(binding, host, k, K, dtype, reps=5):
     """host arrays in -> host arrays out through rm_calc_metrics_* (H2D of A/B/CSR, device work, D2H
     of the metric block), first call (workspace allocation) and steady state (median)."""
-    h = prob.host
-    trp, tri = h["train"]
-    tep, tei, tev = h["test"]
+    trp, tri = host["train"]
+    tep, tei, tev = host["test"]
     want = {name: True for name in binding.METRIC_ORDER}
+    m = host["A"].shape[0]
 
     def call():
         t0 = time.perf_counter()
-        binding.calc_metrics(h["A"], prob.k, h["B"], prob.k, trp, tri if tri.size else np.zeros(1, np.int32), tep, tei, tev,
-                             prob.K, want, False, False, True, 2, 1, 1, 1)
+        binding.calc_metrics(host["A"], k, host["B"], k, trp, tri if tri.size else np.zeros(1, np.int32), tep, tei, tev,
+                             K, want, False, False, True, 2, 1, 1, 1)
         return (time.perf_counter() - t0) * 1e3
     first = call()
     rest = sorted(call() for _ in range(reps))
     steady = rest[len(rest) // 2]
-    return {"first_call_ms": first, "steady_ms": steady, "users_per_s": prob.m / (steady * 1e-3),
-            "what": "rm_calc_metrics_%s: host pointers in, host pointers out (PCIe-inclusive); never `value`" % ("f32" if prob.dtype == np.float32 else "f64")}
+    return {"first_call_ms": first, "steady_ms": steady, "users_per_s": m / (steady * 1e-3),
+            "what": "rm_calc_metrics_%s: host pointers in, host pointers out (PCIe-inclusive), in a process of its own WITHOUT torch -- as the "
+                    "Cython / Rcpp wrappers would call it (torch's bundled HIP runtime moves pageable memory 3-4x slower than the system's); "
+                    "never `value`" % ("f32" if dtype == np.float32 else "f64")}
+
+
+def e2e_child_main(args):
+    """`bench.py --e2e-child`: the host-pointer leg alone, no torch in the process; prints one JSON object."""
+    from recometrics_amd import _binding as binding
+    from recometrics_amd.synth import CONFIGS
+    m, n, k, dtype, K, mean_c, seed = CONFIGS[args.workload]
+    if args.workload == "C3":
+        m = m // 8
+    if args.users:
+        m = args.users
+    binding.load()
+    host = host_problem(m, n, k, mean_c, seed, dtype)
+    print(json.dumps(e2e_host_measure(binding, host, k, K, dtype)))
+
+
+def e2e_host(args, m):
+    """Runs the host-pointer leg as a child process (started from this one, which keeps running: never an exec)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--e2e-child", "--workload", args.workload, "--users", str(m)]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    if res.returncode != 0 or not lines:
+        return {"error": "child failed (%d): %s" % (res.returncode, res.stderr[-400:])}
+    return json.loads(lines[-1])
 
 
 def cpu_baseline(host, K, n_users_total, budget_s, dtype=np.float32):
@@ -286,6 +321,9 @@ def measure(torch, dist, binding, prob, steps, warmup, world, gather_buf):
 
 def main():
     args = parse()
+    if args.e2e_child:                                       # (before torch is imported: that is the point)
+        e2e_child_main(args)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(args)
     import torch
@@ -369,7 +407,7 @@ def main():
         failed = not pc["ok"]
     if rank == 0 and world == 1 and not args.no_e2e:
         try:
-            line["e2e_host"] = e2e_host(binding, prob)
+            line["e2e_host"] = e2e_host(args, m)
         except Exception as e:      # noqa: BLE001
             line["e2e_host"] = {"error": repr(e)}
 
