@@ -417,14 +417,16 @@ def main():
         try:
             stream = torch.cuda.current_stream().cuda_stream
             scratch_out = torch.empty_like(prob.out)
-            prob.step(binding, stream, scratch_out, noise=True)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
+            for _ in range(2):
                 prob.step(binding, stream, scratch_out, noise=True)
             torch.cuda.synchronize()
-            dtn = (time.perf_counter() - t0) / 3
+            t0 = time.perf_counter()
+            for _ in range(10):
+                prob.step(binding, stream, scratch_out, noise=True)
+            torch.cuda.synchronize()
+            dtn = (time.perf_counter() - t0) / 10
             line["noise_on"] = {"users_per_s": m / dtn, "ms_per_step": dtn * 1e3,
+                                "steps": 10, "warmup": 2,
                                 "what": "same workload with break_ties_with_noise=True (the API default), seed 1; never `value`"}
             if args.parity_users > 0:
                 line["noise_on"]["parity"] = parity_check(prob, scratch_out, min(args.parity_users, 1024), noise=True, seed=1)

@@ -156,6 +156,9 @@ template <class T> struct Call {          // one calc_metrics call; every pointe
     // zone: all of them are known by then) are copied to `flag_snapshot`, their number to `*flag_count_host` (page-locked), and
     // `flags_event` is recorded -- the exact pass of those users can start beside the sweep (run_call)
     int *flag_snapshot = nullptr; int *flag_count_host = nullptr; hipEvent_t flags_event = nullptr;
+    // dense train rows built by another pass of the same call over the same users (the exact noise pass beside the first sweep
+    // reads the first pass's rows instead of building 463 MB of its own at BASELINE C2)
+    const unsigned *ext_bits = nullptr; long long ext_words = 0; bool ext_masked = false;
 };
 
 inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
@@ -309,6 +312,8 @@ template <class C> inline void set_train_bits(SweepArgs &sa, Ctx &cx, const C &c
 template <class C> inline void set_train_bits(Sweep64Args &, Ctx &, const C &, int, int, long long, hipStream_t, bool, bool) {}
 inline void set_part_extra(SweepArgs &sa, int extra) { sa.part_extra = extra; }
 inline void set_part_extra(Sweep64Args &, int) {}
+inline void set_ext_bits(SweepArgs &sa, const unsigned *bits, int words) { sa.train_bits = bits; sa.train_words = words; }
+inline void set_ext_bits(Sweep64Args &, const unsigned *, int) {}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // device pipeline (T = float: v_mfma_f32_32x32x2_f32 sweep; T = double: v_mfma_f64_16x16x4_f64 sweep)
@@ -491,9 +496,13 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     // 27k items), and k_merge_positives puts the test items back.  Not when a score can be non-finite (a test item masked by the
     // train row is marked +inf in the tables), not with chunked long rows (more slots than users: their best positives are not in the primary slot),
     // not beyond the lists (k_select_topk works on the stored rows).
-    const bool mask_test = std::is_same<T, float>::value && want_auc && !ext_topk && !check_nan && n_slots > 0 &&
-                           dense_rows_fit(m, (long long)tiles_total * tile_items) && hp.n_slots == hp.n_active && hp.n_only_ndcg == 0 &&
-                           nsub * part_splits + 1 <= MAX_PARTS && !getenv("RM_DEBUG_NO_TEST_MASK");
+    bool mask_test = std::is_same<T, float>::value && want_auc && !ext_topk && !check_nan && n_slots > 0 &&
+                     dense_rows_fit(m, (long long)tiles_total * tile_items) && hp.n_slots == hp.n_active && hp.n_only_ndcg == 0 &&
+                     nsub * part_splits + 1 <= MAX_PARTS && !getenv("RM_DEBUG_NO_TEST_MASK");
+    // rows handed over by another pass: usable when they were built the way this pass would build them (unmasked rows are
+    // always valid: the old scheme)
+    const bool use_ext_bits = c.ext_bits != nullptr && c.ext_words == ((long long)tiles_total * tile_items + 31) / 32 && (!c.ext_masked || mask_test);
+    if (use_ext_bits) mask_test = c.ext_masked;
     const int n_part = nsub * part_splits + (mask_test ? 1 : 0);
     const int part_extra = mask_test ? 1 : 0;
     auto lds_need = [&](bool with_lists) { return lds_need_n(with_lists, nsub); };
@@ -617,7 +626,8 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         P::set_pending(sa, pend_cap, (int)pend_off);
         P::set_sync(sa, (int)sync_off);
         sa.stream_slot0 = stream_slot0; sa.stream_ld = stream_ld; sa.stream_scores = stream_scores;
-        set_train_bits(sa, cx, c, m, n, (long long)tiles_total * tile_items, stream, mask_test, c.noise_flag != nullptr);
+        if (use_ext_bits && dense_rows_fit(m, (long long)tiles_total * tile_items)) set_ext_bits(sa, c.ext_bits, (int)c.ext_words);
+        else set_train_bits(sa, cx, c, m, n, (long long)tiles_total * tile_items, stream, mask_test, c.noise_flag != nullptr);
         set_part_extra(sa, part_extra);
         sa.noise_row = c.noise_row; sa.noise_row0 = c.noise_row0; sa.noise_E = c.noise_E; sa.noise_ld = c.noise_ld;
 
@@ -842,6 +852,9 @@ void run_call(const Call<T> &c_in, hipStream_t stream, Ctx &cx)
             }
             c.only_users = only; c.noise_row = noise_row; c.noise_row0 = 0; c.noise_E = E; c.noise_ld = e_ld; c.noise_flag = nullptr;
             c.eval_users = n_early;
+            if (cx.bits_tag != 0 && cx.bits_tag == c0.items_tag && cx.bits_train_p == c0.train_p && cx.bits_m == m && !getenv("RM_DEBUG_NO_EXT_BITS")) {
+                c.ext_bits = (const unsigned *)cx.bits_ptr; c.ext_words = cx.bits_words; c.ext_masked = cx.bits_masked;      // the first pass's rows
+            }
             run<T>(c, ps, pc);
             HIP_CHECK(hipEventRecord(cx.pass_ev, ps));
             HIP_CHECK(hipStreamWaitEvent(stream, cx.pass_ev, 0));    // behind the first pass (stream order) AND the exact one
