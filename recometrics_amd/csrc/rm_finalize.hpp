@@ -36,6 +36,7 @@ template <class T, class S> struct FinalArgs {     // T = real_t of inputs/outpu
     int *status;                 // [m] optional: 0 ranked, 1 skipped
     // streamed users (slots [stream_slot0, n_slots), rm_device.hpp STREAM_CLASS)
     int stream_slot0;
+    int rank_generic;                                // A/B switch: k_rank_streamed without its fast routine
     const S *stream_scores; long long stream_ld;     // [n_stream][stream_ld] masked candidate scores written by the sweep
     const S *spos_score; const int *spos_item;       // [nnz_test] sorted positives of those users at test_p[u] + rank
     unsigned *shist;             // [nnz_test] at test_p[u] + j: candidates ranking above positive j but not above positive j + 1
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(MERGE_WAVES * WAVE) void k_merge_positives(FinalArg
             if (cand) {
                 vmax = x > vmax ? x : vmax;
                 vmin = x < vmin ? x : vmin;
-                if (streamed) { if (i >= 1) a.shist[te0 + i - 1] += 1u; }
+                if (streamed) { if (i >= 1) atomicAdd(&a.shist[te0 + i - 1], 1u); }      // (k_rank_streamed may be counting beside this kernel)
                 else hist_rw[row0 + (long long)i * stride] += 1u;
             }
             if (filled < K) {                                       // (score desc, item asc) = descending row order
@@ -241,10 +242,103 @@ __device__ __forceinline__ void rank_streamed_lds(const S *row, long long i0, in
     }
 }
 
+// fp32, the usual depths (64 ... 1023 positives: the copies fill the 16 KiB table), batches that lie inside the row: the same
+// search with the sweep's instruction budget (rm_sweep.hpp auc_pass) -- 3 vector instructions and one LDS read per score and
+// level instead of the compiler's 5 + 2 scalar ones, nothing per score for validity:
+//   * the table is aligned to its size, so "entry e of the lane's copy" is tab_addr | (e << lgsb): a level is one OR (the
+//     candidate address), one compare into one of three mask registers in rotation, one select two compares later;
+//   * the two top levels compare against the three pivots every lane of the block shares (scalar registers): the quarter of
+//     the table a score falls into is the number of sorted pivots below it -- three independent compare / select pairs, no read;
+//   * a masked score is the NaN sentinel: every compare with it is false, it ends in bin 0 by itself; bin 0 is a word of
+//     its own in front of the counters, so the histogram update needs no test either.
+// Loads are unconditional 32-bit-indexed reads of whole batches; the ragged end of the row goes through the generic routine.
+#define RM_FCMP_LT(m, p, x) asm volatile("v_cmp_lt_f32 %0, %1, %2" : "=s"(m) : "v"(p), "v"(x))
+#define RM_FCMP_LT_S(m, p, x) asm volatile("v_cmp_lt_f32 %0, %1, %2" : "=s"(m) : "s"(p), "v"(x))
+#define RM_FSEL(d, a, b, m) asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(m))
+template <int LV>
+__device__ __forceinline__ void rank_streamed_fast(const float *row, int i0, int iters, const int *pit, int P, unsigned tab_addr, unsigned hist0_addr,
+                                                   float piv_lo, float piv_root, float piv_hi)
+{
+    constexpr int ILP = 8;
+    constexpr int LGSB = 14 - LV;
+    constexpr unsigned SB = 1u << LGSB;                           // bytes between consecutive entries of the lane's copy
+    constexpr unsigned Q = SB << (LV - 2);                        // a quarter of the table
+    typedef __attribute__((address_space(3))) const float *LdsS;
+    const float *src = row + i0 + (int)threadIdx.x;
+    float nxt[ILP];
+    #pragma unroll
+    for (int q = 0; q < ILP; q++) nxt[q] = src[q * STREAM_RANK_THREADS];
+    const unsigned a1 = tab_addr | Q, a2 = tab_addr | (2 * Q), a3 = tab_addr | (3 * Q);
+    for (int it = 0; it < iters; it += ILP) {
+        float v[ILP]; unsigned at[ILP];
+        #pragma unroll
+        for (int q = 0; q < ILP; q++) { v[q] = nxt[q]; at[q] = tab_addr; }
+        src += ILP * STREAM_RANK_THREADS;
+        if (it + ILP < iters) {                                   // the next batch's HBM latency hides behind this batch's searches
+            #pragma unroll
+            for (int q = 0; q < ILP; q++) nxt[q] = src[q * STREAM_RANK_THREADS];
+        }
+        unsigned long long mk0, mk1, mk2;
+        #pragma unroll
+        for (int i = 0; i < 3 * ILP + 2; i++) {                   // i = pivot * ILP + score
+            if (i < 3 * ILP) {
+                const float pv = i < ILP ? piv_lo : (i < 2 * ILP ? piv_root : piv_hi);
+                if (i % 3 == 0) RM_FCMP_LT_S(mk0, pv, v[i % ILP]); else if (i % 3 == 1) RM_FCMP_LT_S(mk1, pv, v[i % ILP]); else RM_FCMP_LT_S(mk2, pv, v[i % ILP]);
+            }
+            if (i >= 2) {
+                const int j = i - 2;
+                const unsigned tgt = j < ILP ? a1 : (j < 2 * ILP ? a2 : a3);
+                if (j % 3 == 0) RM_FSEL(at[j % ILP], at[j % ILP], tgt, mk0); else if (j % 3 == 1) RM_FSEL(at[j % ILP], at[j % ILP], tgt, mk1); else RM_FSEL(at[j % ILP], at[j % ILP], tgt, mk2);
+            }
+        }
+        #pragma unroll
+        for (int st = 1 << (LV - 3); st >= 1; st >>= 1) {
+            float pv[ILP];
+            #pragma unroll
+            for (int q = 0; q < ILP; q++) pv[q] = *(LdsS)(at[q] + (unsigned)(st - 1) * SB);
+            #pragma unroll
+            for (int i = 0; i < ILP + 2; i++) {
+                // s_waitcnt lgkmcnt(4 / 0), the other counters left alone
+                if (i == 0) __builtin_amdgcn_s_waitcnt(0xC47F); else if (i == 4) __builtin_amdgcn_s_waitcnt(0xC07F);
+                if (i < ILP) { if (i % 3 == 0) RM_FCMP_LT(mk0, pv[i], v[i]); else if (i % 3 == 1) RM_FCMP_LT(mk1, pv[i], v[i]); else RM_FCMP_LT(mk2, pv[i], v[i]); }
+                if (i >= 2) {
+                    const int j = i - 2;
+                    const unsigned cand = at[j] | ((unsigned)st * SB);
+                    if (j % 3 == 0) RM_FSEL(at[j], at[j], cand, mk0); else if (j % 3 == 1) RM_FSEL(at[j], at[j], cand, mk1); else RM_FSEL(at[j], at[j], cand, mk2);
+                }
+            }
+        }
+        float nx[ILP];
+        #pragma unroll
+        for (int q = 0; q < ILP; q++) nx[q] = *(LdsS)(at[q]);             // entry `top - 1` is +inf: always in range
+        bool tie = false;
+        #pragma unroll
+        for (int q = 0; q < ILP; q++) tie |= nx[q] == v[q];
+        if (__any(tie)) {                                                 // exact tie with a positive (rare)
+            #pragma unroll
+            for (int q = 0; q < ILP; q++) {
+                if (nx[q] == v[q]) {
+                    const int item = i0 + (it + q) * STREAM_RANK_THREADS + (int)threadIdx.x;
+                    int l = (int)((at[q] - tab_addr) >> LGSB);
+                    while (l < P && *(LdsS)(tab_addr + ((unsigned)l << LGSB)) == v[q] && pit[l] > item) l++;
+                    at[q] = tab_addr + ((unsigned)l << LGSB);
+                }
+            }
+        }
+        const unsigned one = 1u;
+        #pragma unroll
+        for (int q = 0; q < ILP; q++) {
+            const unsigned ha = hist0_addr + (((at[q] - tab_addr) >> LGSB) << 2);
+            asm volatile("ds_add_u32 %0, %1" :: "v"(ha), "v"(one) : "memory");
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                   // the asm atomics are invisible to the compiler
+}
+
 template <class T, class S>
 __global__ __launch_bounds__(STREAM_RANK_THREADS) void k_rank_streamed(FinalArgs<T, S> a, int parts, int ipt, int row0)
 {   // parts = blocks per row, ipt = items per thread (a multiple of 8): the row is cut into equal pieces
-    __shared__ __attribute__((aligned(16))) char rk_smem[STREAM_RANK_LDS];
+    __shared__ __attribute__((aligned(16384))) char rk_smem[STREAM_RANK_LDS];
     const int d = row0 + blockIdx.x / parts, part = blockIdx.x % parts;
     const int slot = a.stream_slot0 + d;
     const int u = a.slot_user[slot];
@@ -255,13 +349,14 @@ __global__ __launch_bounds__(STREAM_RANK_THREADS) void k_rank_streamed(FinalArgs
     int top = 1;
     while (top <= P) top <<= 1;                                   // table = top entries: P positives, then +inf
     int R = 0;
-    if ((long long)top * per + P <= WORDS) { R = 1; while (R < 32 && (long long)top * 2 * R * per + P <= WORDS) R *= 2; }
+    // (P + 1 counters: the word in front of them is bin 0, "below every positive", counted by the fast routine and never read)
+    if ((long long)top * per + P + 1 <= WORDS) { R = 1; while (R < 32 && (long long)top * 2 * R * per + P + 1 <= WORDS) R *= 2; }
     const int *pit = a.spos_item + te0;
     const S *row = a.stream_scores + (size_t)d * (size_t)a.stream_ld;
     const long long i0 = (long long)part * STREAM_RANK_THREADS * ipt;
     if (R > 0) {
         S *lds_s = (S *)rk_smem;                                  // [top][R]
-        unsigned *lds_h = (unsigned *)(rk_smem + sizeof(S) * (size_t)top * (size_t)R);
+        unsigned *lds_h = (unsigned *)(rk_smem + sizeof(S) * (size_t)top * (size_t)R) + 1;
         for (int i = threadIdx.x; i < top * R; i += STREAM_RANK_THREADS) { const int e = i / R; lds_s[i] = e < P ? a.spos_score[te0 + e] : (S)INFINITY; }
         for (int i = threadIdx.x; i < P; i += STREAM_RANK_THREADS) lds_h[i] = 0u;
         __syncthreads();
@@ -271,6 +366,25 @@ __global__ __launch_bounds__(STREAM_RANK_THREADS) void k_rank_streamed(FinalArgs
         const unsigned hist_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds_h;
         // (depth as a template constant when the copies fill the 4096-entry table: 64 ... 1023 positives)
         const bool full = (long long)top * R == 4096 / per;
+        if (sizeof(S) == 4 && full && top >= 128 && top <= 1024 && !a.rank_generic) {
+            // whole batches inside the row through the fast routine, the ragged end through the generic one
+            const int inside = (int)((a.n - i0) / STREAM_RANK_THREADS);                      // iterations whose 256 items all lie in the row
+            const int iters = inside <= 0 ? 0 : (inside < ipt ? inside : ipt) / 8 * 8;
+            if (iters > 0) {
+                const float *tabf = (const float *)lds_s;
+                const float p_lo = tabf[(top / 4 - 1) * R], p_root = tabf[(top / 2 - 1) * R], p_hi = tabf[(3 * top / 4 - 1) * R];
+                const float s_lo = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p_lo)));
+                const float s_root = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p_root)));
+                const float s_hi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p_hi)));
+                const float *rowf = (const float *)row;
+                const unsigned h0 = hist_addr - 4u;
+                if (top == 128) rank_streamed_fast<7>(rowf, (int)i0, iters, pit, P, tab_addr, h0, s_lo, s_root, s_hi);
+                else if (top == 256) rank_streamed_fast<8>(rowf, (int)i0, iters, pit, P, tab_addr, h0, s_lo, s_root, s_hi);
+                else if (top == 512) rank_streamed_fast<9>(rowf, (int)i0, iters, pit, P, tab_addr, h0, s_lo, s_root, s_hi);
+                else rank_streamed_fast<10>(rowf, (int)i0, iters, pit, P, tab_addr, h0, s_lo, s_root, s_hi);
+            }
+            if (iters < ipt) rank_streamed_lds<S, 8, 0>(row, i0 + (long long)iters * STREAM_RANK_THREADS, ipt - iters, a.n, pit, P, top, lgsb, tab_addr, hist_addr);
+        } else
         if (full && top == 128) rank_streamed_lds<S, 8, 7>(row, i0, ipt, a.n, pit, P, top, lgsb, tab_addr, hist_addr);
         else if (full && top == 256) rank_streamed_lds<S, 8, 8>(row, i0, ipt, a.n, pit, P, top, lgsb, tab_addr, hist_addr);
         else if (full && top == 512) rank_streamed_lds<S, 8, 9>(row, i0, ipt, a.n, pit, P, top, lgsb, tab_addr, hist_addr);

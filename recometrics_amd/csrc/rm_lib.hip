@@ -79,7 +79,7 @@ struct Ctx {
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false, ev_recorded = false;
     hipStream_t side_stream = nullptr;      // second sweep launch of a depth-split call runs beside the first
-    hipEvent_t side_ev[2] = {nullptr, nullptr};
+    hipEvent_t side_ev[3] = {nullptr, nullptr, nullptr};
     hipEvent_t done = nullptr;               // end of the device work of the most recent call on this context
     hipStream_t own_stream = nullptr;        // stream of a shard worker (multi-device calls)
     hipStream_t up_stream = nullptr;         // host-pointer calls: uploads of the NEXT user batch run beside the current batch's kernels
@@ -346,6 +346,18 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     }
     g_last_ctx = &cx;
     HIP_CHECK(hipEventRecord(g_ev[0], stream));
+    // side stream of the context: kernels that do not depend on one another run beside the main stream's (the dense train rows beside
+    // the positives, the streamed users' ranks beside the rest of the finalisation; a depth-split call's second sweep launch)
+    auto side_stream = [&]() -> hipStream_t {
+        if (!cx.side_stream) {
+            HIP_CHECK(hipStreamCreateWithFlags(&cx.side_stream, hipStreamNonBlocking));
+            for (int i = 0; i < 3; i++) HIP_CHECK(hipEventCreateWithFlags(&cx.side_ev[i], hipEventDisableTiming));
+        }
+        return cx.side_stream;
+    };
+    auto fork_side = [&]() { hipStream_t sd = side_stream(); HIP_CHECK(hipEventRecord(cx.side_ev[0], stream)); HIP_CHECK(hipStreamWaitEvent(sd, cx.side_ev[0], 0)); return sd; };
+    auto join_side = [&]() { HIP_CHECK(hipEventRecord(cx.side_ev[1], cx.side_stream)); HIP_CHECK(hipStreamWaitEvent(stream, cx.side_ev[1], 0)); };
+    const bool use_side = !getenv("RM_DEBUG_NO_SIDE");
 
     // ---- plan ----
     int *flags = (int *)ws.get("flags", sizeof(int) * (size_t)m);
@@ -551,6 +563,9 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     auto rank_streamed_rows = [&](int r0, int r1, hipStream_t st) {
         if (r1 <= r0) return;
         hipLaunchKernelGGL((k_rank_streamed<T, T>), dim3((unsigned)((long long)(r1 - r0) * stream_parts)), dim3(STREAM_RANK_THREADS), 0, st, fa, stream_parts, stream_ipt, r0);
+    };
+    auto auc_streamed_rows = [&](int r0, int r1, hipStream_t st) {
+        if (r1 <= r0) return;
         hipLaunchKernelGGL((k_auc_streamed<T, T>), dim3(cdiv((long long)(r1 - r0) * WAVE, 256)), dim3(256), 0, st, fa, r0, r1);
     };
     T *pos_score = nullptr; unsigned *hist = nullptr; int *pos_order = nullptr, *pos_item = nullptr;
@@ -567,6 +582,12 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         const bool items_packed = items_known && cx.packed_tile == tile_items && cx.packed_ng == NG && cx.packed_ptr == (const void *)Bp;
         pack_operands(c.A, c.lda, c.B, c.ldb, n, k, NG, tile_items, slot_user, n_slots, Ap, ap_units, Bp, bp_units, stream, !items_packed);
         cx.packed_tag = c.items_tag; cx.packed_tile = tile_items; cx.packed_ng = NG; cx.packed_ptr = (const void *)Bp;
+
+        // ---- dense train rows (fp32, small item counts) ----
+        // (measured: on the side stream beside the positives' kernels they gain nothing -- both are bound by memory; r3_ab_c2.txt)
+        typename P::Args sa{};
+        if (use_ext_bits && dense_rows_fit(m, (long long)tiles_total * tile_items)) set_ext_bits(sa, c.ext_bits, (int)c.ext_words);
+        else set_train_bits(sa, cx, c, m, n, (long long)tiles_total * tile_items, stream, mask_test, c.noise_flag != nullptr);
 
         // ---- positives ----
         if (want_auc) {
@@ -616,7 +637,6 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         if (want_auc && !ext_topk && !getenv("RM_DEBUG_NO_SEED"))
             hipLaunchKernelGGL((k_seed_thresholds<T, ThrT>), dim3(cdiv(n_slots, 256)), dim3(256), 0, stream, n_slots, stream_slot0, K, GU, slot_user, slot_chunk,
                                user_nslots, flags, c.test_p, grow, pos_score, spos_score, thr_shared);
-        typename P::Args sa{};
         sa.thr_shared = thr_shared;
         sa.n = n; sa.K = K; sa.ngt = NG; sa.n_slots = n_slots; sa.n_groups = n_groups; sa.n_ublocks = n_ublocks;
         sa.n_splits = n_splits; sa.tail_ublocks = tail_ublocks; sa.tail_splits = tail_splits; sa.part_splits = part_splits; sa.tiles_total = tiles_total; sa.jmax = jmax; sa.check_nan = check_nan ? 1 : 0; sa.buffered_lists = (K > 32 || ext_topk) ? 1 : 0; sa.ext_topk = ext_topk ? 1 : 0;
@@ -626,8 +646,6 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         P::set_pending(sa, pend_cap, (int)pend_off);
         P::set_sync(sa, (int)sync_off);
         sa.stream_slot0 = stream_slot0; sa.stream_ld = stream_ld; sa.stream_scores = stream_scores;
-        if (use_ext_bits && dense_rows_fit(m, (long long)tiles_total * tile_items)) set_ext_bits(sa, c.ext_bits, (int)c.ext_words);
-        else set_train_bits(sa, cx, c, m, n, (long long)tiles_total * tile_items, stream, mask_test, c.noise_flag != nullptr);
         set_part_extra(sa, part_extra);
         sa.noise_row = c.noise_row; sa.noise_row0 = c.noise_row0; sa.noise_E = c.noise_E; sa.noise_ld = c.noise_ld;
 
@@ -647,11 +665,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             if (j_shallow >= 0) u_split = hp.class_offset[j_shallow + 1] / (GROUPS_PER_BLOCK * GU);
         }
         if (u_split > 0) {
-            if (!cx.side_stream) {
-                HIP_CHECK(hipStreamCreateWithFlags(&cx.side_stream, hipStreamNonBlocking));
-                for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&cx.side_ev[i], hipEventDisableTiming));
-            }
-            hipStream_t g_side_stream = cx.side_stream;
+            hipStream_t g_side_stream = side_stream();
             hipEvent_t *g_side_ev = cx.side_ev;
             typename P::Args sb = sa;                              // the deep blocks: lists in HBM, as computed above
             P::set_ublocks(sb, u_split, n_ublocks - u_split);
@@ -693,10 +707,21 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
 
     // ---- finalize ----
     fa.n_part = n_part; fa.pl = pl; fa.pst = pst; fa.hist = hist; fa.pos_score = pos_score; fa.pos_item_tab = pos_item;
+    // the streamed users' ranks (HBM-bound: the stored score rows) run on the side stream beside the short kernels of the others
+    fa.stream_slot0 = stream_slot0; fa.stream_scores = stream_scores; fa.stream_ld = stream_ld;
+    fa.spos_score = spos_score; fa.spos_item = spos_item; fa.shist = shist;
+    fa.rank_generic = getenv("RM_DEBUG_RANK_GENERIC") ? 1 : 0;
+    const bool ranks_beside = use_side && n_slots > 0 && want_auc && n_stream > 0;
+    hipStream_t rank_stream = stream;
+    if (ranks_beside) { rank_stream = fork_side(); rank_streamed_rows(0, n_stream, rank_stream); }
     if (mask_test) {
-        fa.stream_slot0 = stream_slot0; fa.spos_score = spos_score; fa.spos_item = spos_item; fa.shist = shist;
         hipLaunchKernelGGL((k_merge_positives<T, T>), dim3(cdiv(n_slots, MERGE_WAVES)), dim3(MERGE_WAVES * WAVE), 0, stream, fa, hist, n_part - 1);
+        if (ranks_beside) {                                        // (it counts the streamed users' own test items: before k_auc_streamed)
+            HIP_CHECK(hipEventRecord(cx.side_ev[2], stream));
+            HIP_CHECK(hipStreamWaitEvent(rank_stream, cx.side_ev[2], 0));
+        }
     }
+    if (ranks_beside) auc_streamed_rows(0, n_stream, rank_stream);
     hipLaunchKernelGGL((k_finalize_skipped<T, T>), dim3(cdiv(m, 256)), dim3(256), 0, stream, fa);
     if (fa.ndcg && hp.n_heavy > 0) {                            // ideal-DCG values of the users with very long test rows
         fa.heavy_topv = (T *)ws.get("heavy_topv", sizeof(T) * (size_t)m * std::min(K, FIN_TOPV));
@@ -704,7 +729,6 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         fa.heavy_users = heavy_users; fa.n_heavy = hp.n_heavy;
         hipLaunchKernelGGL((k_top_values<T, T>), dim3(cdiv((long long)hp.n_heavy * WAVE, 256)), dim3(256), 0, stream, fa);
     }
-    fa.stream_slot0 = stream_slot0; fa.stream_scores = stream_scores; fa.stream_ld = stream_ld;
     if (n_slots > 0 && ext_topk) {
         int sel_ld = 2;
         while (sel_ld < K) sel_ld <<= 1;
@@ -715,10 +739,10 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     }
     if (n_slots > 0) {
         if (want_auc) {
-            fa.spos_score = spos_score; fa.spos_item = spos_item; fa.shist = shist;
-            if (n_stream > 0) rank_streamed_rows(0, n_stream, stream);
+            if (n_stream > 0 && !ranks_beside) { rank_streamed_rows(0, n_stream, stream); auc_streamed_rows(0, n_stream, stream); }
             if (stream_slot0 > 0) hipLaunchKernelGGL((k_auc_slots<T, T>), dim3(cdiv(stream_slot0, 256)), dim3(256), 0, stream, fa);
         }
+        if (ranks_beside) join_side();
         const size_t fin_lds = finalize_lds_bytes<T>(K, n_part);
         HIP_CHECK(hipFuncSetAttribute((const void *)k_finalize<T, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));
         hipLaunchKernelGGL((k_finalize<T, T>), dim3(cdiv(n_slots, FIN_THREADS)), dim3(FIN_THREADS), fin_lds, stream, fa);
