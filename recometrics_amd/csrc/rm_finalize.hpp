@@ -37,6 +37,7 @@ template <class T, class S> struct FinalArgs {     // T = real_t of inputs/outpu
     // streamed users (slots [stream_slot0, n_slots), rm_device.hpp STREAM_CLASS)
     int stream_slot0;
     int rank_generic;                                // A/B switch: k_rank_streamed without its fast routine
+    int fin_slot0, fin_slot1;                        // slot range of a k_finalize launch
     const S *stream_scores; long long stream_ld;     // [n_stream][stream_ld] masked candidate scores written by the sweep
     const S *spos_score; const int *spos_item;       // [nnz_test] sorted positives of those users at test_p[u] + rank
     unsigned *shist;             // [nnz_test] at test_p[u] + j: candidates ranking above positive j but not above positive j + 1
@@ -635,8 +636,8 @@ __global__ void k_finalize(FinalArgs<T, S> a)
     // One thread per SLOT, not per user: the 32 (16) users of a group sit on adjacent threads, so their reads of the
     // group's column-major tables (rank histogram, sorted positives: [row][user of the group]) coalesce into one line
     // per row, and the users of a group have similar row lengths.  Users without a slot are k_finalize_skipped's.
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= a.n_slots || a.slot_chunk[slot] != 0) return;
+    const int slot = a.fin_slot0 + blockIdx.x * blockDim.x + threadIdx.x;          // this launch: slots [fin_slot0, fin_slot1)
+    if (slot >= a.fin_slot1 || a.slot_chunk[slot] != 0) return;
     const int u = a.slot_user[slot];
     const int K = a.K, n = a.n;
     const int f = a.flags[u];

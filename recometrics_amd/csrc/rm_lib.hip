@@ -742,10 +742,20 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             if (n_stream > 0 && !ranks_beside) { rank_streamed_rows(0, n_stream, stream); auc_streamed_rows(0, n_stream, stream); }
             if (stream_slot0 > 0) hipLaunchKernelGGL((k_auc_slots<T, T>), dim3(cdiv(stream_slot0, 256)), dim3(256), 0, stream, fa);
         }
-        if (ranks_beside) join_side();
         const size_t fin_lds = finalize_lds_bytes<T>(K, n_part);
         HIP_CHECK(hipFuncSetAttribute((const void *)k_finalize<T, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));
-        hipLaunchKernelGGL((k_finalize<T, T>), dim3(cdiv(n_slots, FIN_THREADS)), dim3(FIN_THREADS), fin_lds, stream, fa);
+        auto finalize_slots = [&](int s0, int s1) {
+            if (s1 <= s0) return;
+            fa.fin_slot0 = s0; fa.fin_slot1 = s1;
+            hipLaunchKernelGGL((k_finalize<T, T>), dim3(cdiv(s1 - s0, FIN_THREADS)), dim3(FIN_THREADS), fin_lds, stream, fa);
+        };
+        if (ranks_beside) {
+            // the users with tables need nothing from the side stream: their metrics are formed while the streamed users' ranks are
+            // still being counted there; the streamed users' follow behind the join
+            finalize_slots(0, stream_slot0);
+            join_side();
+            finalize_slots(stream_slot0, n_slots);
+        } else finalize_slots(0, n_slots);
     }
     HIP_CHECK(hipGetLastError());
     if (c.topk_idx)

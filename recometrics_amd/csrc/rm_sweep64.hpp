@@ -487,7 +487,9 @@ void k_sweep64(Sweep64Args a)
                 }
                 __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                          // arrive half: DMA share landed (and with it `nxt`)
                 if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"((unsigned)(__UINTPTR_TYPE__)arrive), "v"(1u) : "memory");
-                if (c == NC - 1) do_epi(clo, chi, t0 + i, thr_seen);
+                // the epilogue issues ahead of the SIMD partner's matrix instructions: it is the part of a unit whose length varies, and
+                // the three waves that wait for this one at the next unit's barrier wait less (C5 0.608 -> 0.614, r3_ab_c2.txt r3zj)
+                if (c == NC - 1) { __builtin_amdgcn_s_setprio(3); do_epi(clo, chi, t0 + i, thr_seen); __builtin_amdgcn_s_setprio(0); }
             };
             for (int c = 0; c < NC; c += 2) { unit_body(c, afA, afB); unit_body(c + 1, afB, afA); }
             thr_seen = thr_next;
@@ -528,7 +530,7 @@ void k_sweep64(Sweep64Args a)
             }
             __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                              // arrive half: the next unit's DMA share has landed
             if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"((unsigned)(__UINTPTR_TYPE__)arrive), "v"(1u) : "memory");     // (see the fp32 sweep)
-            if (c == NC - 1) do_epi(clo, chi, t0 + i, thr_seen);
+            if (c == NC - 1) { __builtin_amdgcn_s_setprio(3); do_epi(clo, chi, t0 + i, thr_seen); __builtin_amdgcn_s_setprio(0); }
         }
         thr_seen = thr_next;
     }
