@@ -14,6 +14,10 @@
 #include "rm_list.hpp"
 #include "rm_launch.hpp"
 
+#ifndef RM_EARLY_ARRIVE
+#define RM_EARLY_ARRIVE 4
+#endif
+
 namespace rm {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -476,17 +480,30 @@ void k_sweep64(Sweep64Args a)
                     #pragma unroll
                     for (int r = 0; r < 4; r++) { clo[r] = 0.; chi[r] = 0.; }
                 }
+                // EARLY ARRIVAL: the item operands of the unit's last EARLY factor groups are read together; once they are in registers this
+                // wave is done with the buffer, so it arrives (its DMA share of the next unit has had most of the unit to land) BEFORE
+                // it issues the matrix instructions of those groups -- the partners' wait at the next unit's start ends that much sooner
+                // (the coupling of a sub-tile's four waves at four barriers per tile was 9 % of C5; r3_ab_c2.txt r3zp)
+                constexpr int EARLY = RM_EARLY_ARRIVE < NGC ? RM_EARLY_ARRIVE : NGC;
+                f64x2 tb0[EARLY], tb1[EARLY];
                 #pragma unroll
                 for (int gl = 0; gl < NGC; gl++) {
-                    const f64x2 b0 = bb[gl * 128], b1 = bb[gl * 128 + 16];
+                    if (gl == NGC - EARLY) {
+                        #pragma unroll
+                        for (int e = 0; e < EARLY; e++) { tb0[e] = bb[(gl + e) * 128]; tb1[e] = bb[(gl + e) * 128 + 16]; }
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_waitcnt(0x0070);                              // vmcnt(0) lgkmcnt(0) (expcnt left alone)
+                        if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"((unsigned)(__UINTPTR_TYPE__)arrive), "v"(1u) : "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    const f64x2 b0 = gl >= NGC - EARLY ? tb0[gl >= NGC - EARLY ? gl - (NGC - EARLY) : 0] : bb[gl * 128];
+                    const f64x2 b1 = gl >= NGC - EARLY ? tb1[gl >= NGC - EARLY ? gl - (NGC - EARLY) : 0] : bb[gl * 128 + 16];
                     const f64x2 u = gl < HALF ? cur[gl < HALF ? gl : 0] : af[gl >= HALF ? gl - HALF : 0];
                     clo = __builtin_amdgcn_mfma_f64_16x16x4f64(b0.x, u.x, clo, 0, 0, 0);
                     chi = __builtin_amdgcn_mfma_f64_16x16x4f64(b1.x, u.x, chi, 0, 0, 0);
                     clo = __builtin_amdgcn_mfma_f64_16x16x4f64(b0.y, u.y, clo, 0, 0, 0);
                     chi = __builtin_amdgcn_mfma_f64_16x16x4f64(b1.y, u.y, chi, 0, 0, 0);
                 }
-                __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                          // arrive half: DMA share landed (and with it `nxt`)
-                if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"((unsigned)(__UINTPTR_TYPE__)arrive), "v"(1u) : "memory");
                 // the epilogue issues ahead of the SIMD partner's matrix instructions: it is the part of a unit whose length varies, and
                 // the three waves that wait for this one at the next unit's barrier wait less (C5 0.608 -> 0.614, r3_ab_c2.txt r3zj)
                 if (c == NC - 1) { __builtin_amdgcn_s_setprio(3); do_epi(clo, chi, t0 + i, thr_seen); __builtin_amdgcn_s_setprio(0); }
@@ -519,17 +536,26 @@ void k_sweep64(Sweep64Args a)
                 #pragma unroll
                 for (int r = 0; r < 4; r++) { clo[r] = 0.; chi[r] = 0.; }
             }
+            constexpr int EARLY = RM_EARLY_ARRIVE < NGC ? RM_EARLY_ARRIVE : NGC;           // early arrival: see the loop above
+            f64x2 tb0[EARLY], tb1[EARLY];
             #pragma unroll
             for (int gl = 0; gl < NGC; gl++) {
-                const f64x2 b0 = bb[gl * 128], b1 = bb[gl * 128 + 16];
+                if (gl == NGC - EARLY) {
+                    #pragma unroll
+                    for (int e = 0; e < EARLY; e++) { tb0[e] = bb[(gl + e) * 128]; tb1[e] = bb[(gl + e) * 128 + 16]; }
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_waitcnt(0x0070);                                  // vmcnt(0) lgkmcnt(0): operands in registers, the next unit's DMA share landed
+                    if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"((unsigned)(__UINTPTR_TYPE__)arrive), "v"(1u) : "memory");     // (see the fp32 sweep)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const f64x2 b0 = gl >= NGC - EARLY ? tb0[gl >= NGC - EARLY ? gl - (NGC - EARLY) : 0] : bb[gl * 128];
+                const f64x2 b1 = gl >= NGC - EARLY ? tb1[gl >= NGC - EARLY ? gl - (NGC - EARLY) : 0] : bb[gl * 128 + 16];
                 const f64x2 u = af[AF_RESIDENT ? c * NGC + gl : gl];
                 clo = __builtin_amdgcn_mfma_f64_16x16x4f64(b0.x, u.x, clo, 0, 0, 0);
                 chi = __builtin_amdgcn_mfma_f64_16x16x4f64(b1.x, u.x, chi, 0, 0, 0);
                 clo = __builtin_amdgcn_mfma_f64_16x16x4f64(b0.y, u.y, clo, 0, 0, 0);
                 chi = __builtin_amdgcn_mfma_f64_16x16x4f64(b1.y, u.y, chi, 0, 0, 0);
             }
-            __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                              // arrive half: the next unit's DMA share has landed
-            if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"((unsigned)(__UINTPTR_TYPE__)arrive), "v"(1u) : "memory");     // (see the fp32 sweep)
             if (c == NC - 1) { __builtin_amdgcn_s_setprio(3); do_epi(clo, chi, t0 + i, thr_seen); __builtin_amdgcn_s_setprio(0); }
         }
         thr_seen = thr_next;
