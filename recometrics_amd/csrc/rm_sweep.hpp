@@ -18,8 +18,9 @@
 //   operands       user factors live in registers for the whole sweep (NG float4 per lane, up to 128 factors; beyond
 //                  that the factor axis is streamed in 128-factor chunks); packed item tiles (rm_prep.hpp
 //                  k_pack_items) stream HBM -> LDS by LDS-DMA (inline asm), double buffered.
-//   synchronisation  a split barrier on an LDS arrival counter instead of s_barrier per tile: arrive after the tile's
-//                  last MFMA, wait before the next tile touches the buffers, the whole epilogue in between -- per
+//   synchronisation  a split barrier on an LDS arrival counter instead of s_barrier per tile: arrive once the tile's last
+//                  operands are in registers (before the last eight MFMAs are issued, when the user factors are resident),
+//                  wait before the next tile touches the buffers, the whole epilogue in between -- per
 //                  sub-tile (the four waves that stage and read the same 32 items), not per block; the sub-tile that is
 //                  behind gets the higher issue priority (s_setprio), so that all reach the end of the range together.
 //   grid           two levels (rm_launch.hpp): whole rounds of blocks with n_splits item ranges, then the cheapest user

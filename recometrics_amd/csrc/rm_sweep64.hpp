@@ -461,7 +461,9 @@ void k_sweep64(Sweep64Args a)
                 const int buf = unit & 1;
                 if (unit > 0) {
                     const unsigned target = 4u * (unsigned)unit;
+#ifndef RM_ABL_NO_BARRIER                                                 // (timing only: what the coupling of the domain's four waves costs)
                     while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+#endif
                 }
                 // second half of this chunk first (it is needed 16 MFMAs from now), then the item tile of the next unit, then
                 // the first half of the next chunk (needed a whole chunk from now; after the last chunk: chunk 0 of the next tile)
