@@ -272,6 +272,37 @@ def test_long_test_rows_streamed_or_chunked(hip, oracle, dtype, budget, monkeypa
         _check_against_oracle(hip, oracle, pr, 10, dtype=dtype)
 
 
+@pytest.mark.parametrize("env", [{}, {"RM_DEBUG_RANK_GENERIC": "1"}, {"RM_DEBUG_NO_SIDE": "1"},
+                                 {"RM_DEBUG_RANK_GENERIC": "1", "RM_DEBUG_NO_SIDE": "1"}])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_streamed_ranks_fast_routine_and_side_stream(hip, oracle, env, dtype, monkeypatch):
+    """streamed users of every table depth the fast routine of k_rank_streamed is built for (64 .. 1023 test items: 128, 256, 512
+    and 1024 table entries) next to shorter and longer rows, an item count that leaves a ragged end for the generic routine, and a
+    masked stretch (a user whose train row covers a run of items): the ranks with the fast routine / the generic one, on the side
+    stream / on the main one, are the oracle's"""
+    from recometrics_amd.synth import make_factors
+    rng = np.random.default_rng(909)
+    m, n, k = 96, 9000 + 37, 24
+    A, B = make_factors(m, n, k, dtype, seed=3)
+    lens = [3, 40, 63, 64, 65, 100, 127, 128, 200, 255, 256, 400, 511, 512, 800, 1023, 1024, 1500]
+    rows_tr, rows_te = [], []
+    for u in range(m):
+        nte = lens[u % len(lens)]
+        items = rng.permutation(n)[: nte + 150]
+        te = np.sort(items[:nte]); tr = np.sort(items[nte:])
+        if u % 7 == 0:                                              # a run of consecutive train items: whole masked stretches in the row
+            tr = np.union1d(tr, np.setdiff1d(np.arange(2000, 2600), te))
+        rows_te.append(te); rows_tr.append(tr)
+    def csr(rows):
+        indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+        return indptr, np.concatenate(rows).astype(np.int32)
+    tep, tei = csr(rows_te)
+    pr = {"A": A, "B": B, "train": csr(rows_tr), "test": (tep, tei, rng.integers(1, 21, size=tei.shape[0]).astype(dtype))}
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    _check_against_oracle(hip, oracle, pr, 10, dtype=dtype)
+
+
 @pytest.mark.parametrize("dtype,budget", [(np.float32, None), (np.float64, None), (np.float32, "1"), (np.float64, "1")])
 def test_tie_noise_rankings_equal_the_oracle(hip, oracle, dtype, budget, monkeypatch):
     """break_ties_with_noise=True (the API default): ordered top-K lists, the rank of every test item and all metrics equal
