@@ -132,8 +132,14 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
     #pragma unroll
     for (int st = FIRST_ST; st >= 1; st >>= 1) {
         float pv[16];
+#ifdef RM_ABL_NOLDS_SEARCH
+        // timing only (wrong results): the pivots come from a register move instead of LDS -- what the reads' latency costs
+        #pragma unroll
+        for (int r = 0; r < 16; r++) asm volatile("v_mov_b32 %0, %1" : "=v"(pv[r]) : "v"(at[r]));
+#else
         #pragma unroll
         for (int r = 0; r < 16; r++) pv[r] = *(LdsF32Ptr)(at[r] + (st - 1) * 128);
+#endif
         #pragma unroll
         for (int i = 0; i < 16 + 2; i++) {
             // s_waitcnt lgkmcnt(12 / 8 / 4 / 0) with the other counters left alone (gfx9 encoding, see WAIT_VMCNT0)
