@@ -29,6 +29,15 @@ for it in range(cases):
     kw = dict(cumulative=bool(rng.random() < 0.3), cold=bool(rng.random() < 0.7), noise=bool(rng.random() < 0.45), metrics=metrics,
               min_items_pool=int(rng.choice([1, 2, 10])), min_pos_test=int(rng.choice([1, 1, 3])), seed=int(rng.choice([1, 7, 2 ** 35 + 3])))
     pr = make_problem(m, n, k, dtype, mean_c=mean_c, seed=int(rng.integers(1 << 30)))
+    if rng.random() < 0.3:                           # test items that are also train items (never candidates: reference :491-497)
+        trp, tri = pr["train"]; tep_, tei_ = pr["test"][:2]
+        rows = []
+        for u in range(m):
+            tr = tri[trp[u]:trp[u + 1]]; te = tei_[tep_[u]:tep_[u + 1]]
+            r = rng.random()
+            add = te[rng.random(te.shape[0]) < 0.3] if r < 0.3 else (te if r < 0.36 else te[:0])
+            rows.append(np.union1d(tr, add).astype(np.int32))
+        pr["train"] = (np.concatenate([[0], np.cumsum([x.shape[0] for x in rows])]).astype(np.int32), np.concatenate(rows).astype(np.int32))
     if kw["noise"] and rng.random() < 0.5:          # cold items: blocks of exactly tied scores that only the noise orders
         pr["B"] = pr["B"].copy(); pr["B"][rng.random(n) < 0.2] = 0
     if os.environ.get("FUZZ_TIES") and not kw["noise"]:   # exact ties without noise (deviation D4: item order): cold items and duplicated items
@@ -44,7 +53,8 @@ for it in range(cases):
         for name in want:
             g, w = got[name], want[name]
             nan_ok = (np.isnan(g) == np.isnan(w)).all()
-            d = np.nanmax(np.abs(np.where(np.isnan(g), 0, g).astype(np.float64) - np.where(np.isnan(w), 0, w))) if g.size else 0.0
+            w0 = np.where(np.isnan(w), 0, w).astype(np.float64)
+            d = np.nanmax(np.abs(np.where(np.isnan(g), 0, g).astype(np.float64) - w0) / np.maximum(1.0, np.abs(w0))) if g.size else 0.0
             if not nan_ok or d > 1e-5:
                 msg.append("%s nan_ok=%s maxdiff=%g" % (name, nan_ok, d))
             elif name == "PR_AUC" and "RM_STREAM_BUDGET_MB" in os.environ:      # chunked sums of long rows: 1e-12

@@ -48,5 +48,9 @@ def assert_close(got, want, tol, what=""):
     assert got.shape == want.shape, (what, got.shape, want.shape)
     nan_g, nan_w = np.isnan(got), np.isnan(want)
     assert (nan_g == nan_w).all(), "%s: NaN pattern differs at %s" % (what, np.argwhere(nan_g != nan_w)[:5].tolist())
-    d = np.abs(np.where(nan_g, 0, got).astype(np.float64) - np.where(nan_w, 0, want).astype(np.float64))
-    assert d.max(initial=0) <= tol, "%s: max abs diff %g > %g at %s" % (what, d.max(), tol, np.unravel_index(d.argmax(), d.shape))
+    w64 = np.where(nan_w, 0, want).astype(np.float64)
+    d = np.abs(np.where(nan_g, 0, got).astype(np.float64) - w64)
+    # (relative beyond magnitude 1: a user whose test items are all train items gets a meaningless ROC-AUC of ~ -2e14 from the
+    # reference's formula -- reproduced to the last bit or two, which is far more than `tol` in absolute terms)
+    d = d / np.maximum(1.0, np.abs(w64))
+    assert d.max(initial=0) <= tol, "%s: max diff %g > %g at %s" % (what, d.max(), tol, np.unravel_index(d.argmax(), d.shape))

@@ -151,6 +151,7 @@ def _check_against_oracle(hip, oracle, pr, k, dtype=np.float32, **kw):
                 if name == "ROC_AUC":
                     d = np.abs(np.nan_to_num(got[name].astype(np.float64)) - np.nan_to_num(real[name].astype(np.float64)))
                     assert (np.isnan(got[name]) == np.isnan(real[name])).all()
+                    d = d / np.maximum(1.0, np.abs(np.nan_to_num(real[name].astype(np.float64))))      # (relative beyond magnitude 1, see assert_close)
                     assert (d <= TOL + 1.0 / np.maximum(npos_u * nneg_u, 1)).all(), "ROC_AUC vs the compiled reference: %g" % d.max()
                     continue
                 assert_close(got[name], real[name], TOL, "%s cumulative=%s vs the compiled reference" % (name, cumulative))
@@ -270,6 +271,28 @@ def test_long_test_rows_streamed_or_chunked(hip, oracle, dtype, budget, monkeypa
             assert_same_bits(got[name], ref[name], "budget too small == never stream: " + name)
     else:
         _check_against_oracle(hip, oracle, pr, 10, dtype=dtype)
+
+
+@pytest.mark.parametrize("noise", [False, True])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_test_items_that_are_also_train_items(hip, oracle, dtype, noise):
+    """rows whose TEST entries partly (or all) repeat TRAIN entries: the reference never scores a train item (src/recometrics.hpp:491-497),
+    so such a test item is no candidate and can never be hit, while it still counts in the row lengths (:479-482, recall's
+    denominator); users with few and with many (streamed) test items, one whose test row lies entirely inside its train row"""
+    from recometrics_amd.synth import make_problem
+    rng = np.random.default_rng(4242)
+    pr = make_problem(260, 3000 + 11, 40, dtype, mean_c=220, seed=88)
+    trp, tri = pr["train"]; tep, tei, tev = pr["test"]
+    rows = []
+    for u in range(trp.shape[0] - 1):
+        tr = tri[trp[u]:trp[u + 1]]; te = tei[tep[u]:tep[u + 1]]
+        if u % 3 == 0: add = te[rng.random(te.shape[0]) < 0.3]            # a third of its test items also in the train row
+        elif u % 11 == 1: add = te                                        # every test item is a train item
+        else: add = te[:0]
+        rows.append(np.union1d(tr, add).astype(np.int32))
+    trp2 = np.concatenate([[0], np.cumsum([r.shape[0] for r in rows])]).astype(np.int32)
+    pr["train"] = (trp2, np.concatenate(rows).astype(np.int32))
+    _check_against_oracle(hip, oracle, pr, 10, dtype=dtype, noise=noise, seed=5)
 
 
 @pytest.mark.parametrize("env", [{}, {"RM_DEBUG_RANK_GENERIC": "1"}, {"RM_DEBUG_NO_SIDE": "1"},
