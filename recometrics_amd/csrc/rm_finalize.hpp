@@ -38,6 +38,7 @@ template <class T, class S> struct FinalArgs {     // T = real_t of inputs/outpu
     int stream_slot0;
     int rank_generic;                                // A/B switch: k_rank_streamed without its fast routine
     int fin_slot0, fin_slot1;                        // slot range of a k_finalize launch
+    int auc_defer_slot0;                             // k_finalize leaves ROC / PR-AUC of the slots from here on to k_finalize_auc (n_slots = none)
     const S *stream_scores; long long stream_ld;     // [n_stream][stream_ld] masked candidate scores written by the sweep
     const S *spos_score; const int *spos_item;       // [nnz_test] sorted positives of those users at test_p[u] + rank
     unsigned *shist;             // [nnz_test] at test_p[u] + j: candidates ranking above positive j but not above positive j + 1
@@ -625,6 +626,38 @@ __global__ void k_finalize_skipped(FinalArgs<T, S> a)
     fill_user_nan(a, u);                                            // rank_sorted was zeroed by the host
 }
 
+// ROC-AUC / PR-AUC of one user from the rank sums of its slots (reference :795-865)
+template <class T, class S>
+__device__ __forceinline__ void finalize_auc(const FinalArgs<T, S> &a, int u, int base, int npos, int C)
+{
+    const int nsl = a.user_nslots[u];
+    unsigned long long sum_ranks = 0; int h = 0; double ap_full = 0;
+    for (int c = nsl - 1; c >= 0; c--) {                           // chunks hold ascending scores: combine them downwards
+        const AucPart r = a.auc_part[a.slot_index[base + c]];
+        sum_ranks += r.sum_ranks;
+        ap_full = nsl == 1 ? r.s2 : ap_full + ((double)h * r.s1 + r.s2);
+        h += r.nvalid;
+    }
+    const unsigned long long P = (unsigned long long)npos, Nneg = (unsigned long long)C - P;
+    if (a.roc) a.roc[u] = (T)(1. - (double)(sum_ranks - (P * (P + 1)) / 2) / (double)(P * Nneg));
+    if (a.pr) a.pr[u] = (T)(ap_full / (double)npos);
+}
+
+// the two AUC outputs of the users k_finalize left open (slots [auc_defer_slot0, n_slots): the streamed users when their ranks are
+// counted on the side stream)
+template <class T, class S>
+__global__ void k_finalize_auc(FinalArgs<T, S> a)
+{
+    const int slot = a.auc_defer_slot0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= a.n_slots || a.slot_chunk[slot] != 0) return;
+    const int u = a.slot_user[slot];
+    const T probe = a.roc ? a.roc[u] : a.pr[u];
+    if (probe != probe) return;                                    // invalid user, or one without AUC (only_ndcg): NaN stays
+    const int npos = a.test_p[u + 1] - a.test_p[u];
+    const int C = a.n - (a.train_p[u + 1] - a.train_p[u]);
+    finalize_auc(a, u, a.uslot_base[u], npos, C);
+}
+
 template <class T, class S>
 __global__ void k_finalize(FinalArgs<T, S> a)
 {
@@ -791,17 +824,13 @@ __global__ void k_finalize(FinalArgs<T, S> a)
         if (a.roc) a.roc[u] = qnan<T>();
         if (a.pr) a.pr[u] = qnan<T>();
     } else if (a.req & (RQ_ROC | RQ_PR)) {
-        const int nsl = a.user_nslots[u];
-        unsigned long long sum_ranks = 0; int h = 0; double ap_full = 0;
-        for (int c = nsl - 1; c >= 0; c--) {                       // chunks hold ascending scores: combine them downwards
-            const AucPart r = a.auc_part[a.slot_index[base + c]];
-            sum_ranks += r.sum_ranks;
-            ap_full = nsl == 1 ? r.s2 : ap_full + ((double)h * r.s1 + r.s2);
-            h += r.nvalid;
-        }
-        const unsigned long long P = (unsigned long long)npos, Nneg = (unsigned long long)C - P;
-        if (a.roc) a.roc[u] = (T)(1. - (double)(sum_ranks - (P * (P + 1)) / 2) / (double)(P * Nneg));
-        if (a.pr) a.pr[u] = (T)(ap_full / (double)npos);
+        if (slot >= a.auc_defer_slot0) {
+            // the rank sums of this user are still being formed on the side stream (k_rank_streamed / k_auc_streamed): everything else
+            // of the user is done here, beside them; k_finalize_auc fills these two in behind the join.  A zero says "valid, to be
+            // filled in" (an invalid user's outputs are all NaN by now and stay so)
+            if (a.roc) a.roc[u] = (T)0;
+            if (a.pr) a.pr[u] = (T)0;
+        } else finalize_auc(a, u, base, npos, C);
     }
 
 #if defined(RM_ABL_FIN_STOP) && RM_ABL_FIN_STOP == 3

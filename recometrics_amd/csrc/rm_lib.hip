@@ -749,9 +749,15 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             fa.fin_slot0 = s0; fa.fin_slot1 = s1;
             hipLaunchKernelGGL((k_finalize<T, T>), dim3(cdiv(s1 - s0, FIN_THREADS)), dim3(FIN_THREADS), fin_lds, stream, fa);
         };
-        if (ranks_beside) {
-            // the users with tables need nothing from the side stream: their metrics are formed while the streamed users' ranks are
-            // still being counted there; the streamed users' follow behind the join
+        fa.auc_defer_slot0 = n_slots;
+        if (ranks_beside && (req & (RQ_ROC | RQ_PR)) && !getenv("RM_DEBUG_NO_DEFER_AUC")) {
+            // nothing of k_finalize but the two AUC values of the streamed users needs the side stream: it runs for everybody while
+            // their ranks are still being counted there, and a short kernel fills those two in behind the join
+            fa.auc_defer_slot0 = stream_slot0;
+            finalize_slots(0, n_slots);
+            join_side();
+            hipLaunchKernelGGL((k_finalize_auc<T, T>), dim3(cdiv(n_slots - stream_slot0, 256)), dim3(256), 0, stream, fa);
+        } else if (ranks_beside) {
             finalize_slots(0, stream_slot0);
             join_side();
             finalize_slots(stream_slot0, n_slots);
