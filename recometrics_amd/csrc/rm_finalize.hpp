@@ -38,6 +38,7 @@ template <class T, class S> struct FinalArgs {     // T = real_t of inputs/outpu
     int stream_slot0;
     int rank_generic;                                // A/B switch: k_rank_streamed without its fast routine
     int fin_slot0, fin_slot1;                        // slot range of a k_finalize launch
+    int fused_auc;                                   // bit 0: k_rank_streamed also walks the counts of a row it holds whole (one block per row, table in LDS); bit 1: + the users' own test items
     int auc_defer_slot0;                             // k_finalize leaves ROC / PR-AUC of the slots from here on to k_finalize_auc (n_slots = none)
     const S *stream_scores; long long stream_ld;     // [n_stream][stream_ld] masked candidate scores written by the sweep
     const S *spos_score; const int *spos_item;       // [nnz_test] sorted positives of those users at test_p[u] + rank
@@ -244,6 +245,60 @@ __device__ __forceinline__ void rank_streamed_lds(const S *row, long long i0, in
     }
 }
 
+// One wavefront per streamed user: ranks of its positives from the counts above (descending walk), the ROC ingredients,
+// and the PR-AUC sum in the reference's own order -- left to right over the positives by descending score (:795-865) --
+// so that PR-AUC is bit-identical for these users whatever the length of the row.  `count(j)` = scores counted in bin j
+// ("exactly j + 1 positives rank below the candidate"), from the global counters (k_auc_streamed) or from the LDS of the block
+// that has just counted them (k_rank_streamed, when one block holds a user's whole row).
+template <class T, class S, class Count>
+__device__ __forceinline__ void auc_walk_streamed(const FinalArgs<T, S> &a, int slot, int te0, int P, int lane, Count count)
+{
+    unsigned long long above = 0, sum_ranks = 0;
+    double s2 = 0;
+    int nvalid = 0;
+    for (int base = P; base > 0; base -= WAVE) {
+        const int j = base - 1 - lane;                            // lane 0 holds the best remaining positive
+        const bool live = j >= 0;
+        const unsigned long long h = live ? (unsigned long long)count(j) : 0ull;
+        unsigned long long incl = h;
+        #pragma unroll
+        for (int dd = 1; dd < WAVE; dd <<= 1) {
+            const unsigned lo32 = (unsigned)__shfl_up((int)(unsigned)incl, dd), hi32 = (unsigned)__shfl_up((int)(unsigned)(incl >> 32), dd);
+            if (lane >= dd) incl += ((unsigned long long)hi32 << 32) | lo32;
+        }
+        const S ps = live ? a.spos_score[te0 + j] : (S)0;
+        const bool valid = live && !(isinf(ps) && ps > 0);        // +inf = masked by the train row
+        const unsigned long long vm = __ballot(valid);
+        const unsigned long long rank = above + incl + 1;
+        const int myidx = nvalid + __popcll(vm & ((1ull << lane) - 1ull)) + 1;
+        const double term = valid ? (double)myidx / (double)rank : 0.;
+        unsigned long long rs = valid ? rank : 0ull;
+        #pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) {
+            const unsigned lo32 = (unsigned)__shfl_xor((int)(unsigned)rs, dd), hi32 = (unsigned)__shfl_xor((int)(unsigned)(rs >> 32), dd);
+            rs += ((unsigned long long)hi32 << 32) | lo32;
+        }
+        sum_ranks += rs;
+        for (unsigned long long mm = vm; mm; mm &= mm - 1) s2 += lane_bcast<double>(term, __ffsll((long long)mm) - 1);
+        if (a.rank_sorted && valid) a.rank_sorted[te0 + j] = (long long)rank;
+        const int last = (base < WAVE ? base : WAVE) - 1;         // lane of the lowest positive of this step
+        above += ((unsigned long long)(unsigned)__shfl((int)(unsigned)(incl >> 32), last) << 32) | (unsigned)__shfl((int)(unsigned)incl, last);
+        nvalid += __popcll(vm);
+    }
+    if (lane == 0) { AucPart r; r.sum_ranks = sum_ranks; r.s1 = 0; r.s2 = s2; r.nvalid = nvalid; r.pad = 0; a.auc_part[slot] = r; }
+}
+
+// does the block of k_rank_streamed that counts a streamed user's row also walk its counts?  (one block per row, table in LDS)
+template <class S>
+__device__ __forceinline__ bool rank_block_walks(int fused_auc, int P)
+{
+    if (!(fused_auc & 1)) return false;
+    constexpr int per = (int)sizeof(S) / 4;
+    int top = 1;
+    while (top <= P) top <<= 1;
+    return (long long)top * per + P + 1 <= STREAM_RANK_LDS / 4;
+}
+
 // fp32, the usual depths (64 ... 1023 positives: the copies fill the 16 KiB table), batches that lie inside the row: the same
 // search with the sweep's instruction budget (rm_sweep.hpp auc_pass) -- 3 vector instructions and one LDS read per score and
 // level instead of the compiler's 5 + 2 scalar ones, nothing per score for validity:
@@ -393,6 +448,22 @@ __global__ __launch_bounds__(STREAM_RANK_THREADS) void k_rank_streamed(FinalArgs
         else if (full && top == 1024) rank_streamed_lds<S, 8, 10>(row, i0, ipt, a.n, pit, P, top, lgsb, tab_addr, hist_addr);
         else rank_streamed_lds<S, 8, 0>(row, i0, ipt, a.n, pit, P, top, lgsb, tab_addr, hist_addr);
         __syncthreads();
+        if (parts == 1 && (a.fused_auc & 1)) {
+            // this block has counted the user's whole row: its first wave walks the counts right here, out of LDS (k_auc_streamed's walk
+            // without the trip through the global counters and without a launch behind this one).  When the dense rows mark the
+            // users' own test items (fused_auc & 2) the sweep never saw those: positive i of the sorted table counts in bin i - 1,
+            // exactly what k_merge_positives adds to the global counters
+            if (threadIdx.x < WAVE) {
+                const bool own = (a.fused_auc & 2) != 0;
+                const S *sp = a.spos_score + te0;
+                auc_walk_streamed<T, S>(a, slot, te0, P, (int)threadIdx.x, [&](int j) {
+                    unsigned c = lds_h[j];
+                    if (own && j + 1 < P) { const S x = sp[j + 1]; c += (!(isinf(x) && x > 0) && x == x) ? 1u : 0u; }
+                    return c;
+                });
+            }
+            return;
+        }
         for (int i = threadIdx.x; i < P; i += STREAM_RANK_THREADS) { const unsigned c = lds_h[i]; if (c) atomicAdd(&a.shist[te0 + i], c); }
     } else {                                                      // very long row: search in global memory
         const S *tab = a.spos_score + te0;
@@ -516,9 +587,6 @@ __global__ __launch_bounds__(SELECT_THREADS) void k_select_topk(FinalArgs<T, S> 
     }
 }
 
-// One wavefront per streamed user: ranks of its positives from the counts above (descending walk), the ROC ingredients,
-// and the PR-AUC sum in the reference's own order -- left to right over the positives by descending score (:795-865) --
-// so that PR-AUC is bit-identical for these users whatever the length of the row.
 template <class T, class S>
 __global__ void k_auc_streamed(FinalArgs<T, S> a, int row0, int row1)
 {
@@ -528,39 +596,9 @@ __global__ void k_auc_streamed(FinalArgs<T, S> a, int row0, int row1)
     const int u = a.slot_user[slot];
     if (a.flags[u] & UF_ONLY_NDCG) return;
     const int te0 = a.test_p[u], P = a.test_p[u + 1] - te0;
-    unsigned long long above = 0, sum_ranks = 0;
-    double s2 = 0;
-    int nvalid = 0;
-    for (int base = P; base > 0; base -= WAVE) {
-        const int j = base - 1 - lane;                            // lane 0 holds the best remaining positive
-        const bool live = j >= 0;
-        const unsigned long long h = live ? (unsigned long long)a.shist[te0 + j] : 0ull;
-        unsigned long long incl = h;
-        #pragma unroll
-        for (int dd = 1; dd < WAVE; dd <<= 1) {
-            const unsigned lo32 = (unsigned)__shfl_up((int)(unsigned)incl, dd), hi32 = (unsigned)__shfl_up((int)(unsigned)(incl >> 32), dd);
-            if (lane >= dd) incl += ((unsigned long long)hi32 << 32) | lo32;
-        }
-        const S ps = live ? a.spos_score[te0 + j] : (S)0;
-        const bool valid = live && !(isinf(ps) && ps > 0);        // +inf = masked by the train row
-        const unsigned long long vm = __ballot(valid);
-        const unsigned long long rank = above + incl + 1;
-        const int myidx = nvalid + __popcll(vm & ((1ull << lane) - 1ull)) + 1;
-        const double term = valid ? (double)myidx / (double)rank : 0.;
-        unsigned long long rs = valid ? rank : 0ull;
-        #pragma unroll
-        for (int dd = 32; dd >= 1; dd >>= 1) {
-            const unsigned lo32 = (unsigned)__shfl_xor((int)(unsigned)rs, dd), hi32 = (unsigned)__shfl_xor((int)(unsigned)(rs >> 32), dd);
-            rs += ((unsigned long long)hi32 << 32) | lo32;
-        }
-        sum_ranks += rs;
-        for (unsigned long long mm = vm; mm; mm &= mm - 1) s2 += lane_bcast<double>(term, __ffsll((long long)mm) - 1);
-        if (a.rank_sorted && valid) a.rank_sorted[te0 + j] = (long long)rank;
-        const int last = (base < WAVE ? base : WAVE) - 1;         // lane of the lowest positive of this step
-        above += ((unsigned long long)(unsigned)__shfl((int)(unsigned)(incl >> 32), last) << 32) | (unsigned)__shfl((int)(unsigned)incl, last);
-        nvalid += __popcll(vm);
-    }
-    if (lane == 0) { AucPart r; r.sum_ranks = sum_ranks; r.s1 = 0; r.s2 = s2; r.nvalid = nvalid; r.pad = 0; a.auc_part[slot] = r; }
+    if (rank_block_walks<S>(a.fused_auc, P)) return;               // done by k_rank_streamed
+    const unsigned *sh = a.shist + te0;
+    auc_walk_streamed<T, S>(a, slot, te0, P, lane, [&](int j) { return sh[j]; });
 }
 
 // The L = min(K, npos) largest test VALUES of a user, descending (ideal DCG, reference :868-961), for users whose row is too

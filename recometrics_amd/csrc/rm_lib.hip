@@ -712,16 +712,26 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     fa.spos_score = spos_score; fa.spos_item = spos_item; fa.shist = shist;
     fa.rank_generic = getenv("RM_DEBUG_RANK_GENERIC") ? 1 : 0;
     const bool ranks_beside = use_side && n_slots > 0 && want_auc && n_stream > 0;
+    // one block of k_rank_streamed per row (rows up to 32,768 items) with the user's table in LDS: the block also walks its counts
+    // (k_auc_streamed's job); k_auc_streamed is then only launched when some row is too long for that
+    bool auc_launch = true;
+    if (stream_parts == 1 && !getenv("RM_DEBUG_NO_FUSED_AUC")) {
+        fa.fused_auc = 1 | (mask_test ? 2 : 0);
+        long long top = 1;
+        while (top <= hp.max_npos) top <<= 1;
+        // (k_metrics > 256 streams everybody without counting the long rows first: the longest one is not known then)
+        auc_launch = ext_topk || !(top * (long long)(sizeof(T) / 4) + hp.max_npos + 1 <= STREAM_RANK_LDS / 4);
+    }
     hipStream_t rank_stream = stream;
     if (ranks_beside) { rank_stream = fork_side(); rank_streamed_rows(0, n_stream, rank_stream); }
     if (mask_test) {
         hipLaunchKernelGGL((k_merge_positives<T, T>), dim3(cdiv(n_slots, MERGE_WAVES)), dim3(MERGE_WAVES * WAVE), 0, stream, fa, hist, n_part - 1);
-        if (ranks_beside) {                                        // (it counts the streamed users' own test items: before k_auc_streamed)
+        if (ranks_beside && auc_launch) {                          // (it counts the streamed users' own test items: before k_auc_streamed)
             HIP_CHECK(hipEventRecord(cx.side_ev[2], stream));
             HIP_CHECK(hipStreamWaitEvent(rank_stream, cx.side_ev[2], 0));
         }
     }
-    if (ranks_beside) auc_streamed_rows(0, n_stream, rank_stream);
+    if (ranks_beside && auc_launch) auc_streamed_rows(0, n_stream, rank_stream);
     hipLaunchKernelGGL((k_finalize_skipped<T, T>), dim3(cdiv(m, 256)), dim3(256), 0, stream, fa);
     if (fa.ndcg && hp.n_heavy > 0) {                            // ideal-DCG values of the users with very long test rows
         fa.heavy_topv = (T *)ws.get("heavy_topv", sizeof(T) * (size_t)m * std::min(K, FIN_TOPV));
@@ -739,7 +749,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     }
     if (n_slots > 0) {
         if (want_auc) {
-            if (n_stream > 0 && !ranks_beside) { rank_streamed_rows(0, n_stream, stream); auc_streamed_rows(0, n_stream, stream); }
+            if (n_stream > 0 && !ranks_beside) { rank_streamed_rows(0, n_stream, stream); if (auc_launch) auc_streamed_rows(0, n_stream, stream); }
             if (stream_slot0 > 0) hipLaunchKernelGGL((k_auc_slots<T, T>), dim3(cdiv(stream_slot0, 256)), dim3(256), 0, stream, fa);
         }
         const size_t fin_lds = finalize_lds_bytes<T>(K, n_part);

@@ -296,7 +296,8 @@ def test_test_items_that_are_also_train_items(hip, oracle, dtype, noise):
 
 
 @pytest.mark.parametrize("env", [{}, {"RM_DEBUG_RANK_GENERIC": "1"}, {"RM_DEBUG_NO_SIDE": "1"},
-                                 {"RM_DEBUG_RANK_GENERIC": "1", "RM_DEBUG_NO_SIDE": "1"}])
+                                 {"RM_DEBUG_RANK_GENERIC": "1", "RM_DEBUG_NO_SIDE": "1"}, {"RM_DEBUG_NO_FUSED_AUC": "1"},
+                                 {"RM_DEBUG_NO_DEFER_AUC": "1"}, {"RM_DEBUG_NO_TEST_MASK": "1"}])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_streamed_ranks_fast_routine_and_side_stream(hip, oracle, env, dtype, monkeypatch):
     """streamed users of every table depth the fast routine of k_rank_streamed is built for (64 .. 1023 test items: 128, 256, 512
@@ -307,7 +308,9 @@ def test_streamed_ranks_fast_routine_and_side_stream(hip, oracle, env, dtype, mo
     rng = np.random.default_rng(909)
     m, n, k = 96, 9000 + 37, 24
     A, B = make_factors(m, n, k, dtype, seed=3)
-    lens = [3, 40, 63, 64, 65, 100, 127, 128, 200, 255, 256, 400, 511, 512, 800, 1023, 1024, 1500]
+    # (2048 and more: the table no longer fits LDS, the search and the counters are in global memory and k_auc_streamed walks them --
+    # next to rows whose block of k_rank_streamed walks its own counts)
+    lens = [3, 40, 63, 64, 65, 100, 127, 128, 200, 255, 256, 400, 511, 512, 800, 1023, 1024, 1500, 2047, 2048, 2600, 4000]
     rows_tr, rows_te = [], []
     for u in range(m):
         nte = lens[u % len(lens)]
