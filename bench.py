@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--parity-users", type=int, default=2048, help="users of the timed outputs compared with the reference (0 = skip)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-pointer (PCIe-inclusive) measurement")
     ap.add_argument("--e2e-child", action="store_true", help=argparse.SUPPRESS)      # internal: the host-pointer leg in a process of its own
+    ap.add_argument("--sharded-child", type=int, default=0, help=argparse.SUPPRESS)  # internal: rm_set_devices([0..N-1]) against the unsharded call
+    ap.add_argument("--no-other", action="store_true", help="skip the compact legs over the other BASELINE configs (C3, C4, C5)")
     return ap.parse_args()
 
 
@@ -61,7 +63,15 @@ def respawn_under_torchrun(args):
 def host_problem(m, n, k, mean_c, seed, dtype=np.float32, shard=0):
     """The synthetic workload as host arrays (the same for the device-resident problem and for the host-pointer leg)."""
     from recometrics_amd.synth import make_factors, make_interactions
-    _, B = make_factors(1, n, k, dtype, seed)                            # item factors: the same replica on every rank
+    if (n * k) >> 28:                                                    # C4's 10M x 128: drawn in row chunks (bounded host memory)
+        rng = np.random.default_rng(seed)
+        B = np.empty((n, k), dtype=dtype)
+        sc = np.float32(1.0 / np.sqrt(k))
+        for r0 in range(0, n, 1 << 20):
+            r1 = min(n, r0 + (1 << 20))
+            B[r0:r1] = rng.standard_normal((r1 - r0, k), dtype=np.float32) * sc
+    else:
+        _, B = make_factors(1, n, k, dtype, seed)                        # item factors: the same replica on every rank
     A, _ = make_factors(m, 1, k, dtype, seed + 1 + 1000 * shard)         # this rank's user shard
     trp, tri, tep, tei, tev = make_interactions(m, n, mean_c, dtype, seed + 1000 * shard)
     return dict(A=A, B=B, train=(trp, tri), test=(tep, tei, tev))
@@ -70,7 +80,7 @@ def host_problem(m, n, k, mean_c, seed, dtype=np.float32, shard=0):
 class DeviceProblem:
     """Synthetic workload resident in HBM (torch tensors are only the memory owner; the hot path gets raw pointers)."""
 
-    def __init__(self, torch, dev, m, n, k, mean_c, seed, K, dtype=np.float32, shard=0):
+    def __init__(self, torch, dev, m, n, k, mean_c, seed, K, dtype=np.float32, shard=0, cumulative=False):
         self.m, self.n, self.k, self.K, self.dtype = m, n, k, K, dtype
         self.host = host_problem(m, n, k, mean_c, seed, dtype, shard)
         A, B = self.host["A"], self.host["B"]
@@ -79,29 +89,45 @@ class DeviceProblem:
         self.A, self.B = t(A), t(B)
         self.trp, self.tri, self.tep, self.tei, self.tev = t(trp), t(tri if tri.size else np.zeros(1, np.int32)), t(tep), t(tei), t(tev)
         self.nnz_tr, self.nnz_te = int(tri.shape[0]), int(tei.shape[0])
-        self.out = torch.empty((10, m), dtype=torch.float32 if dtype == np.float32 else torch.float64, device=dev)   # per-user metric block
+        self.cumulative = bool(cumulative)
+        tdt = torch.float32 if dtype == np.float32 else torch.float64
+        if not self.cumulative:
+            self.out = torch.empty((10, m), dtype=tdt, device=dev)           # per-user metric block
+            self.out_ptrs = lambda o: [o[i].data_ptr() for i in range(10)]     # noqa: E731
+        else:                                                                # eight [m, K] blocks, then ROC / PR-AUC [m]
+            self.out = torch.empty((8 * K + 2) * m, dtype=tdt, device=dev)
+            es = self.out.element_size()
+            self.out_ptrs = lambda o: [o.data_ptr() + es * (i * K * m if i < 8 else 8 * K * m + (i - 8) * m) for i in range(10)]   # noqa: E731
+
+    def metric(self, o, i):
+        """metric i of the output block `o` as a [m] / [m, K] tensor"""
+        if not self.cumulative:
+            return o[i]
+        K, m = self.K, self.m
+        return o[i * K * m:(i + 1) * K * m].view(m, K) if i < 8 else o[8 * K * m + (i - 8) * m:8 * K * m + (i - 7) * m]
 
     def step(self, binding, stream, out=None, noise=False):
         o = self.out if out is None else out
         binding.calc_metrics_device(
             self.dtype, self.A.data_ptr(), self.k, self.B.data_ptr(), self.k, self.m, self.n, self.k,
             self.trp.data_ptr(), self.tri.data_ptr(), self.nnz_tr, self.tep.data_ptr(), self.tei.data_ptr(),
-            self.tev.data_ptr(), self.nnz_te, self.K, [o[i].data_ptr() for i in range(10)],
-            cumulative=False, break_ties_with_noise=noise, stream=stream)
+            self.tev.data_ptr(), self.nnz_te, self.K, self.out_ptrs(o),
+            cumulative=self.cumulative, break_ties_with_noise=noise, stream=stream)
 
 
 def load_traffic(workload, users):
     """HBM bytes per sweep launch from the committed PMC run (scratch/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in
-    separate rocprofv3 passes, FETCH_SIZE doubled per the gfx950 correction); None when no matching profile exists."""
-    for rnd in ("r3", "r2"):                                  # the newest committed profile of this workload and user count
-        path = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (rnd, workload))
+    separate rocprofv3 passes, FETCH_SIZE doubled per the gfx950 correction) and the file it was read from -- a constant of
+    that profile, not a counter of this run; (None, None) when no matching profile exists."""
+    for rnd in ("r4", "r3", "r2"):                            # the newest committed profile of this workload and user count
+        rel = os.path.join("profiles", "%s_traffic_%s.json" % (rnd, workload))
         try:
-            d = json.load(open(path))
+            d = json.load(open(os.path.join(ROOT, rel)))
             if int(d.get("users", -1)) == int(users):
-                return d["hbm_bytes"]
+                return d["hbm_bytes"], rel
         except Exception:      # noqa: BLE001
             pass
-    return None
+    return None, None
 
 
 def stratified_users(host, n_users, seed=0):
@@ -143,37 +169,58 @@ def sub_problem(host, users):
     return host["A"][users], host["B"], (ntrp, ntri), (ntep, ntei, ntev)
 
 
-def parity_check(prob, out, n_users, noise=False, seed=1):
+def parity_check(prob, out, n_users, noise=False, seed=1, cpu_seconds=15.0, binding=None):
     """verify parity on the same inputs in the same run before accepting a number -- a stratified sample of
-    the users of the timed outputs (`out`: the [10, m] metric block on the device) against the REAL reference compiled by
+    the users of the timed outputs (`out`: the metric block on the device) against the REAL reference compiled by
     oracle/Makefile (oracle/_ref, canonical build) when it is present, else against the restatement: metrics within 1e-5,
     identical NaN pattern.  With `noise` the reference draws its mt19937(seed + user) tie noise per ORIGINAL user index, so
     the sample is evaluated user by user range: contiguous runs keep their indices through `user0`-free calls only when they
-    start at 0 -- the noise check therefore uses the first users plus nothing else."""
+    start at 0 -- the noise check therefore uses the first users plus nothing else.
+    Every sampled user whose metrics differ from the reference's in any BIT (ROC-AUC apart: x87 long double there) must have
+    an exactly tied score on one of its positives (deviation D4: the reference leaves tied scores in libstdc++'s order,
+    oracle/ties.py) -- `tie_users` counts them, a differing user without such a tie fails the check."""
     from oracle import oracle as orc
+    from oracle.ties import tie_pairs_per_user
     host = prob.host
     # a bounded amount of CPU work: the reference evaluates ~7e9 (item x factor) products per second on the box's cores
     # (4,300 users/s at C2), so ~15 s allow 1e11 / (n k) users -- 2,048 at C2 and C3, ~800 at the north-star shape, ~90 at C4
-    n_users = int(max(64, min(n_users, 1.1e11 / (float(prob.n) * float(prob.k)))))
+    n_users = int(max(16, min(n_users, cpu_seconds * 7.0e9 / (float(prob.n) * float(prob.k)))))
     users = np.arange(min(n_users, prob.m)) if noise else stratified_users(host, n_users)
     A, B, tr, te = sub_problem(host, users)
     impl, kind = (orc.Reference(), "reference") if orc.reference_available() else (orc.Oracle(), "port")
     # (the reference addresses its per-thread scratch as thread * n in int32, src/recometrics.hpp:499: at n = 10M more than 214
     # threads overflow it)
     nthreads = max(1, min(256, os.cpu_count() or 1, (2 ** 31 - 1) // int(B.shape[0])))
-    want = impl.calc(A, B, tr, te, prob.K, nthreads=nthreads, noise=noise, seed=seed, dtype=prob.dtype)
-    got = out[:, torch_index(out, users)].cpu().numpy()
+    want = impl.calc(A, B, tr, te, prob.K, nthreads=nthreads, noise=noise, seed=seed, dtype=prob.dtype, cumulative=prob.cumulative)
+    uidx = torch_index(out, users)
     info = {"users": int(users.shape[0]), "checker": kind, "streamed_users": int((np.diff(te[0]) > 63).sum()),
             "cold_users": int((np.diff(tr[0]) == 0).sum()), "sample": "first users" if noise else "stratified"}
     worst = 0.0
+    differing = np.zeros(users.shape[0], bool)
     for i, name in enumerate(orc.METRICS):
-        w, g = want[orc.NAMES[name]], got[i]
+        w = want[orc.NAMES[name]]
+        g = prob.metric(out, i)[uidx].cpu().numpy()
         if not (np.isnan(w) == np.isnan(g)).all():
             return dict(info, ok=False, what="NaN pattern of %s" % name)
         d = float(np.nanmax(np.abs(w.astype(np.float64) - g.astype(np.float64)), initial=0.0))
         worst = max(worst, d)
         if d > 1e-5:
             return dict(info, ok=False, what="%s differs by %g" % (name, d))
+        if name != "roc":
+            bits = np.uint32 if g.dtype == np.float32 else np.uint64
+            same = (np.ascontiguousarray(g).view(bits) == np.ascontiguousarray(w).view(bits)) | (np.isnan(g) & np.isnan(w))
+            differing |= ~same.reshape(users.shape[0], -1).all(axis=1)
+    info["bitwise_differing_users"] = int(differing.sum())
+    if differing.any() and binding is not None and kind == "reference":
+        who = np.flatnonzero(differing)[:128]                  # (a dense score row per user: bounded)
+        sc = binding.debug_scores(np.ascontiguousarray(A[who]), np.ascontiguousarray(B))
+        pairs = tie_pairs_per_user(sc, tr, te, who, noise_zone=(2.0 ** -14 if noise and prob.dtype == np.float32 else None))
+        info["tie_users_checked"] = int(who.shape[0])
+        info["tie_users"] = int((pairs > 0).sum())
+        if (pairs == 0).any():
+            return dict(info, ok=False, what="users %s differ from the reference in a bit without an exact tie on a positive" % users[who[pairs == 0]][:5].tolist())
+    else:
+        info["tie_users"] = 0
     return dict(info, ok=True, max_abs_diff=worst)
 
 
@@ -204,8 +251,43 @@ def e2e_host_measure(binding, host, k, K, dtype, reps=5):
                     "never `value`" % ("f32" if dtype == np.float32 else "f64")}
 
 
+def api_default_measure(host, k, K, dtype, reps=5):
+    """The call a user makes: recometrics_amd.calc_reco_metrics(X_train, X_test, A, B, k=10, all_metrics=True, as_df=False)
+    -- the API defaults otherwise: break_ties_with_noise=True, nthreads=-1 -- with SciPy CSR matrices in (reference
+    recometrics/__init__.py:553-562).  Every repetition gets FRESH csr_array objects over the same buffers, so SciPy does not
+    know whether their indices are sorted and the library's multi-threaded check runs each time (csrc/rm_csr.cpp)."""
+    import scipy.sparse as sp
+    import recometrics_amd
+    trp, tri = host["train"]
+    tep, tei, tev = host["test"]
+    m, n = host["A"].shape[0], host["B"].shape[0]
+    ones = np.ones(tri.shape[0], dtype)
+
+    def fresh():
+        return (sp.csr_array((ones, tri, trp), shape=(m, n), copy=False), sp.csr_array((tev, tei, tep), shape=(m, n), copy=False))
+
+    def call(mats):
+        t0 = time.perf_counter()
+        out = recometrics_amd.calc_reco_metrics(mats[0], mats[1], host["A"], host["B"], k=K, all_metrics=True, as_df=False)
+        return (time.perf_counter() - t0) * 1e3, out
+    first, _ = call(fresh())
+    times = sorted(call(fresh())[0] for _ in range(reps))
+    mats = fresh()
+    call(mats)
+    same = sorted(call(mats)[0] for _ in range(reps))          # the same objects again: SciPy's flag is set, no check at all
+    t0 = time.perf_counter()
+    xs = fresh()
+    xs[0].sort_indices(); xs[1].sort_indices()
+    scipy_ms = (time.perf_counter() - t0) * 1e3
+    return {"first_call_ms": first, "ms": times[len(times) // 2], "same_objects_ms": same[len(same) // 2],
+            "users_per_s": m / (times[len(times) // 2] * 1e-3), "scipy_sort_indices_ms": scipy_ms,
+            "what": "recometrics_amd.calc_reco_metrics(X_train, X_test, A, B, k=%d, all_metrics=True, as_df=False): noise on, SciPy CSR in, "
+                    "fresh matrix objects per call (sortedness unknown to SciPy), torch-free process; `scipy_sort_indices_ms` = what "
+                    "SciPy's own single-threaded pass over the two matrices takes on this host (the reference's path); never `value`" % K}
+
+
 def e2e_child_main(args):
-    """`bench.py --e2e-child`: the host-pointer leg alone, no torch in the process; prints one JSON object."""
+    """`bench.py --e2e-child`: the host-pointer leg and the Python-API leg, no torch in the process; prints one JSON object."""
     from recometrics_amd import _binding as binding
     from recometrics_amd.synth import CONFIGS
     m, n, k, dtype, K, mean_c, seed = CONFIGS[args.workload]
@@ -215,14 +297,57 @@ def e2e_child_main(args):
         m = args.users
     binding.load()
     host = host_problem(m, n, k, mean_c, seed, dtype)
-    print(json.dumps(e2e_host_measure(binding, host, k, K, dtype)))
+    res = {"e2e_host": e2e_host_measure(binding, host, k, K, dtype)}
+    try:
+        res["api_default"] = api_default_measure(host, k, K, dtype)
+    except Exception as e:      # noqa: BLE001
+        res["api_default"] = {"error": repr(e)}
+    print(json.dumps(res))
 
 
-def e2e_host(args, m):
-    """Runs the host-pointer leg as a child process (started from this one, which keeps running: never an exec)."""
+def sharded_child_main(args):
+    """`bench.py --sharded-child N`: the workload through rm_set_devices([0 .. N-1]) in ONE process (one host thread, stream and
+    workspace per device, item factors fanned out device to device) against the unsharded call on device 0: every output
+    array must be bit-identical.  No torch in the process."""
+    from recometrics_amd import _binding as binding
+    from recometrics_amd.synth import CONFIGS
+    m, n, k, dtype, K, mean_c, seed = CONFIGS[args.workload]
+    if args.workload == "C3":
+        m = m // 8
+    if args.users:
+        m = args.users
+    binding.load()
+    ndev = binding.device_count()
+    devices = [i % max(ndev, 1) for i in range(args.sharded_child)]
+    host = host_problem(m, n, k, mean_c, seed, dtype)
+    trp, tri = host["train"]
+    tep, tei, tev = host["test"]
+    want = {name: True for name in binding.METRIC_ORDER}
+
+    def call():
+        t0 = time.perf_counter()
+        o = binding.calc_metrics(host["A"], k, host["B"], k, trp, tri if tri.size else np.zeros(1, np.int32), tep, tei, tev,
+                                 K, want, False, False, True, 2, 1, 1, 1)
+        return (time.perf_counter() - t0) * 1e3, o
+    binding.set_devices([0])
+    call()
+    t_one, base = call()
+    binding.set_devices(devices)
+    call()
+    t_sh, got = call()
+    binding.set_devices([])
+    bits = np.uint32 if dtype == np.float32 else np.uint64
+    same = all(((a.view(bits) == b.view(bits)) | (np.isnan(a) & np.isnan(b))).all() for a, b in zip(base, got))
+    print(json.dumps({"devices": devices, "distinct_devices": len(set(devices)), "visible_devices": ndev, "users": m,
+                      "bitwise_equal_to_unsharded": bool(same), "unsharded_ms": t_one, "sharded_ms": t_sh,
+                      "what": "rm_calc_metrics_* (host pointers) with rm_set_devices(%s) against rm_set_devices([0]); second call of each" % devices}))
+
+
+def run_child(args, m, extra):
+    """Runs a leg as a child process (started from this one, which keeps running: never an exec)."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--e2e-child", "--workload", args.workload, "--users", str(m)]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--users", str(m)] + extra
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     if res.returncode != 0 or not lines:
         return {"error": "child failed (%d): %s" % (res.returncode, res.stderr[-400:])}
@@ -324,6 +449,9 @@ def main():
     if args.e2e_child:                                       # (before torch is imported: that is the point)
         e2e_child_main(args)
         return
+    if args.sharded_child:
+        sharded_child_main(args)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(args)
     import torch
@@ -349,6 +477,27 @@ def main():
     binding.load()
     binding.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # A multi-GPU line is only worth something if the ranks really are N processes on N DISTINCT devices talking through RCCL:
+    # every rank reports (host, device identity), and the run is refused otherwise (RM_BENCH_BACKEND=gloo, the tests' stand-in
+    # on a one-GPU box, is reported as such and not refused)
+    self_check = None
+    if world > 1:
+        import socket
+        props = torch.cuda.get_device_properties(local_rank)
+        ident = (socket.gethostname(), str(getattr(props, "uuid", "")), str(getattr(props, "pci_bus_id", "")), local_rank)
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        distinct = len({(h, u, b) if (u or b) else (h, i) for h, u, b, i in idents})
+        distinct_idx = len({(h, i) for h, _, _, i in idents})
+        ok = (rccl_ranks == args.gpus == world) and comm_backend == "nccl" and distinct == world and distinct_idx == world
+        self_check = {"ok": bool(ok), "rccl_ranks": rccl_ranks, "gpus_asked": args.gpus, "comm_backend": comm_backend,
+                      "distinct_devices": min(distinct, distinct_idx), "devices": ["%s:%d %s" % (h, i, b or u) for h, u, b, i in idents]}
+        if not ok and backend == "nccl":
+            if rank == 0:
+                print(json.dumps({"error": "bench.py --gpus %d: not %d RCCL ranks on %d distinct devices" % (args.gpus, args.gpus, args.gpus),
+                                  "multi_gpu_self_check": self_check}))
+            dist.destroy_process_group()
+            sys.exit(3)
 
     m, n, k, dtype, K, mean_c, seed = CONFIGS[args.workload]
     if args.workload == "C3":
@@ -388,7 +537,9 @@ def main():
                    "users_per_gpu": m, "n_items": n, "n_factors": k, "k_metrics": K,
                    "sharding": "users sharded, item factors replicated, 1 all-gather of the metric block per step (overlapped with the next step)"},
         "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s",
-                     "frac": achieved_tf / peak, "traffic": load_traffic(args.workload, m),
+                     "frac": achieved_tf / peak, "traffic": load_traffic(args.workload, m)[0],
+                     "traffic_source": ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of the same command, committed; a constant of that "
+                                        "profile, not a counter of this run)" % load_traffic(args.workload, m)[1]) if load_traffic(args.workload, m)[1] else None,
                      "kernel": "k_sweep (main launch: %.1f %% of the users)" % (100 * share), "avg_launch_ms": sweep_ms, "flops_per_launch": flops_per_launch,
                      "hbm_equiv_GBs": n * k * esize * m * share / (sweep_ms * 1e-3) / 1e9,
                      "hbm_equiv_frac": n * k * esize * m * share / (sweep_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
@@ -399,7 +550,7 @@ def main():
     failed = False
     if rank == 0 and args.parity_users > 0:
         try:
-            pc = parity_check(prob, prob.out, args.parity_users)
+            pc = parity_check(prob, prob.out, args.parity_users, binding=binding)
         except Exception as e:      # noqa: BLE001
             pc = {"users": 0, "ok": False, "what": repr(e)}
         line["parity_checked"] = pc["users"] if pc["ok"] else 0
@@ -407,7 +558,9 @@ def main():
         failed = not pc["ok"]
     if rank == 0 and world == 1 and not args.no_e2e:
         try:
-            line["e2e_host"] = e2e_host(args, m)
+            child = run_child(args, m, ["--e2e-child"])
+            line["e2e_host"] = child.get("e2e_host", child)
+            line["api_default"] = child.get("api_default", {"error": "no result"})
         except Exception as e:      # noqa: BLE001
             line["e2e_host"] = {"error": repr(e)}
 
@@ -429,7 +582,7 @@ def main():
                                 "steps": 10, "warmup": 2,
                                 "what": "same workload with break_ties_with_noise=True (the API default), seed 1; never `value`"}
             if args.parity_users > 0:
-                line["noise_on"]["parity"] = parity_check(prob, scratch_out, min(args.parity_users, 1024), noise=True, seed=1)
+                line["noise_on"]["parity"] = parity_check(prob, scratch_out, min(args.parity_users, 1024), noise=True, seed=1, binding=binding)
                 failed = failed or not line["noise_on"]["parity"]["ok"]
             del scratch_out
         except Exception as e:      # noqa: BLE001
@@ -456,11 +609,59 @@ def main():
                 "hbm_equiv_GBs": n2 * k2 * 4.0 * m2 * sh2 / (sw2 * 1e-3) / 1e9,
                 "hbm_equiv_frac": n2 * k2 * 4.0 * m2 * sh2 / (sw2 * 1e-3) / 1e9 / PEAK_HBM_GBS}
             if args.parity_users > 0:
-                line["north_star_shape"]["parity"] = parity_check(p2, p2.out, min(args.parity_users, 512))
+                line["north_star_shape"]["parity"] = parity_check(p2, p2.out, min(args.parity_users, 512), binding=binding)
                 failed = failed or not line["north_star_shape"]["parity"]["ok"]
             del p2
         except Exception as e:      # noqa: BLE001
             line["north_star_shape"] = {"error": repr(e)}
+
+    if rank == 0 and world == 1 and not args.no_extra and not args.no_other:
+        # every other BASELINE config in the same driver-run line, as compact legs: 3 timed steps after 1 warm-up, the sweep's
+        # fraction of the MFMA peak, and a parity sample against the compiled reference bounded to ~5 s of CPU work each
+        others = {}
+        specs = [("C3", 125000, True, "C3: 1M users over 8 GPUs = 125,000 users per GPU, cumulative K = 1..20"),
+                 ("C4", 8192, False, "C4: a slice of 8,192 of its 100,000 users at the full 10M items, K = 100 + AUC"),
+                 ("C5", 16384, False, "C5: a slice of 16,384 of its 200,000 users (50,000 per GPU on 4), 256 factors fp64, K = 50")]
+        for wname, mo, cum, what in specs:
+            if wname == args.workload:
+                continue
+            try:
+                _, no, ko, dto, Ko, co, so = CONFIGS[wname]
+                if "prob" in locals() and hasattr(prob, "A"):
+                    del prob.A, prob.B
+                torch.cuda.empty_cache()
+                po = DeviceProblem(torch, dev, mo, no, ko, co, so, Ko, dto, cumulative=cum)
+                dto_, swo, pro, fio, _ = measure(torch, dist, binding, po, 3, 1, 1, None)
+                tmo = binding.timings()
+                sho = (tmo.get("timed_slots") or 0) / tmo["total_slots"] if tmo.get("total_slots") else 1.0
+                pk = PEAK_FP32_MFMA_TFLOPS if dto == np.float32 else PEAK_FP64_MFMA_TFLOPS
+                tfo = 2.0 * no * ko * mo * sho / (swo * 1e-3) / 1e12
+                others[wname] = {"workload": what, "users": mo, "n_items": no, "n_factors": ko, "k_metrics": Ko, "cumulative": cum,
+                                 "dtype": "f32" if dto == np.float32 else "f64", "steps": 3, "warmup": 1,
+                                 "users_per_s": mo * 3 / dto_, "ms_per_step": dto_ / 3 * 1e3, "sweep_ms": swo, "prep_ms": pro, "finalize_ms": fio,
+                                 "mfma_TFLOPs": tfo, "mfma_peak_TFLOPs": pk, "mfma_frac": tfo / pk}
+                if args.parity_users > 0:
+                    others[wname]["parity"] = parity_check(po, po.out, min(args.parity_users, 512), cpu_seconds=5.0, binding=binding)
+                    failed = failed or not others[wname]["parity"]["ok"]
+                del po
+                binding.load().rm_release_workspace()
+                torch.cuda.empty_cache()
+            except Exception as e:      # noqa: BLE001
+                others[wname] = {"error": repr(e)}
+        line["other_configs"] = others
+
+    if world > 1:
+        # the first real multi-GPU run checks itself: the same workload through rm_set_devices([0 .. N-1]) in ONE (torch-free)
+        # process must equal the unsharded call bit for bit -- two distinct devices, peer copies of the item factors over xGMI
+        line["multi_gpu_self_check"] = self_check
+        if rank == 0:
+            try:
+                line["sharded_host"] = run_child(args, m, ["--sharded-child", str(world)])
+                if line["sharded_host"].get("bitwise_equal_to_unsharded") is False:
+                    failed = True
+            except Exception as e:      # noqa: BLE001
+                line["sharded_host"] = {"error": repr(e)}
+        dist.barrier()
 
     if rank == 0 and world == 1 and not args.no_cpu:
         try:

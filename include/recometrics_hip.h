@@ -172,6 +172,16 @@ int rm_split_copy(const void *result, int which, void *dst);    /* copies array 
 void rm_split_free(void *result);
 const char *rm_split_last_error(void);
 
+/* ---- CSR normalisation in front of the metric call (host only) --------------------------------------------------------
+ * Replaces the `X.sort_indices()` of the reference's Python caller (recometrics/__init__.py:35-41 `_as_csr`, applied to X_train
+ * and X_test at :553-562; the R caller's `sort_sparse_indices`, R/recometrics.R): SciPy's single-threaded pass over every
+ * stored entry becomes a pass over row ranges on `nthreads` host threads (<= 0: all).
+ * rm_csr_rows_sorted: 1 = the column indices of every row ascend (equal neighbours allowed, as SciPy's has_sorted_indices),
+ *   0 = some row does not, -1 = bad argument.  rm_csr_sort_rows: sorts every row's (index, value) pairs by index, in place,
+ *   stable; `values` are `value_bytes` (0 = no values, 4, 8) wide. */
+int rm_csr_rows_sorted(const int32_t *indptr, const int32_t *indices, int32_t m, int32_t nthreads);
+int rm_csr_sort_rows(const int32_t *indptr, int32_t *indices, void *values, int32_t value_bytes, int32_t m, int32_t nthreads);
+
 #ifdef __cplusplus
 }
 #endif

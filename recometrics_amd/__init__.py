@@ -41,14 +41,30 @@ def _row_major_with_ld(X):
     return np.ascontiguousarray(X), X.shape[1]          # reversed / overlapping / unaligned rows: a size_t cannot express them
 
 
-def _sorted_csr_int32(X):
-    """CSR with sorted column indices and int32 index arrays (reference __init__.py:26-41; sorts in place, like it)."""
+def _sorted_csr_int32(X, nthreads=0):
+    """CSR with sorted column indices and int32 index arrays (reference __init__.py:26-41; sorts in place, like it).
+
+    SciPy's `sort_indices()` walks every stored entry on one thread whenever it does not already know the answer (26-33 ms
+    for the two matrices of BASELINE C2 in front of a 10 ms device call): a matrix whose flag is set is trusted, otherwise the
+    check -- and the sort, should it be needed -- run in the library on `nthreads` host threads (csrc/rm_csr.cpp) and the
+    flag is set, so the next call on the same matrix is free, as with SciPy."""
     from scipy.sparse import csr_array, issparse
     X = X.tocsr() if issparse(X) and X.format != "csr" else (X if issparse(X) else csr_array(X))
-    X.sort_indices()
     if X.indptr.dtype != np.int32 or X.indices.dtype != np.int32:
+        known = getattr(X, "_has_sorted_indices", None)
         X = X.copy()
         X.indptr, X.indices = X.indptr.astype(np.int32), X.indices.astype(np.int32)
+        if known:
+            X.has_sorted_indices = True
+    if getattr(X, "_has_sorted_indices", None) is True:       # SciPy's cached answer (set by its own sort / check, or by us below)
+        return X
+    if not (X.indices.flags.c_contiguous and X.indptr.flags.c_contiguous and X.data.flags.c_contiguous
+            and X.data.dtype.itemsize in (4, 8) and X.indices.flags.writeable and X.data.flags.writeable):
+        X.sort_indices()                                        # unusual storage: SciPy's own pass
+        return X
+    if not _binding.csr_rows_sorted(X.indptr, X.indices, nthreads):
+        _binding.csr_sort_rows(X.indptr, X.indices, X.data, nthreads)
+    X.has_sorted_indices = True
     return X
 
 
@@ -207,10 +223,10 @@ def calc_reco_metrics(
         A, B = _fold_item_biases(A, B, item_biases, n_items, dtype)
 
     # ---- normalise storage: sorted int32 CSR, test values and factors in `dtype`, row-major factors ----
-    X_train = _sorted_csr_int32(X_train)
+    X_train = _sorted_csr_int32(X_train, nthreads)
     if X_train.shape[0] > n_users:
-        X_train = _sorted_csr_int32(X_train[:n_users])
-    X_test = _sorted_csr_int32(X_test)
+        X_train = _sorted_csr_int32(X_train[:n_users], nthreads)
+    X_test = _sorted_csr_int32(X_test, nthreads)
     if X_test.dtype != dtype:
         X_test = X_test.astype(dtype)
     A, lda = _row_major_with_ld(A.astype(dtype, copy=False))

@@ -21,6 +21,7 @@ EXPORTS = (
     "rm_last_error", "rm_device_count", "rm_set_device", "rm_set_devices", "rm_get_devices", "rm_request_interrupt",
     "rm_get_timings", "rm_release_workspace",
     "rm_split_f32", "rm_split_f64", "rm_split_size", "rm_split_copy", "rm_split_free", "rm_split_last_error",
+    "rm_csr_rows_sorted", "rm_csr_sort_rows",
 )
 
 
@@ -64,6 +65,10 @@ def load():
     lib.rm_split_free.argtypes = [vp]
     lib.rm_split_free.restype = None
     lib.rm_split_last_error.restype = C.c_char_p
+    lib.rm_csr_rows_sorted.argtypes = [vp, vp, i32, i32]
+    lib.rm_csr_rows_sorted.restype = ci
+    lib.rm_csr_sort_rows.argtypes = [vp, vp, vp, i32, i32, i32]
+    lib.rm_csr_sort_rows.restype = ci
     lib.rm_last_error.restype = C.c_char_p
     lib.rm_get_timings.argtypes = [C.POINTER(C.c_double), ci]
     lib.rm_set_device.argtypes = [ci]
@@ -162,6 +167,28 @@ def timings():
     keys = ("prep_ms", "sweep_ms", "finalize_ms", "device_ms", "sweep_launches", "item_splits", "sweep_blocks", "lds_bytes",
             "timed_slots", "total_slots")
     return {k: buf[i] for i, k in enumerate(keys[:n])}
+
+
+def csr_rows_sorted(indptr, indices, nthreads=0):
+    """True when the column indices of every row of an int32 CSR ascend (rm_csr_rows_sorted: multi-threaded pass)."""
+    lib = load()
+    assert indptr.dtype == np.int32 and indices.dtype == np.int32
+    rc = lib.rm_csr_rows_sorted(_p(indptr), _p(indices), indptr.shape[0] - 1, int(nthreads))
+    if rc < 0:
+        raise ValueError("rm_csr_rows_sorted: bad argument")
+    return bool(rc)
+
+
+def csr_sort_rows(indptr, indices, data, nthreads=0):
+    """Sorts every row's (index, value) pairs by index, in place (rm_csr_sort_rows); `data` may be None."""
+    lib = load()
+    assert indptr.dtype == np.int32 and indices.dtype == np.int32 and indices.flags.writeable
+    vb = 0 if data is None else data.dtype.itemsize
+    if vb not in (0, 4, 8):
+        raise ValueError("values must be 4 or 8 bytes wide")
+    rc = lib.rm_csr_sort_rows(_p(indptr), _p(indices), None if data is None else _p(data), vb, indptr.shape[0] - 1, int(nthreads))
+    if rc:
+        _raise(lib, rc)
 
 
 def _suffix(dtype):

@@ -10,7 +10,7 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "librecometrics_hip.so")
 SOURCES = ["rm_lib.hip", "rm_sweep32.hip", "rm_sweep32_hbm.hip", "rm_sweep32_n3.hip", "rm_sweep32_large.hip",
-           "rm_sweep64_small.hip", "rm_sweep64_large.hip", "rm_split.cpp"]
+           "rm_sweep64_small.hip", "rm_sweep64_large.hip", "rm_split.cpp", "rm_csr.cpp"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-inline-asm"]   # m0 is clobbered by the LDS-DMA asm on purpose
 
 
@@ -44,7 +44,7 @@ def _compile(src, extra):
     if src.startswith("rm_sweep"):
         extra = list(extra) + SWEEP_FLAGS
     if src.endswith(".cpp"):        # host-only translation unit
-        cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", "-fPIC", "-pthread", "-c", os.path.join(CSRC, src), "-o", obj]
     else:
         cmd = [_hipcc()] + FLAGS + list(extra) + ["-c", os.path.join(CSRC, src), "-o", obj]
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -44,6 +44,15 @@ struct RmError { int code; std::string msg; };
                           std::string(#expr) + ": " + hipGetErrorString(e_)};                             \
     } while (0)
 
+// bytes the cached workspaces of ALL contexts hold (RM_DEBUG_FREE_MB: tests simulate a device with that much memory, so that
+// the memory-bound regimes -- user batches sized by the score rows of k_metrics > 256 -- are reached with small inputs)
+std::atomic<long long> g_ws_bytes{0};
+inline long long debug_free_cap()
+{
+    const char *e = getenv("RM_DEBUG_FREE_MB");
+    return e ? (atoll(e) << 20) : -1;
+}
+
 // ---- cached device workspace (per device), so that repeated calls do not pay hipMalloc ----
 struct Workspace {
     std::map<std::string, std::pair<void *, size_t>> bufs;
@@ -52,17 +61,21 @@ struct Workspace {
         bytes = std::max<size_t>(bytes, 256);
         auto &b = bufs[name];
         if (b.second < bytes) {
-            if (b.first) { (void)hipFree(b.first); b.first = nullptr; b.second = 0; }
+            if (b.first) { (void)hipFree(b.first); g_ws_bytes -= (long long)b.second; b.first = nullptr; b.second = 0; }
             const size_t cap = bytes + bytes / 8;
+            const long long sim = debug_free_cap();
+            if (sim >= 0 && g_ws_bytes.load() + (long long)cap > sim)
+                throw RmError{RM_ERR_NOMEM, "hipMalloc(" + name + ", " + std::to_string(cap) + " B): beyond RM_DEBUG_FREE_MB"};
             hipError_t e = hipMalloc(&b.first, cap);
             if (e != hipSuccess) { b.first = nullptr; throw RmError{RM_ERR_NOMEM, "hipMalloc(" + name + ", " + std::to_string(cap) + " B): " + hipGetErrorString(e)}; }
             b.second = cap;
+            g_ws_bytes += (long long)cap;
         }
         return b.first;
     }
     void release()
     {
-        for (auto &kv : bufs) if (kv.second.first) (void)hipFree(kv.second.first);
+        for (auto &kv : bufs) if (kv.second.first) { (void)hipFree(kv.second.first); g_ws_bytes -= (long long)kv.second.second; }
         bufs.clear();
     }
 };
@@ -268,6 +281,8 @@ inline long long free_plus_owned(const Workspace &ws, std::initializer_list<cons
 {
     size_t fr = 0, tot = 0;
     HIP_CHECK(hipMemGetInfo(&fr, &tot));
+    const long long sim = debug_free_cap();
+    if (sim >= 0) fr = (size_t)std::max<long long>(0, std::min<long long>((long long)fr, sim - g_ws_bytes.load()));
     long long owned = 0;
     for (const char *nm : names) { auto it = ws.bufs.find(nm); if (it != ws.bufs.end()) owned += (long long)it->second.second; }
     return (long long)fr + owned;
@@ -286,9 +301,9 @@ inline bool dense_rows_fit(int m, long long n_pad)
     const long long words = (n_pad + 31) / 32;
     return (size_t)m * (size_t)words * 4 <= ((size_t)1 << 30) && words <= TRAIN_BITS_MAX_WORDS && !getenv("RM_DEBUG_NO_TRAIN_BITS");
 }
-// `mask_test`: the rows mark the users' TEST items as well (k_merge_positives puts them back after the sweep); `want_pure`: also
-// keep the rows of the train items alone (the tie noise of a later pass indexes its draws by them)
-template <class C> inline void set_train_bits(SweepArgs &sa, Ctx &cx, const C &c, int m, int n, long long n_pad, hipStream_t stream, bool mask_test, bool want_pure)
+// `mask_test`: the rows mark the users' TEST items as well (k_merge_positives puts them back after the sweep; rm_noise.hpp clears
+// the test items' bits in its own copy of a row)
+template <class C> inline void set_train_bits(SweepArgs &sa, Ctx &cx, const C &c, int m, int n, long long n_pad, hipStream_t stream, bool mask_test)
 {
     Workspace &ws = cx.ws;
     const long long words = (n_pad + 31) / 32;
@@ -296,20 +311,18 @@ template <class C> inline void set_train_bits(SweepArgs &sa, Ctx &cx, const C &c
     sa.train_bits = nullptr; sa.train_words = 0;
     if (!dense_rows_fit(m, n_pad)) { cx.bits_tag = 0; return; }
     unsigned *bits = (unsigned *)ws.get("train_bits", bytes);
-    unsigned *pure = nullptr;                                      // (rm_noise.hpp clears the test items' bits in its own copy of a row)
-    (void)want_pure;
     // (the exact second pass of the tie noise evaluates a subset of the same users: the rows of the first pass are still there)
     const bool ready = c.same_train_rows && cx.bits_ptr == (const void *)bits && cx.bits_words == words && cx.bits_m == m && cx.bits_masked == mask_test;
     if (!ready) {
         const unsigned blocks = (unsigned)std::min<long long>(((long long)m + TRAIN_BITS_WAVES - 1) / TRAIN_BITS_WAVES, 256 * 8);
         hipLaunchKernelGGL(k_train_bits, dim3(blocks), dim3(TRAIN_BITS_WAVES * WAVE), sizeof(unsigned) * (size_t)TRAIN_BITS_WAVES * (size_t)words, stream,
-                           m, n, (int)words, c.train_p, c.train_i, mask_test ? c.test_p : nullptr, c.test_i, bits, pure);
+                           m, n, (int)words, c.train_p, c.train_i, mask_test ? c.test_p : nullptr, c.test_i, bits);
     }
     cx.bits_ptr = (const void *)bits; cx.bits_words = words; cx.bits_m = m; cx.bits_masked = mask_test;
     cx.bits_tag = c.items_tag; cx.bits_train_p = c.train_p;
     sa.train_bits = bits; sa.train_words = (int)words;
 }
-template <class C> inline void set_train_bits(Sweep64Args &, Ctx &, const C &, int, int, long long, hipStream_t, bool, bool) {}
+template <class C> inline void set_train_bits(Sweep64Args &, Ctx &, const C &, int, int, long long, hipStream_t, bool) {}
 inline void set_part_extra(SweepArgs &sa, int extra) { sa.part_extra = extra; }
 inline void set_part_extra(Sweep64Args &, int) {}
 inline void set_ext_bits(SweepArgs &sa, const unsigned *bits, int words) { sa.train_bits = bits; sa.train_words = words; }
@@ -355,8 +368,13 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         }
         return cx.side_stream;
     };
-    auto fork_side = [&]() { hipStream_t sd = side_stream(); HIP_CHECK(hipEventRecord(cx.side_ev[0], stream)); HIP_CHECK(hipStreamWaitEvent(sd, cx.side_ev[0], 0)); return sd; };
-    auto join_side = [&]() { HIP_CHECK(hipEventRecord(cx.side_ev[1], cx.side_stream)); HIP_CHECK(hipStreamWaitEvent(stream, cx.side_ev[1], 0)); };
+    // (an error between a fork and its join must not leave the side stream reading the call's buffers behind the caller's back)
+    struct SideGuard {
+        Ctx &cx; bool open = false;
+        ~SideGuard() { if (open && cx.side_stream) (void)hipStreamSynchronize(cx.side_stream); }
+    } side_guard{cx};
+    auto fork_side = [&]() { hipStream_t sd = side_stream(); HIP_CHECK(hipEventRecord(cx.side_ev[0], stream)); HIP_CHECK(hipStreamWaitEvent(sd, cx.side_ev[0], 0)); side_guard.open = true; return sd; };
+    auto join_side = [&]() { HIP_CHECK(hipEventRecord(cx.side_ev[1], cx.side_stream)); HIP_CHECK(hipStreamWaitEvent(stream, cx.side_ev[1], 0)); side_guard.open = false; };
     const bool use_side = !getenv("RM_DEBUG_NO_SIDE");
 
     // ---- plan ----
@@ -587,7 +605,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         // (measured: on the side stream beside the positives' kernels they gain nothing -- both are bound by memory; r3_ab_c2.txt)
         typename P::Args sa{};
         if (use_ext_bits && dense_rows_fit(m, (long long)tiles_total * tile_items)) set_ext_bits(sa, c.ext_bits, (int)c.ext_words);
-        else set_train_bits(sa, cx, c, m, n, (long long)tiles_total * tile_items, stream, mask_test, c.noise_flag != nullptr);
+        else set_train_bits(sa, cx, c, m, n, (long long)tiles_total * tile_items, stream, mask_test);
 
         // ---- positives ----
         if (want_auc) {
@@ -905,7 +923,16 @@ void run_call(const Call<T> &c_in, hipStream_t stream, Ctx &cx)
             if (cx.bits_tag != 0 && cx.bits_tag == c0.items_tag && cx.bits_train_p == c0.train_p && cx.bits_m == m && !getenv("RM_DEBUG_NO_EXT_BITS")) {
                 c.ext_bits = (const unsigned *)cx.bits_ptr; c.ext_words = cx.bits_words; c.ext_masked = cx.bits_masked;      // the first pass's rows
             }
-            run<T>(c, ps, pc);
+            // (whatever fails in there -- the peer context duplicates workspace under memory pressure --, nothing of it may still be
+            // reading this context's buffers (flag snapshot, dense train rows, A / B) when the error reaches the caller)
+            try { run<T>(c, ps, pc); }
+            catch (...) {
+                (void)hipStreamSynchronize(ps);
+                if (pc.side_stream) (void)hipStreamSynchronize(pc.side_stream);
+                g_last_ctx = &cx;
+                throw;
+            }
+            g_last_ctx = &cx;                                        // rm_get_timings reports the main pass, not the small exact one
             HIP_CHECK(hipEventRecord(cx.pass_ev, ps));
             HIP_CHECK(hipStreamWaitEvent(stream, cx.pass_ev, 0));    // behind the first pass (stream order) AND the exact one
             hipLaunchKernelGGL(k_noise_scatter<T>, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, snap, sc);
@@ -1158,7 +1185,10 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     Ctx *ctxs[2] = {&cx, &cx};
     hipStream_t streams[2] = {stream, stream};
     std::unique_lock<std::mutex> peer_lock;
-    if (n_batches > 1 && !getenv("RM_DEBUG_ONE_CONTEXT")) {
+    // (not with k_metrics > 256: a batch is then sized by the score rows ONE context may hold -- a third of the free memory --
+    // and a second context holding as much again leaves the first one's next batch short: RM_ERR_NOMEM on the third batch)
+    const bool rows_bound = K > 256 || getenv("RM_DEBUG_EXT_TOPK") != nullptr;
+    if (n_batches > 1 && !rows_bound && !getenv("RM_DEBUG_ONE_CONTEXT")) {
         Ctx &pc = peer_context(cx);
         peer_lock = std::unique_lock<std::mutex>(pc.mu);
         if (!pc.own_stream) HIP_CHECK(hipStreamCreateWithFlags(&pc.own_stream, hipStreamNonBlocking));
@@ -1534,11 +1564,17 @@ extern "C" int rm_release_workspace(void)
     return guarded([&] {
         int dev = 0;
         HIP_CHECK(hipGetDevice(&dev));
-        std::lock_guard<std::mutex> lk(g_ctx_mu);
-        for (auto &kv : g_ctx) if (kv.first.first == dev) {
-            std::lock_guard<std::mutex> cl(kv.second->mu);
-            kv.second->ws.release();
-            kv.second->packed_tag = 0;
+        // (contexts are never destroyed, so the pointers stay valid; a context's mutex is NOT taken under g_ctx_mu: a running
+        // call holds its context and may ask for a peer context, which takes g_ctx_mu -- the other order would deadlock)
+        std::vector<Ctx *> mine;
+        {
+            std::lock_guard<std::mutex> lk(g_ctx_mu);
+            for (auto &kv : g_ctx) if (kv.first.first == dev) mine.push_back(kv.second.get());
+        }
+        for (Ctx *c : mine) {
+            std::lock_guard<std::mutex> cl(c->mu);
+            c->ws.release();
+            c->packed_tag = 0; c->bits_tag = 0; c->bits_ptr = nullptr;
         }
     });
 }

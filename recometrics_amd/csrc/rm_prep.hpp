@@ -334,10 +334,10 @@ __global__ void k_seed_thresholds(int n_slots, int stream_slot0, int K, int gu, 
 constexpr int TRAIN_BITS_MAX_WORDS = 4096;            // 131,072 items: 16 KiB of LDS per wavefront
 constexpr int TRAIN_BITS_WAVES = 4;
 // With `test_p` the TEST items are marked as well (`bits`), and the sweep then never sees a user's own test items: they come
-// back in k_merge_positives (rm_finalize.hpp).  `pure` (optional) receives the row of the train items alone -- what the tie
-// noise indexes its draws by (rm_noise.hpp k_noise_rows_bits).
+// back in k_merge_positives (rm_finalize.hpp); the tie noise, which indexes its draws by the train items alone, clears the test
+// items' bits in its own LDS copy of a row (rm_noise.hpp k_noise_rows_bits).
 __global__ __launch_bounds__(TRAIN_BITS_WAVES * WAVE) void k_train_bits(int m, int n, int words, const int *train_p, const int *train_i,
-                                                                        const int *test_p, const int *test_i, unsigned *bits, unsigned *pure)
+                                                                        const int *test_p, const int *test_i, unsigned *bits)
 {
     extern __shared__ unsigned tb_lds[];                      // [TRAIN_BITS_WAVES][words]
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -349,10 +349,6 @@ __global__ __launch_bounds__(TRAIN_BITS_WAVES * WAVE) void k_train_bits(int m, i
         for (int e = train_p[u] + lane; e < train_p[u + 1]; e += WAVE) { const int item = train_i[e]; atomicOr(&row[item >> 5], 1u << (item & 31)); }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (pure) {
-            unsigned *outp = pure + (size_t)u * words;
-            for (int w = lane; w < words; w += WAVE) outp[w] = row[w];
-        }
         if (test_p) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();

@@ -486,6 +486,9 @@ void k_sweep(SweepArgs a)
 #else
     constexpr bool EARLY_ARRIVE = false;
 #endif
+    // (the early arrival sits in front of factor groups NG - 2 and NG - 1 of do_mfma's loop, which advances by two: an odd group count
+    // would never arrive and hang the sub-tile barrier)
+    static_assert(!EARLY_ARRIVE || NG % 2 == 0, "early arrival needs an even number of factor groups");
     LdsU32Ptr arrive_p = (LdsU32Ptr)(smem + a.sync_off) + sub;
     auto do_mfma = [&](f32x16 &acc, int buf, int chunk, unsigned tile_bits) {
         const float4 *bb = ldsB + buf * BUF_F4 + sub * NG * 64 + h * 32 + ul;      // LDS image [sub][g][h][32 items]

@@ -227,6 +227,28 @@ def test_bench_with_two_ranks(hip, scaling):
     assert line["value"] > 0 and line["parity_checked"] > 0 and line["parity"]["ok"]
     users = 2 * 6001 if scaling == "weak" else 6001
     assert abs(line["value"] - users * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]
+    # the run checks itself: here the stand-in backend and the shared GPU are REPORTED (with RCCL they would be refused, exit 3)
+    sc = line["multi_gpu_self_check"]
+    assert sc["rccl_ranks"] == 2 and sc["comm_backend"] == "gloo" and sc["ok"] is False and sc["distinct_devices"] == 1
+    sh = line["sharded_host"]
+    assert sh["bitwise_equal_to_unsharded"] is True and len(sh["devices"]) == 2, sh
+
+
+def test_bench_refuses_a_multi_gpu_run_that_is_not_one():
+    """bench.py --gpus 2 with RCCL on a box with ONE GPU: two ranks cannot sit on two distinct devices -- the run must end
+    non-zero without a result line (whatever fails first: RCCL's own refusal of a shared device, or the self-check)"""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RM_BENCH_BACKEND", None)
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a box with exactly one GPU")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--users", "2048",
+                          "--no-cpu", "--no-extra"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode != 0
+    for ln in res.stdout.splitlines():
+        if ln.startswith("{"):
+            assert "value" not in json.loads(ln)
 
 
 def test_cython_binding_equals_the_ctypes_binding(hip, oracle=None):
@@ -347,3 +369,71 @@ def test_noise_and_batch_pipelines_agree(hip, env, monkeypatch):
     got = call()
     for name, g, w in zip(hip.METRIC_ORDER, got, want):
         assert_same_bits(g, w, "%s under %s" % (name, env))
+
+
+@pytest.mark.parametrize("noise", [False, True])
+def test_k_metrics_beyond_the_lists_when_memory_sizes_the_batches(hip, monkeypatch, noise):
+    """k_metrics > 256 with a memory budget that BINDS: RM_DEBUG_FREE_MB makes the library see a device with 3 GB (what its
+    cached workspaces hold is subtracted), rows are 0.8 MB (200 k items), so a batch is ~900 users and 2,600 users take three.
+    Such a call used to alternate its batches between two contexts, each keeping a full set of score rows: the third batch
+    found a third of the remaining memory too small and failed with RM_ERR_NOMEM.  Now: one context, and every output equals
+    the same users evaluated in separate one-batch calls, bit for bit."""
+    from recometrics_amd.synth import make_problem
+    pr = make_problem(2600, 200_000, 8, np.float32, mean_c=40, seed=31)
+    trp, tri = pr["train"]; tep, tei, tev = pr["test"]
+    K = 300
+    hip.load().rm_release_workspace()
+
+    def call(u0, u1):
+        p0, p1 = trp[u0:u1 + 1] - trp[u0], tep[u0:u1 + 1] - tep[u0]
+        return hip.calc_metrics(pr["A"][u0:u1], 8, pr["B"], 8, p0.astype(np.int32), tri[trp[u0]:trp[u1]], p1.astype(np.int32), tei[tep[u0]:tep[u1]],
+                                tev[tep[u0]:tep[u1]], K, ALL, False, noise, True, 2, 1, 1, 9)
+    cuts = [0, 650, 1300, 1950, 2600]
+    if noise:
+        parts = None            # (the reference's noise is seeded per ORIGINAL user index: slices starting elsewhere are other streams)
+    else:
+        parts = [call(a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    hip.load().rm_release_workspace()
+    monkeypatch.setenv("RM_DEBUG_FREE_MB", "3000")
+    monkeypatch.setenv("RM_HOST_TRACE", "1")
+    got = call(0, 2600)                                       # raised MemoryError before the fix
+    monkeypatch.delenv("RM_DEBUG_FREE_MB")
+    hip.load().rm_release_workspace()
+    if parts is not None:
+        for i, name in enumerate(hip.METRIC_ORDER):
+            assert_same_bits(got[i], np.concatenate([p[i] for p in parts]), name + " (K = 300, memory-bound batches)")
+    else:
+        again = call(0, 2600)                                 # without the cap: one batch
+        for i, name in enumerate(hip.METRIC_ORDER):
+            assert_same_bits(got[i], again[i], name + " (K = 300, memory-bound batches, noise on)")
+
+
+def test_release_workspace_beside_running_calls_does_not_deadlock():
+    """rm_release_workspace() from one thread while another runs host calls that alternate between two contexts (the call
+    holds its context's mutex and asks for the peer context under the registry's mutex; the release used to take the two in
+    the opposite order: ABBA).  In a process of its own, with a time limit."""
+    code = r"""
+import sys, threading, numpy as np
+sys.path.insert(0, %r)
+from recometrics_amd import _binding as hip
+from recometrics_amd.synth import make_problem
+hip.load()
+pr = make_problem(20000, 600, 8, np.float32, mean_c=20, seed=3)
+trp, tri = pr["train"]; tep, tei, tev = pr["test"]
+ALL = {name: True for name in hip.METRIC_ORDER}
+call = lambda: hip.calc_metrics(pr["A"], 8, pr["B"], 8, trp, tri, tep, tei, tev, 5, ALL, False, True, True, 2, 1, 1, 3)
+want = call()
+stop = threading.Event()
+def releaser():
+    while not stop.is_set():
+        hip.load().rm_release_workspace()
+th = threading.Thread(target=releaser); th.start()
+for _ in range(25):
+    got = call()
+    for g, w in zip(got, want):
+        assert ((g == w) | (np.isnan(g) & np.isnan(w))).all()
+stop.set(); th.join()
+print("NO_DEADLOCK")
+""" % ROOT
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "NO_DEADLOCK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]

@@ -11,6 +11,7 @@ import pytest
 
 from _util import assert_close, assert_same_bits, golden_cases, load_golden
 from _util import same_bits as _util_same_bits
+from oracle.ties import tie_pairs_per_user
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -140,27 +141,34 @@ def _check_against_oracle(hip, oracle, pr, k, dtype=np.float32, **kw):
             # libstdc++'s sort there (deviation D4) -- the synthetic factors have none.
             real = ref.calc(pr["A"], pr["B"], pr["train"], pr["test"], k, cumulative=cumulative, dtype=dtype, nthreads=NT, **kw)
             # Noise off: scores that are EXACTLY equal (with 40,000 fp32 scores per user a handful of pairs always are) are ordered
-            # by item id here and in the restatement, and by libstdc++'s introsort in the reference -- deviation D4; such a pair
-            # moves one positive by one rank.  So: everything within the tolerance, and bit-identical for all but a few users.
-            differing = np.zeros(len(tep) - 1, bool)
-            # (one swapped pair moves a positive by one rank: 1 / (positives x negatives) of ROC-AUC, more than 1e-5 for a user
-            # with a dozen test items among a few thousand candidates)
+            # by item id here and in the restatement, and by libstdc++'s introsort in the reference -- deviation D4.  Such a pair
+            # changes a metric only when one of the two is a test item of the user (oracle/ties.py), so: EVERY user that differs
+            # from the compiled reference -- in the last bit of any metric, or by more than 1e-5 in ROC-AUC (formed in x87 long
+            # double there: an ulp apart for everybody) -- must have a candidate whose score equals one of its positives' scores
+            # exactly, or the test fails.  A tied pair moves a positive by one rank, 1 / (positives x negatives) of ROC-AUC.
+            n_users = len(tep) - 1
+            differing = np.zeros(n_users, bool)
+            for name in real:
+                assert (np.isnan(got[name]) == np.isnan(real[name])).all(), name
+                if name != "ROC_AUC":
+                    assert_close(got[name], real[name], TOL, "%s cumulative=%s vs the compiled reference" % (name, cumulative))
+                    differing |= ~_util_same_bits(got[name], real[name]).reshape(n_users, -1).all(axis=1)
+            d_roc = np.zeros(n_users)
+            if "ROC_AUC" in real:
+                r64 = np.nan_to_num(real["ROC_AUC"].astype(np.float64))
+                d_roc = np.abs(np.nan_to_num(got["ROC_AUC"].astype(np.float64)) - r64) / np.maximum(1.0, np.abs(r64))   # (relative beyond magnitude 1, see assert_close)
+                differing |= d_roc > TOL
+            pairs = np.zeros(n_users, np.int64)
+            if differing.any():
+                who = np.flatnonzero(differing)
+                sc = hip.debug_scores(np.ascontiguousarray(pr["A"][who], dtype), np.ascontiguousarray(pr["B"], dtype))
+                noisy = bool(kw.get("noise"))
+                pairs[who] = tie_pairs_per_user(sc, pr["train"], pr["test"], who, noise_zone=(2.0 ** -14 if noisy and dtype == np.float32 else None))
+                unexplained = who[pairs[who] == 0]
+                assert unexplained.size == 0, "users %s differ from the compiled reference without an exact tie on a positive" % unexplained[:8].tolist()
             npos_u = np.diff(tep).astype(np.float64)
             nneg_u = np.maximum(pr["B"].shape[0] - np.diff(trp) - npos_u, 1)
-            for name in real:
-                if name == "ROC_AUC":
-                    d = np.abs(np.nan_to_num(got[name].astype(np.float64)) - np.nan_to_num(real[name].astype(np.float64)))
-                    assert (np.isnan(got[name]) == np.isnan(real[name])).all()
-                    d = d / np.maximum(1.0, np.abs(np.nan_to_num(real[name].astype(np.float64))))      # (relative beyond magnitude 1, see assert_close)
-                    assert (d <= TOL + 1.0 / np.maximum(npos_u * nneg_u, 1)).all(), "ROC_AUC vs the compiled reference: %g" % d.max()
-                    continue
-                assert_close(got[name], real[name], TOL, "%s cumulative=%s vs the compiled reference" % (name, cumulative))
-                if name != "ROC_AUC":
-                    differing |= ~_util_same_bits(want[name], real[name]).reshape(len(tep) - 1, -1).all(axis=1)
-            # (how many users differ in the last bit grows with the item count -- at a million fp32 scores per user thousands of pairs
-            # are exactly tied and most users have a test item in one; at a few thousand items there are none)
-            if pr["B"].shape[0] <= 3000 and dtype == np.float64:
-                assert differing.sum() == 0, "restatement and compiled reference differ for %d users" % differing.sum()
+            assert (d_roc <= TOL + pairs / np.maximum(npos_u * nneg_u, 1)).all(), "ROC_AUC vs the compiled reference: %g" % d_roc.max()
         # PR_AUC of a user with more than 63 test items is assembled from per-chunk partial sums (finalize):
         # same terms, different association than the reference's single running sum -> a few ulp(fp64), checked at 1e-12
         # (only when such users take one sweep slot per chunk, RM_STREAM_BUDGET_MB=0; by default their ranks come from
@@ -601,8 +609,15 @@ def test_baseline_c2_at_its_full_user_count(hip, noise):
         if name != "roc":
             differing |= ~_util_same_bits(arr[users], want[NAMES[name]])
     # exactly tied scores (a few pairs among 26,744 fp32 scores per user; the fp32 noise of 1e-12 does not separate scores of
-    # ordinary magnitude) are ordered by item id here and by libstdc++'s sort there (deviation D4): a few users move by an ulp
-    assert differing.mean() < 0.10, "%d of %d users differ bitwise" % (differing.sum(), users.shape[0])
+    # ordinary magnitude) are ordered by item id here and by libstdc++'s sort there (deviation D4): every user that differs in
+    # the last bit of a metric must have a candidate whose score equals one of its positives' exactly (oracle/ties.py)
+    if differing.any() and isinstance(impl, Reference):
+        who = np.flatnonzero(differing)
+        sc = hip.debug_scores(sA[who], sB)
+        pairs = tie_pairs_per_user(sc, str_, ste, who, noise_zone=(2.0 ** -14 if noise else None))
+        assert (pairs > 0).all(), "users %s differ from the compiled reference without an exact tie on a positive" % users[who[pairs == 0]][:8].tolist()
+    else:
+        assert not differing.any()
     roc = outs[hip.METRIC_ORDER.index("roc")]
     assert abs(np.nanmean(roc) - 0.5) < 0.005 and np.isnan(roc).sum() == (np.diff(tep) == 0).sum()
 

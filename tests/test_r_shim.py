@@ -44,7 +44,7 @@ def test_shim_builds_and_maps_nan_to_na_real():
         assert hasattr(lib, name) or name.startswith("rm_last") or name.startswith("rm_has")
 
 
-def _call(lib, dtype, pr, K, cumulative, want, noise=False, seed=1):
+def _call(lib, dtype, pr, K, cumulative, want, noise=False, seed=1, cold=True, min_items_pool=2, min_pos_test=1):
     """Hand the shim what Rcpp hands it."""
     m, k = pr["A"].shape
     n = pr["B"].shape[0]
@@ -58,7 +58,9 @@ def _call(lib, dtype, pr, K, cumulative, want, noise=False, seed=1):
         At_store, Bt_store, store = At, Bt, np.float64
     trp, tri = pr["train"]
     tep, tei, tev = pr["test"]
-    tev64 = tev.astype(np.float64)                                # X_test@x is a double vector in either path
+    trp, tep = np.ascontiguousarray(trp, np.int32), np.ascontiguousarray(tep, np.int32)
+    tri, tei = np.ascontiguousarray(tri, np.int32), np.ascontiguousarray(tei, np.int32)
+    tev64 = np.ascontiguousarray(tev, np.float64)                 # X_test@x is a double vector in either path
     outs, ptrs = {}, (C.c_void_p * 10)()
     for i, name in enumerate(ORDER):
         if not want.get(name):
@@ -69,7 +71,8 @@ def _call(lib, dtype, pr, K, cumulative, want, noise=False, seed=1):
         ptrs[i] = outs[name].ctypes.data
     fn = lib.rm_r_calc_metrics_f32 if dtype == np.float32 else lib.rm_r_calc_metrics_f64
     rc = fn(At_store.ctypes.data, Bt_store.ctypes.data, m, n, k, trp.ctypes.data, tri.ctypes.data if tri.size else None,
-            tep.ctypes.data, tei.ctypes.data, tev64.ctypes.data, K, int(cumulative), int(noise), ptrs, 1, 2, 1, 1, seed)
+            tep.ctypes.data, tei.ctypes.data if tei.size else None, tev64.ctypes.data if tev64.size else None, K, int(cumulative), int(noise), ptrs,
+            int(cold), min_items_pool, min_pos_test, 1, seed)
     assert rc == 0, rc
     res = {}
     for name, arr in outs.items():
@@ -124,3 +127,96 @@ def test_float_path_reads_the_test_values_only_for_ndcg():
     b = _call(lib, np.float32, pr2, 5, False, want)
     for name in a:
         assert_same_bits(a[name], b[name], name)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N4 against the ORACLE, not against ourselves: the fixtures under tests/golden are outputs of the real reference (compiled from
+# /root/reference by oracle/Makefile; tests/golden/make_golden.py) for the reference's own R test cases -- g1_* / g3_* are
+# tests/testthat/test-ndcg.R:7-124, g2_* are test-auc.R:22-61 -- plus the edge-user block g4_*, the cumulative NDCG quirks g5_*
+# and the random blocks g6_*.  They go through rm_r_calc_metrics_f32 / _f64 the way Rcpp hands them over (Rwrapper.cpp:61-410):
+# [k, m] column-major factors, float32 as the bits of int32 storage, double test values, [k_metrics, m] outputs.
+R_CASES = [c for c in __import__("_util").golden_cases() if c.startswith(("g1_", "g2_", "g3_", "g4_", "g5_", "g6_"))]
+SHORT = {"P@K": "p", "TP@K": "tp", "R@K": "r", "AP@K": "ap", "TAP@K": "tap", "NDCG@K": "ndcg", "Hit@K": "hit", "RR@K": "rr",
+         "ROC_AUC": "roc", "PR_AUC": "pr"}
+
+
+def _run_fixture(lib, case):
+    from _util import load_golden
+    dtype, inp, variants = load_golden(case)
+    out = []
+    for kw, expected in variants:
+        want = {name: name in kw["metrics"] for name in ORDER}
+        got = _call(lib, dtype, inp, kw["k"], kw.get("cumulative", False), want, noise=kw.get("noise", False), seed=kw.get("seed", 1),
+                    cold=kw.get("cold", True), min_items_pool=kw.get("min_items_pool", 2), min_pos_test=kw.get("min_pos_test", 1))
+        out.append((kw, expected, got, dtype, inp))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", R_CASES)
+def test_reference_fixtures_through_the_r_shaped_entry(case):
+    from _util import assert_close
+    lib = _shim()
+    for vi, (kw, expected, got, dtype, inp) in enumerate(_run_fixture(lib, case)):
+        assert {SHORT[k] for k in expected} == set(got), (case, vi)
+        tep, tev = inp["test"][0], inp["test"][2]
+        nan_value_user = np.array([np.isnan(tev[tep[u]:tep[u + 1]]).any() for u in range(len(tep) - 1)])
+        for long_name, w in expected.items():
+            g = np.ascontiguousarray(got[SHORT[long_name]])
+            assert g.shape == w.shape, (case, vi, long_name, g.shape, w.shape)
+            if long_name == "NDCG@K" and nan_value_user.any():       # deviation D6 (NaN among a user's test VALUES): not comparable
+                g, w = g.copy(), w.copy()
+                g[nan_value_user] = 0; w[nan_value_user] = 0
+            assert_close(g, w, 1e-5, "%s v%d %s %s through the R entry" % (case, vi, kw, long_name))
+            if dtype == np.float64:
+                # where the reference's R build yields NA_real_ (its NAN_ under _FOR_R, src/recometrics.hpp:75-80) the entry must
+                # hand R exactly that bit pattern -- is.na() is true for any NaN, but identical(x, NA_real_) is not
+                nan = np.isnan(w)
+                assert (g.view(np.uint64)[nan] == NA_REAL_BITS).all(), "%s v%d %s: NaN must be NA_real_" % (case, vi, long_name)
+                assert not (g.view(np.uint64)[~nan] == NA_REAL_BITS).any()
+
+
+@pytest.mark.gpu
+def test_literal_expectations_of_the_reference_r_tests():
+    """What tests/testthat/test-ndcg.R and test-auc.R assert in R, asserted on what the R-shaped entry returns"""
+    lib = _shim()
+    res = {c: _run_fixture(lib, c) for c in R_CASES if c.startswith(("g1_", "g2_", "g3_"))}
+    ndcg = lambda c, v=0: res[c][v][2]["ndcg"]          # noqa: E731
+    # test-ndcg.R:7-35 "Invalid cases", :73-105 "All negative values" / "All zeros": expect_true(is.na(res$ndcg_at_5)) -- NA_real_ itself
+    for c in ("g3_B_zero", "g3_B_ones", "g3_B_nan", "g3_B_inf", "g3_B_some_nan", "g3_B_pm_inf", "g3_vals_all_neg", "g3_vals_all_zero"):
+        for v in range(len(res[c])):
+            assert ndcg(c, v).view(np.uint64)[0] == NA_REAL_BITS, (c, v)
+    # test-ndcg.R:37-71 "Some negative values": > 0, < 0, > 0
+    assert ndcg("g1_ndcg_neg_a")[0] > 0 and ndcg("g1_ndcg_neg_b")[0] < 0 and ndcg("g1_ndcg_neg_c")[0] > 0
+    # test-ndcg.R:107-124 "Fewer items than k": expect_equal(res3[,1], res5[,1])
+    assert ndcg("g1_ndcg_fewer", 0)[0] == ndcg("g1_ndcg_fewer", 1)[0]
+    # test-auc.R:22-61: expect_equal(r$roc_auc, 1), expect_equal(r$pr_auc, 1), expect_equal(r$roc_auc, 0)
+    for v in range(len(res["g2_auc_perfect"])):
+        assert res["g2_auc_perfect"][v][2]["roc"][0] == 1 and res["g2_auc_perfect"][v][2]["pr"][0] == 1
+    assert res["g2_auc_perfect_f32"][0][2]["roc"][0] == 1 and res["g2_auc_perfect_f32"][0][2]["pr"][0] == 1
+    for v in range(len(res["g2_auc_zero"])):
+        assert res["g2_auc_zero"][v][2]["roc"][0] == 0
+
+
+@pytest.mark.gpu
+def test_random_roc_auc_with_float_carriers_like_test_auc_r():
+    """test-auc.R:7-20 "Random ROC-AUC": A, B from float::flrnorm (float32 in integer storage), empty train matrix, 10 % test
+    density, nthreads = 1: mean ROC-AUC within 0.03 of one half; and the same call against the oracle"""
+    from oracle.oracle import NAMES, Oracle
+    lib = _shim()
+    rng = np.random.default_rng(1)
+    m, n, k = 100, 20, 3
+    A = rng.standard_normal((m, k)).astype(np.float32)
+    B = rng.standard_normal((n, k)).astype(np.float32)
+    mask = rng.random((m, n)) < 0.1
+    tep = np.concatenate([[0], np.cumsum(mask.sum(1))]).astype(np.int32)
+    tei = np.concatenate([np.flatnonzero(r) for r in mask]).astype(np.int32)
+    tev = rng.standard_normal(tei.shape[0])
+    pr = dict(A=A, B=B, train=(np.zeros(m + 1, np.int32), np.zeros(0, np.int32)), test=(tep, tei, tev))
+    want = {name: name == "roc" for name in ORDER}
+    got = _call(lib, np.float32, pr, 5, False, want, noise=True, seed=1)["roc"]
+    assert abs(np.nanmean(got) - 0.5) <= 0.03
+    ref = Oracle().calc(A, B, pr["train"], (tep, tei, tev.astype(np.float32)), 5, metrics=("roc",), noise=True, seed=1, nthreads=1, dtype=np.float32)
+    w = ref[NAMES["roc"]]
+    assert (np.isnan(w) == np.isnan(got)).all()
+    assert np.nanmax(np.abs(w.astype(np.float64) - got.astype(np.float64)), initial=0) <= 1e-5
