@@ -871,13 +871,15 @@ void k_sweep(SweepArgs a)
             a.pst[(size_t)slot * n_part + part] = ps;
             ListEntry *dst = a.pl + ((size_t)slot * n_part + part) * K;
             if (LLDS && sub == 0) { keylist_sort_desc<GROUP_USERS>(Ll, K); for (int i = 0; i < K; i++) unpack_key(Ll[i * GROUP_USERS], dst[i].s, dst[i].idx); }
-            if (LLDS && sub != 0) for (int i = 0; i < K; i++) { dst[i].s = neg_inf_f(); dst[i].idx = IDX_EMPTY; }      // the group's list is written once
+            // (an EMPTY part is marked by its first entry alone -- k_finalize looks at nothing else of it, rm_finalize.hpp -- so the
+            // parts that hold nothing cost one scattered 8-byte store per lane instead of K)
+            if (LLDS && sub != 0) { dst[0].s = neg_inf_f(); dst[0].idx = IDX_EMPTY; }      // the group's list is written once
             // a user block cut into fewer ranges than the arrays are laid out for: its first block fills in the missing parts
             if (split == 0) for (int sp = nsplit; sp < a.part_splits; sp++) {
                 ps.vmax = neg_inf_f(); ps.vmin = pos_inf_f(); ps.has_nan = 0;
                 a.pst[(size_t)slot * n_part + sp * NSUB + sub] = ps;
                 ListEntry *de = a.pl + ((size_t)slot * n_part + sp * NSUB + sub) * K;
-                if (a.pl) for (int i = 0; i < K; i++) { de[i].s = neg_inf_f(); de[i].idx = IDX_EMPTY; }
+                if (a.pl) { de[0].s = neg_inf_f(); de[0].idx = IDX_EMPTY; }
             }
         }
     }

@@ -582,7 +582,7 @@ void k_sweep64(Sweep64Args a)
                 ps.vmax = neg_inf_d(); ps.vmin = pos_inf_d(); ps.has_nan = 0;
                 a.pst[(size_t)slot * n_part + sp * 2 + sub] = ps;
                 Entry<double> *de = a.pl + ((size_t)slot * n_part + sp * 2 + sub) * K;
-                if (a.pl) for (int i = 0; i < K; i++) { de[i].s = neg_inf_d(); de[i].idx = IDX_EMPTY; }
+                if (a.pl) { de[0].s = neg_inf_d(); de[0].idx = IDX_EMPTY; }          // (an empty part is marked by its first entry alone)
             }
         }
     }

@@ -152,7 +152,10 @@ def _check_against_oracle(hip, oracle, pr, k, dtype=np.float32, **kw):
                 assert (np.isnan(got[name]) == np.isnan(real[name])).all(), name
                 if name != "ROC_AUC":
                     assert_close(got[name], real[name], TOL, "%s cumulative=%s vs the compiled reference" % (name, cumulative))
-                    differing |= ~_util_same_bits(got[name], real[name]).reshape(n_users, -1).all(axis=1)
+                    diff = ~_util_same_bits(got[name], real[name]).reshape(n_users, -1).all(axis=1)
+                    if name == "PR_AUC" and os.environ.get("RM_STREAM_BUDGET_MB") == "0":
+                        diff &= np.diff(tep) <= 63          # deviation D7 (fallback only): per-chunk partial sums, a few ulp(fp64), checked below at 1e-12
+                    differing |= diff
             d_roc = np.zeros(n_users)
             if "ROC_AUC" in real:
                 r64 = np.nan_to_num(real["ROC_AUC"].astype(np.float64))
