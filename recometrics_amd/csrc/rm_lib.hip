@@ -15,6 +15,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <csignal>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -172,6 +173,10 @@ template <class T> struct Call {          // one calc_metrics call; every pointe
     // dense train rows built by another pass of the same call over the same users (the exact noise pass beside the first sweep
     // reads the first pass's rows instead of building 463 MB of its own at BASELINE C2)
     const unsigned *ext_bits = nullptr; long long ext_words = 0; bool ext_masked = false;
+    // fp32 tie noise of a host-pointer call in user batches: the batch only runs its FIRST pass and flags the users the noise can
+    // touch in this array (its slice of a range-wide one); the exact pass over all flagged users of the range follows the
+    // last batch (noise_exact_pass) -- per batch it costs two host-side waits that keep the next batch from being enqueued
+    int *first_pass_flags = nullptr;
 };
 
 inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
@@ -812,36 +817,106 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
 // can touch -- and only those are evaluated again, exactly.
 std::atomic<unsigned long long> g_call_counter{1};       // tags of calls: the packed item image survives between the passes / batches of one
 
+template <class T> struct NoiseGeom {
+    int per; long long e_ld, d_ld, cap;
+    NoiseGeom(const Workspace &ws, int n)
+    {
+        per = sizeof(T) == 4 ? 1 : 2;
+        e_ld = ((long long)n + 191) / 192 * 192;                                  // covers either tile size of the sweep
+        d_ld = ((long long)n * per + MT_N - 1) / MT_N * MT_N;
+        const long long row_bytes = e_ld * (long long)sizeof(T) + d_ld * 4;
+        long long budget;
+        if (const char *e = getenv("RM_NOISE_BUDGET_MB")) budget = atoll(e) << 20;
+        else budget = free_plus_owned(ws, {"noise_draws", "noise_rows"}) / 3;
+        cap = std::max<long long>(1, std::min<long long>(budget / row_bytes, 1 << 20));
+    }
+};
+// per-user mt19937(seed + user) draws -> per-item noise rows for `rows` users (row_user: their indices, null = users 0 .. rows - 1)
 template <class T>
-void run_call(const Call<T> &c_in, hipStream_t stream, Ctx &cx)
+void noise_make_rows(Ctx &cx, const Call<T> &c0, const NoiseGeom<T> &g, const int *row_user, int rows, const int *train_p, long long user0,
+                     unsigned *D, T *E, hipStream_t stream)
 {
+    const int n = c0.n, m = c0.m;
+    hipLaunchKernelGGL(k_mt_draws, dim3(cdiv(rows, MT_WAVES)), dim3(MT_WAVES * WAVE), 0, stream, row_user, rows, c0.seed, user0,
+                       train_p, n, g.per, D, g.d_ld);
+    // the dense train rows of this call's own first pass (fp32, small item counts), when they cover exactly these users
+    const bool dense = cx.bits_tag != 0 && cx.bits_tag == c0.items_tag && cx.bits_train_p == train_p && cx.bits_m == m && row_user != nullptr;
+    if (dense)
+        hipLaunchKernelGGL(k_noise_rows_bits<T>, dim3(rows), dim3(NOISE_ROWS_THREADS), sizeof(int) * (size_t)(2 * cx.bits_words + 1), stream, row_user, rows,
+                           (const unsigned *)cx.bits_ptr, (int)cx.bits_words, n, cx.bits_masked ? 1 : 0, train_p, c0.train_i, c0.test_p, c0.test_i,
+                           D, g.d_ld, E, g.e_ld);
+    else
+        hipLaunchKernelGGL(k_noise_rows<T>, dim3(cdiv((long long)rows * g.e_ld, 256)), dim3(256), 0, stream, row_user, rows, train_p, c0.train_i, n,
+                           D, g.d_ld, E, g.e_ld);
+}
+
+// The exact pass of the fp32 tie noise over the users flagged in `flag` [m]: rows of noise for them (in batches of what the memory
+// budget allows), the whole pipeline again for exactly those users.  `n_known` < 0: the number of flagged users is counted here
+// (one wait for the stream).  Returns that number; `row_user_out` (optional) receives the workspace array of their indices.
+template <class T>
+int noise_exact_pass(const Call<T> &c0, const int *flag, const int *skip, int n_known, hipStream_t stream, Ctx &cx, const int **row_user_out = nullptr)
+{
+    Workspace &ws = cx.ws;
+    const int m = c0.m;
+    const NoiseGeom<T> g(ws, c0.n);
+    int *noise_row = (int *)ws.get("noise_row", sizeof(int) * (size_t)m);
+    int *row_user = (int *)ws.get("noise_row_user", sizeof(int) * (size_t)(n_known >= 0 ? std::max(n_known, 1) : m));
+    int *counter = (int *)ws.get("noise_counter", sizeof(int));
+    unsigned char *only = (unsigned char *)ws.get("noise_only", (size_t)m);
+    HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(k_noise_assign_rows, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, flag, skip, noise_row, row_user, counter);
+    int n_flagged = n_known;
+    if (n_known < 0) {
+        HIP_CHECK(hipMemcpyAsync(cx.pinned_small + 2, counter, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        n_flagged = cx.pinned_small[2];
+    }
+    if (row_user_out) *row_user_out = row_user;
+    for (long long r0 = 0; r0 < n_flagged; r0 += g.cap) {
+        const int rows = (int)std::min<long long>(g.cap, n_flagged - r0);
+        hipLaunchKernelGGL(k_noise_select, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, noise_row, (int)r0, (int)r0 + rows, only);
+        unsigned *D = (unsigned *)ws.get("noise_draws", sizeof(unsigned) * (size_t)rows * (size_t)g.d_ld);
+        T *E = (T *)ws.get("noise_rows", sizeof(T) * (size_t)rows * (size_t)g.e_ld);
+        noise_make_rows<T>(cx, c0, g, row_user + r0, rows, c0.train_p, c0.user0, D, E, stream);
+        Call<T> c = c0;
+        c.only_users = only; c.noise_row = noise_row; c.noise_row0 = (int)r0; c.noise_E = E; c.noise_ld = g.e_ld; c.noise_flag = nullptr;
+        c.first_pass_flags = nullptr; c.flag_snapshot = nullptr;
+        c.eval_users = rows;
+        run<T>(c, stream, cx);
+    }
+    return n_flagged;
+}
+
+// `defer` (host-pointer calls in user batches): the fp32 noise path ends with a look at what the first pass flagged on top of the
+// users evaluated beside it -- a wait for the whole batch.  With `defer` that tail is handed back instead of run: the caller
+// enqueues its next batch first and runs the tail when it needs this batch's results (true = a sequential exact pass rewrote
+// outputs behind whatever the caller had enqueued after this call).
+template <class T>
+void run_call(const Call<T> &c_in, hipStream_t stream, Ctx &cx, std::function<bool()> *defer = nullptr)
+{
+    if (defer) *defer = nullptr;
     if (!c_in.noise || getenv("RM_NOISE_OFF")) { run<T>(c_in, stream, cx); return; }     // RM_NOISE_OFF: A/B timing only
     Call<T> c0 = c_in;
     if (c0.items_tag == 0) c0.items_tag = g_call_counter.fetch_add(1);                   // (a device-pointer call: its passes share B)
     Workspace &ws = cx.ws;
-    const int m = c0.m, n = c0.n;
-    const int per = sizeof(T) == 4 ? 1 : 2;
-    const long long e_ld = ((long long)n + 191) / 192 * 192;                      // covers either tile size of the sweep
-    const long long d_ld = ((long long)n * per + MT_N - 1) / MT_N * MT_N;
-    const long long row_bytes = e_ld * (long long)sizeof(T) + d_ld * 4;
-    long long budget;
-    if (const char *e = getenv("RM_NOISE_BUDGET_MB")) budget = atoll(e) << 20;
-    else budget = free_plus_owned(ws, {"noise_draws", "noise_rows"}) / 3;
-    const long long cap = std::max<long long>(1, std::min<long long>(budget / row_bytes, 1 << 20));
-    auto make_rows_into = [&](const int *row_user, int rows, const int *train_p, long long user0, unsigned *D, T *E, hipStream_t stream) {
-        hipLaunchKernelGGL(k_mt_draws, dim3(cdiv(rows, MT_WAVES)), dim3(MT_WAVES * WAVE), 0, stream, row_user, rows, c0.seed, user0,
-                           train_p, n, per, D, d_ld);
-        // the dense train rows of this call's own first pass (fp32, small item counts), when they cover exactly these users
-        const bool dense = cx.bits_tag != 0 && cx.bits_tag == c0.items_tag && cx.bits_train_p == train_p && cx.bits_m == m && row_user != nullptr;
-        if (dense)
-            hipLaunchKernelGGL(k_noise_rows_bits<T>, dim3(rows), dim3(NOISE_ROWS_THREADS), sizeof(int) * (size_t)(2 * cx.bits_words + 1), stream, row_user, rows,
-                               (const unsigned *)cx.bits_ptr, (int)cx.bits_words, n, cx.bits_masked ? 1 : 0, train_p, c0.train_i, c0.test_p, c0.test_i,
-                               D, d_ld, E, e_ld);
-        else
-            hipLaunchKernelGGL(k_noise_rows<T>, dim3(cdiv((long long)rows * e_ld, 256)), dim3(256), 0, stream, row_user, rows, train_p, c0.train_i, n,
-                               D, d_ld, E, e_ld);
+    const int m = c0.m;
+    if (!cx.pinned_small) {
+        HIP_CHECK(hipHostMalloc((void **)&cx.pinned_small, 64, hipHostMallocDefault));
+        HIP_CHECK(hipEventCreateWithFlags(&cx.flags_ev, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&cx.pass_ev, hipEventDisableTiming));
+    }
+    if (sizeof(T) == 4 && c0.first_pass_flags) {                    // a batch of a host-pointer call: see Call::first_pass_flags
+        Call<T> c1 = c0;
+        c1.noise_flag = c0.first_pass_flags;
+        run<T>(c1, stream, cx);
+        return;
+    }
+    const NoiseGeom<T> g(ws, c0.n);
+    const long long e_ld = g.e_ld, d_ld = g.d_ld, cap = g.cap;
+    auto make_rows_into = [=, &cx](const int *row_user, int rows, const int *train_p, long long user0, unsigned *D, T *E, hipStream_t st) {
+        noise_make_rows<T>(cx, c0, g, row_user, rows, train_p, user0, D, E, st);
     };
-    auto make_rows = [&](const int *row_user, int rows, const int *train_p, long long user0, unsigned *&D, T *&E) {
+    auto make_rows = [=, &ws](const int *row_user, int rows, const int *train_p, long long user0, unsigned *&D, T *&E) {
         D = (unsigned *)ws.get("noise_draws", sizeof(unsigned) * (size_t)rows * (size_t)d_ld);
         E = (T *)ws.get("noise_rows", sizeof(T) * (size_t)rows * (size_t)e_ld);
         make_rows_into(row_user, rows, train_p, user0, D, E, stream);
@@ -875,11 +950,6 @@ void run_call(const Call<T> &c_in, hipStream_t stream, Ctx &cx)
     const bool beside = !c0.topk_idx && !c0.only_users && !getenv("RM_DEBUG_NOISE_SEQUENTIAL");
     int *snap = nullptr;
     if (beside) {
-        if (!cx.pinned_small) {
-            HIP_CHECK(hipHostMalloc((void **)&cx.pinned_small, 64, hipHostMallocDefault));
-            HIP_CHECK(hipEventCreateWithFlags(&cx.flags_ev, hipEventDisableTiming));
-            HIP_CHECK(hipEventCreateWithFlags(&cx.pass_ev, hipEventDisableTiming));
-        }
         snap = (int *)ws.get("noise_flag_snap", sizeof(int) * (size_t)m);
         *cx.pinned_small = 0;
         c1.flag_snapshot = snap; c1.flag_count_host = cx.pinned_small; c1.flags_event = cx.flags_ev;
@@ -940,30 +1010,20 @@ void run_call(const Call<T> &c_in, hipStream_t stream, Ctx &cx)
             n_beside = n_early;
         }
     }
-    int n_flagged = 0;
-    HIP_CHECK(hipMemcpyAsync(&n_flagged, &plan->n_noise_flagged, sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
-    cx.timings[4] = 0;                                              // (reported below: users evaluated exactly)
-    n_flagged -= n_beside;                                          // what the first pass's k_finalize flagged on top (top-K in the zone)
-    if (n_flagged <= 0) return;
-    int *noise_row = (int *)ws.get("noise_row", sizeof(int) * (size_t)m);
-    int *row_user = (int *)ws.get("noise_row_user", sizeof(int) * (size_t)n_flagged);
-    int *counter = (int *)ws.get("noise_counter", sizeof(int));
-    unsigned char *only = (unsigned char *)ws.get("noise_only", (size_t)m);
-    HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(int), stream));
-    hipLaunchKernelGGL(k_noise_assign_rows, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, flag, n_beside > 0 ? (const int *)snap : (const int *)nullptr,
-                       noise_row, row_user, counter);
-    for (long long r0 = 0; r0 < n_flagged; r0 += cap) {
-        const int rows = (int)std::min<long long>(cap, n_flagged - r0);
-        hipLaunchKernelGGL(k_noise_select, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, noise_row, (int)r0, (int)r0 + rows, only);
-        unsigned *D; T *E;
-        make_rows(row_user + r0, rows, c0.train_p, c0.user0, D, E);
+    int *n_flagged_host = cx.pinned_small + 1;
+    HIP_CHECK(hipMemcpyAsync(n_flagged_host, &plan->n_noise_flagged, sizeof(int), hipMemcpyDeviceToHost, stream));
+    auto tail = [=, &cx]() -> bool {
+        HIP_CHECK(hipStreamSynchronize(stream));
+        cx.timings[4] = 0;
+        const int n_flagged = *n_flagged_host - n_beside;               // what the first pass's k_finalize flagged on top (top-K in the zone)
+        if (n_flagged <= 0) return false;
         Call<T> c = c0;
-        c.only_users = only; c.noise_row = noise_row; c.noise_row0 = (int)r0; c.noise_E = E; c.noise_ld = e_ld; c.noise_flag = nullptr;
         c.same_train_rows = true;
-        c.eval_users = rows;
-        run<T>(c, stream, cx);
-    }
+        noise_exact_pass<T>(c, flag, n_beside > 0 ? (const int *)snap : (const int *)nullptr, n_flagged, stream, cx);
+        return true;
+    };
+    if (defer) *defer = tail;
+    else tail();
 }
 
 template <class F> int guarded(F &&f)
@@ -1202,6 +1262,17 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
         hblocks[i] = out_w ? (T *)ctxs[i]->pinned_get(sizeof(T) * out_w * (size_t)mb_max) : nullptr;
     }
     const bool two_ctx = ctxs[1] != ctxs[0];
+    // fp32 tie noise over several batches: every batch runs its first pass only and flags the users the noise can touch in its
+    // slice of `range_flag`; ONE exact pass over the flagged users of the whole range follows the last batch.  (Per batch, the
+    // exact pass costs two waits on the host -- for the flags, for its own plan -- during which the next batch is not enqueued:
+    // 14.6 ms against 10.2 without noise at BASELINE C2, profiles/r4_host_entry.txt.)  Not with the ranking outputs of rm_rank_*.
+    const bool range_noise = h.noise && std::is_same<T, float>::value && n_batches > 1 && !h.topk_idx && !getenv("RM_NOISE_OFF") &&
+                             !getenv("RM_DEBUG_NOISE_PER_BATCH");
+    int *range_flag = nullptr;
+    if (range_noise) {
+        range_flag = (int *)ws.get("noise_flag_range", sizeof(int) * (size_t)m);
+        HIP_CHECK(hipMemsetAsync(range_flag, 0, sizeof(int) * (size_t)m, up));      // (in front of batch 0's rows: every batch waits for its rows' event)
+    }
     auto upload_users = [&](int bi) {                                 // rows [cuts[bi], cuts[bi + 1]) into their places, on `up`
         const long long b0 = cuts[bi], b1 = cuts[bi + 1];
         if (h.lda == (size_t)k) HIP_CHECK(hipMemcpyAsync(dA + (size_t)b0 * k, h.A + ((size_t)u0 + b0) * k, sizeof(T) * (size_t)(b1 - b0) * k, hipMemcpyHostToDevice, up));
@@ -1222,11 +1293,15 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     if (!shared || shard == 0) { upload_items(); stamp("items enqueued"); upload_users(0); }
     else { upload_users(0); upload_items(); HIP_CHECK(hipEventRecord(cx.up_ev[0], up)); }
     stamp("batch 0 rows enqueued");
-    struct InFlight { bool on = false; long long b0 = 0; int mb = 0; size_t boff[10]; size_t bo = 0; int which = 0; } fl[2];
+    // (`tail`: what the fp32 tie noise still has to look at once the batch is through, run_call; `copy_out`: the batch's device-to-host
+    // copies, enqueued behind the batch and once more when the tail rewrote outputs)
+    struct InFlight { bool on = false; long long b0 = 0; int mb = 0; size_t boff[10]; size_t bo = 0; int which = 0;
+                      std::function<bool()> tail; std::function<void()> copy_out; } fl[2];
     auto finish = [&](int which) {                                    // wait for the batch in flight on context `which`, hand its outputs over
         InFlight &f = fl[which];
         if (!f.on) return;
         f.on = false;
+        if (f.tail) { const bool again = f.tail(); f.tail = nullptr; if (again) f.copy_out(); }
         HIP_CHECK(hipStreamSynchronize(streams[which]));
         stamp("batch done");
         for (int i = 0; i < 10; i++) {
@@ -1267,17 +1342,24 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
         }
         c.items_tag = tag;
         c.seed = h.seed; c.user0 = (long long)u0 + b0;
-        run_call<T>(c, bs, bc);                                      // enqueued (one short plan read-back inside)
+        if (range_noise) c.first_pass_flags = range_flag + b0;
+        // enqueued (one short plan read-back inside; with more than one batch the tie noise's last look at the batch is deferred to
+        // finish(): the next batch is enqueued first)
+        run_call<T>(c, bs, bc, n_batches > 1 ? &f.tail : nullptr);
         f.on = true;
         stamp("batch enqueued");
-        if (f.bo) HIP_CHECK(hipMemcpyAsync(hblocks[which], dblocks[which], sizeof(T) * f.bo, hipMemcpyDeviceToHost, bs));
-        if (h.topk_idx) {
-            HIP_CHECK(hipMemcpyAsync(h.topk_idx + ((size_t)u0 + b0) * K, c.topk_idx, sizeof(int) * (size_t)mb * K, hipMemcpyDeviceToHost, bs));
-            HIP_CHECK(hipMemcpyAsync(h.topk_score + ((size_t)u0 + b0) * K, c.topk_score, sizeof(T) * (size_t)mb * K, hipMemcpyDeviceToHost, bs));
-            HIP_CHECK(hipMemcpyAsync(h.status + u0 + b0, c.status, sizeof(int) * (size_t)mb, hipMemcpyDeviceToHost, bs));
-            const long long e0 = tep[b0], e1 = tep[b1];             // this batch's test entries (range-relative)
-            if (e1 > e0) HIP_CHECK(hipMemcpyAsync(h.pos_rank + te0 + e0, c.pos_rank + e0, sizeof(long long) * (size_t)(e1 - e0), hipMemcpyDeviceToHost, bs));
-        }
+        const size_t bo = f.bo;
+        const long long e0 = tep[b0], e1 = tep[b1];                 // this batch's test entries (range-relative)
+        f.copy_out = [=, &h]() {
+            if (bo) HIP_CHECK(hipMemcpyAsync(hblocks[which], dblocks[which], sizeof(T) * bo, hipMemcpyDeviceToHost, bs));
+            if (h.topk_idx) {
+                HIP_CHECK(hipMemcpyAsync(h.topk_idx + ((size_t)u0 + b0) * K, c.topk_idx, sizeof(int) * (size_t)mb * K, hipMemcpyDeviceToHost, bs));
+                HIP_CHECK(hipMemcpyAsync(h.topk_score + ((size_t)u0 + b0) * K, c.topk_score, sizeof(T) * (size_t)mb * K, hipMemcpyDeviceToHost, bs));
+                HIP_CHECK(hipMemcpyAsync(h.status + u0 + b0, c.status, sizeof(int) * (size_t)mb, hipMemcpyDeviceToHost, bs));
+                if (e1 > e0) HIP_CHECK(hipMemcpyAsync(h.pos_rank + te0 + e0, c.pos_rank + e0, sizeof(long long) * (size_t)(e1 - e0), hipMemcpyDeviceToHost, bs));
+            }
+        };
+        f.copy_out();
         // the next batch's rows travel while this batch's sweep runs (the copies below block the host, not the device)
         if (bi + 1 < n_batches && !g_interrupt) upload_users(bi + 1);
         stamp("next rows enqueued");
@@ -1290,6 +1372,36 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     }
     finish(0); finish(1);
     g_last_ctx = &cx;
+    if (range_noise && !g_interrupt && out_w) {
+        // the exact pass over the users of the range that the first passes flagged: into a metric block of its own, from which the
+        // host takes the flagged users' values
+        Call<T> c{};
+        c.A = dA; c.lda = k; c.B = dB; c.ldb = k; c.m = m; c.n = n; c.k = k;
+        c.train_p = dtrp; c.train_i = dtri; c.nnz_train = nnz_tr;
+        c.test_p = dtep; c.test_i = dtei; c.test_v = dtev; c.nnz_test = nnz_te;
+        c.K = K; c.cumulative = h.cumulative; c.noise = true; c.cold = h.cold; c.min_items_pool = h.mip; c.min_pos_test = h.mpt;
+        c.items_tag = tag; c.seed = h.seed; c.user0 = (long long)u0;
+        T *dx = (T *)ws.get("o_exact", sizeof(T) * out_w * (size_t)m);
+        size_t off[10], bo = 0;
+        for (int i = 0; i < 10; i++) { off[i] = bo; c.out[i] = h.outs[i] ? dx + bo : nullptr; if (h.outs[i]) bo += (size_t)m * (i >= 8 ? 1 : per); }
+        const int *row_user = nullptr;
+        const int n_flagged = noise_exact_pass<T>(c, range_flag, nullptr, -1, stream, cx, &row_user);
+        stamp("exact pass enqueued");
+        if (n_flagged > 0) {
+            T *hx = (T *)cx.pinned_get(sizeof(T) * bo + sizeof(int) * (size_t)n_flagged);
+            int *hu = (int *)(hx + bo);
+            HIP_CHECK(hipMemcpyAsync(hx, dx, sizeof(T) * bo, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(hu, row_user, sizeof(int) * (size_t)n_flagged, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            for (int i = 0; i < 10; i++) {
+                if (!h.outs[i]) continue;
+                const size_t w = i >= 8 ? 1 : per;
+                for (int f = 0; f < n_flagged; f++)
+                    std::memcpy(h.outs[i] + ((size_t)u0 + hu[f]) * w, hx + off[i] + (size_t)hu[f] * w, sizeof(T) * w);
+            }
+            stamp("exact pass scattered");
+        }
+    }
     HIP_CHECK(hipStreamSynchronize(up));                              // `rb` and the caller's arrays go out of use (also after an interrupt)
     if (trace) {
         std::string line = "rm host trace (" + std::to_string(n_batches) + " batches, ms):";
@@ -1464,7 +1576,7 @@ extern "C" int rm_calc_metrics_dev_##SUFFIX(                                    
         std::lock_guard<std::mutex> lk(cx.mu);                                                                          \
         cx.acc[0] = cx.acc[1] = cx.acc[2] = cx.acc[3] = 0;                                                              \
         c.seed = seed; c.user0 = 0;                                                                                     \
-        run_call<T>(c, (hipStream_t)stream, cx);                                                                             \
+        run_call<T>(c, (hipStream_t)stream, cx);                                                                        \
     });                                                                                                                 \
 }                                                                                                                       \
 extern "C" int rm_rank_##SUFFIX(                                                                                        \

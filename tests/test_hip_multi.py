@@ -347,7 +347,8 @@ def test_pipelined_uploads_equal_one_batch(hip, monkeypatch):
         assert (rk[key] == rk1[key]).all() or key == "topk_score", key
 
 
-@pytest.mark.parametrize("env", [{"RM_DEBUG_NOISE_SEQUENTIAL": "1"}, {"RM_DEBUG_ONE_CONTEXT": "1"}, {"RM_DEBUG_NO_TEST_MASK": "1"}, {}])
+@pytest.mark.parametrize("env", [{"RM_DEBUG_NOISE_SEQUENTIAL": "1"}, {"RM_DEBUG_ONE_CONTEXT": "1"}, {"RM_DEBUG_NO_TEST_MASK": "1"}, {"RM_DEBUG_NOISE_PER_BATCH": "1"},
+                                 {"RM_DEBUG_NOISE_PER_BATCH": "1", "RM_DEBUG_NOISE_SEQUENTIAL": "1"}, {}])
 def test_noise_and_batch_pipelines_agree(hip, env, monkeypatch):
     """the API default (tie noise on) through the host entry with > 16,384 users: the exact pass of the flagged users beside the
     first sweep on a peer context, batches alternating between two contexts, test items masked by the dense rows -- against
@@ -361,8 +362,9 @@ def test_noise_and_batch_pipelines_agree(hip, env, monkeypatch):
     def call():
         return hip.calc_metrics(pr["A"], 12, pr["B"], 12, trp, tri, tep, tei, tev, 8, ALL, True, True, True, 2, 1, 1, 2 ** 34 + 1)
     monkeypatch.setenv("RM_DEBUG_NOISE_SEQUENTIAL", "1"); monkeypatch.setenv("RM_DEBUG_ONE_CONTEXT", "1"); monkeypatch.setenv("RM_DEBUG_NO_TEST_MASK", "1")
+    monkeypatch.setenv("RM_DEBUG_NOISE_PER_BATCH", "1")           # (default: ONE exact pass over the flagged users of the whole range behind the last batch)
     want = call()
-    for key in ("RM_DEBUG_NOISE_SEQUENTIAL", "RM_DEBUG_ONE_CONTEXT", "RM_DEBUG_NO_TEST_MASK"):
+    for key in ("RM_DEBUG_NOISE_SEQUENTIAL", "RM_DEBUG_ONE_CONTEXT", "RM_DEBUG_NO_TEST_MASK", "RM_DEBUG_NOISE_PER_BATCH"):
         monkeypatch.delenv(key)
     for key, val in env.items():
         monkeypatch.setenv(key, val)
