@@ -82,7 +82,12 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
     // distance, so the LDS atomic below takes it as its immediate offset instead of an address add per score
     constexpr unsigned HIST_DELTA = (unsigned)GROUPS_PER_BLOCK * (1u << J) * GROUP_USERS * 4u;
     unsigned at[16];                                           // address of row `base`
-    constexpr int TOP = J >= 2 ? 2 : 0;                        // levels resolved from registers
+#ifndef RM_TOP_LEVELS
+#define RM_TOP_LEVELS 2
+#endif
+    // levels resolved from registers: 2 = root and the roots of its two subtrees (three independent compares per score), 1 = the
+    // root alone, 0 = every level reads its pivot from LDS (A/B: profiles/r4_ab_c2.txt)
+    constexpr int TOP = J >= 2 ? RM_TOP_LEVELS : 0;
     unsigned long long mk0, mk1, mk2;                          // lane masks in SGPR pairs, in rotation
 #ifdef RM_ABL_LUT
     // timing model of a table-driven start (wrong results): 3 (4 at depth 6) vector instructions and one byte read per score
@@ -118,6 +123,16 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
                 const int j = i - 2;
                 const unsigned tgt = j < 16 ? a1 : (j < 32 ? a2 : a3);
                 if (j % 3 == 0) RM_SEL(at[j % 16], at[j % 16], tgt, mk0); else if (j % 3 == 1) RM_SEL(at[j % 16], at[j % 16], tgt, mk1); else RM_SEL(at[j % 16], at[j % 16], tgt, mk2);
+            }
+        }
+    } else if (TOP == 1) {
+        const unsigned a2 = pos_addr | (128u << (J >= 1 ? J - 1 : 0));         // the upper half of the table
+        #pragma unroll
+        for (int i = 0; i < 16 + 2; i++) {
+            if (i < 16) { if (i % 3 == 0) RM_CMP_LT(mk0, piv_root, v[i]); else if (i % 3 == 1) RM_CMP_LT(mk1, piv_root, v[i]); else RM_CMP_LT(mk2, piv_root, v[i]); }
+            if (i >= 2) {
+                const int j = i - 2;
+                if (j % 3 == 0) RM_SEL(at[j], pos_addr, a2, mk0); else if (j % 3 == 1) RM_SEL(at[j], pos_addr, a2, mk1); else RM_SEL(at[j], pos_addr, a2, mk2);
             }
         }
     } else {
@@ -183,9 +198,14 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
 #else
     if (__any(dmin == 0.f)) {
 #endif
+        // (the tile's first item made opaque INSIDE the rare branch: left visible, the sixteen item ids of the walk are loop-invariant
+        // code the compiler hoists in front of the switch over the table depths -- 24 v_or per tile on the common path, 6 % of the
+        // sweep's vector instructions at BASELINE C2, for a branch one tile in forty takes)
+        int sb_walk = sb;
+        asm volatile("" : "+s"(sb_walk));
         auto walk = [&](int r) {
             if (df[r] == 0.f) {
-                const int item = sb + mfma32_row(r, h);
+                const int item = sb_walk + mfma32_row(r, h);
                 unsigned t = at[r] - pos_addr;                       // row t holds a positive with exactly this score
                 while (*(const int *)((const char *)pos_item_g + t) > item) {        // (the id table has the score table's [row][32 users] layout)
                     t += 128;
@@ -618,10 +638,19 @@ void k_sweep(SweepArgs a)
         }
         // (2) min / max over candidates (NaN-ignoring, so the sentinel is invisible) (:519-524): v_max3 / v_min3 trees
         // (the maxima of the four register quads are kept: the top-K path below skips a whole quad with one test)
-        float qmax[4] = {hw_max3(v[0], v[1], hw_max(v[2], v[3])), hw_max3(v[4], v[5], hw_max(v[6], v[7])),
-                         hw_max3(v[8], v[9], hw_max(v[10], v[11])), hw_max3(v[12], v[13], hw_max(v[14], v[15]))};
-        float tmax = hw_max3(qmax[0], qmax[1], hw_max(qmax[2], qmax[3]));
-        vmax = hw_max(vmax, tmax);
+        // (ONE asm statement: the compiler puts an s_nop in front of every instruction that reads a register an asm statement has
+        // just written -- it cannot see that the statement holds no instruction with a destination select -- which was one issue
+        // slot per level of this tree)
+        float qmax[4], tmax;
+        asm("v_max_f32 %0, %8, %9\n\tv_max3_f32 %0, %6, %7, %0\n\t"
+            "v_max_f32 %1, %12, %13\n\tv_max3_f32 %1, %10, %11, %1\n\t"
+            "v_max_f32 %2, %16, %17\n\tv_max3_f32 %2, %14, %15, %2\n\t"
+            "v_max_f32 %3, %20, %21\n\tv_max3_f32 %3, %18, %19, %3\n\t"
+            "v_max_f32 %4, %2, %3\n\tv_max3_f32 %4, %0, %1, %4\n\t"
+            "v_max_f32 %5, %5, %4"
+            : "=&v"(qmax[0]), "=&v"(qmax[1]), "=&v"(qmax[2]), "=&v"(qmax[3]), "=&v"(tmax), "+v"(vmax)
+            : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+              "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
         // The minimum is only ever compared with the maximum (all candidates equal, :524) and tested for infinity (:522).  When
         // the host has proved every score finite, it is tracked until every lane of the wave has seen two different scores
         // -- from then on "min < max" is settled for good and the eight instructions per tile are skipped (what is reported
