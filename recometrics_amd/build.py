@@ -27,11 +27,36 @@ def _deps():
             + glob.glob(os.path.join(root, "include", "*.h")))
 
 
+STAMP = os.path.join(CSRC, "build_stamp.json")
+
+
+def sources_digest():
+    """sha256 over the contents of everything the library is compiled from (file names included), and over the flags"""
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted(_deps()):
+        h.update(os.path.basename(p).encode() + b"\0")
+        h.update(open(p, "rb").read())
+    h.update(repr((SOURCES, FLAGS, SWEEP_FLAGS)).encode())
+    return h.hexdigest()
+
+
+def read_stamp():
+    import json
+    try:
+        return json.load(open(STAMP))
+    except Exception:      # noqa: BLE001
+        return None
+
+
 def needs_build():
+    """The library is rebuilt when it is missing or when it was not built from the sources as they are now: the decision is
+    made on CONTENT (the digest build() records next to the library, csrc/build_stamp.json), not on modification times -- a
+    checkout, a copy to another box or a touched file must neither force nor hide a rebuild."""
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in _deps())
+    st = read_stamp()
+    return not st or st.get("sources_sha256") != sources_digest() or st.get("library_bytes") != os.path.getsize(LIB)
 
 
 # the sweeps: no SLP vectorisation -- it pairs independent f32 adds into v_pk_add_f32, which issue at less than half the rate of
@@ -57,6 +82,8 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     out = out or LIB
     if not force and out == LIB and not needs_build():
         return LIB
+    import time
+    t_start = time.time()
     with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         results = list(ex.map(lambda s: _compile(s, extra_flags), SOURCES))
     if verbose:
@@ -66,6 +93,13 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
                          capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
+    if out == LIB and not extra_flags:
+        import json
+        import time
+        ver = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True).stdout.splitlines()
+        json.dump({"sources_sha256": sources_digest(), "library_bytes": os.path.getsize(LIB), "built_at": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
+                   "translation_units": SOURCES, "flags": FLAGS, "sweep_flags": SWEEP_FLAGS, "hipcc": ver[0] if ver else "?",
+                   "seconds": round(time.time() - t_start, 1)}, open(STAMP, "w"), indent=1)
     return out
 
 

@@ -122,13 +122,15 @@ __global__ void k_auc_slots(FinalArgs<T, S> a)
 //     it, so it counts in bin i like every other candidate with i positives below it;
 //   * validity statistics and top-K: the extra part `extra` of pst / pl = max / min / NaN of the test items' scores and their
 //     K best in (score desc, item asc) order; k_finalize merges parts, whoever wrote them.
-// Test items masked by the train row (+inf in the tables) are not candidates.  Only users with ONE slot reach this kernel
+// Test items masked by the train row (+inf in the tables) are not candidates.  Only users with ONE slot reach this scheme
 // (table users with <= 63 test items and streamed users); the host keeps the old scheme when a call has chunked users.
+// Since round 4 the TABLE users are put back by the sweep itself (rm_sweep.hpp: the block of a user's first item range holds
+// its table in LDS) and this kernel is launched for the streamed users only, `slot0` = their first slot.
 constexpr int MERGE_WAVES = 4;                            // slots per block of k_merge_positives (one wavefront each)
 template <class T, class S>
-__global__ __launch_bounds__(MERGE_WAVES * WAVE) void k_merge_positives(FinalArgs<T, S> a, unsigned *hist_rw, int extra)
+__global__ __launch_bounds__(MERGE_WAVES * WAVE) void k_merge_positives(FinalArgs<T, S> a, int extra, int slot0)
 {
-    const int slot = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), lane = threadIdx.x & 63;
+    const int slot = slot0 + __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), lane = threadIdx.x & 63;
     if (slot >= a.n_slots) return;
     const int u = a.slot_user[slot];
     const int K = a.K, NP = a.n_part;
@@ -137,15 +139,11 @@ __global__ __launch_bounds__(MERGE_WAVES * WAVE) void k_merge_positives(FinalArg
     int has_nan = 0, filled = 0;                                    // `filled` is wave-uniform
     if (!(a.flags[u] & UF_ONLY_NDCG)) {
         const int te0 = a.test_p[u], npos = a.test_p[u + 1] - te0;
-        const bool streamed = slot >= a.stream_slot0;
-        const int g = slot / a.gu, ul = slot % a.gu;
-        const long long row0 = streamed ? 0 : (a.grow[g] + g) * a.gu + ul;
-        const long long stride = streamed ? 1 : a.gu;
-        const S *PS = streamed ? a.spos_score + te0 : a.pos_score + row0;
-        const int *PI = streamed ? a.spos_item + te0 : a.pos_item_tab + row0;
+        const S *PS = a.spos_score + te0;                           // the streamed user's positives, ascending (score, item desc)
+        const int *PI = a.spos_item + te0;
         for (int top = npos - 1; top >= 0; top -= WAVE) {           // best rows first: lane 0 holds the best of the 64
             const int i = top - lane;
-            const S x = i >= 0 ? PS[(long long)i * stride] : (S)INFINITY;
+            const S x = i >= 0 ? PS[i] : (S)INFINITY;
             const bool masked = isinf(x) && x > 0;                  // masked by the train row (or beyond the row)
             const bool isn = x != x;
             const bool cand = !masked && !isn;
@@ -153,13 +151,12 @@ __global__ __launch_bounds__(MERGE_WAVES * WAVE) void k_merge_positives(FinalArg
             if (cand) {
                 vmax = x > vmax ? x : vmax;
                 vmin = x < vmin ? x : vmin;
-                if (streamed) { if (i >= 1) atomicAdd(&a.shist[te0 + i - 1], 1u); }      // (k_rank_streamed may be counting beside this kernel)
-                else hist_rw[row0 + (long long)i * stride] += 1u;
+                if (i >= 1) atomicAdd(&a.shist[te0 + i - 1], 1u);   // (k_rank_streamed may be counting beside this kernel)
             }
             if (filled < K) {                                       // (score desc, item asc) = descending row order
                 const unsigned long long mk = __ballot(cand);
                 const int pos = filled + __popcll(mk & ((1ull << lane) - 1ull));
-                if (cand && pos < K) { L[pos].s = x; L[pos].idx = PI[(long long)i * stride]; }
+                if (cand && pos < K) { L[pos].s = x; L[pos].idx = PI[i]; }
                 filled += __popcll(mk);
             }
         }

@@ -93,7 +93,7 @@ struct Ctx {
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false, ev_recorded = false;
     hipStream_t side_stream = nullptr;      // second sweep launch of a depth-split call runs beside the first
-    hipEvent_t side_ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t done = nullptr;               // end of the device work of the most recent call on this context
     hipStream_t own_stream = nullptr;        // stream of a shard worker (multi-device calls)
     hipStream_t up_stream = nullptr;         // host-pointer calls: uploads of the NEXT user batch run beside the current batch's kernels
@@ -369,7 +369,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     auto side_stream = [&]() -> hipStream_t {
         if (!cx.side_stream) {
             HIP_CHECK(hipStreamCreateWithFlags(&cx.side_stream, hipStreamNonBlocking));
-            for (int i = 0; i < 3; i++) HIP_CHECK(hipEventCreateWithFlags(&cx.side_ev[i], hipEventDisableTiming));
+            for (int i = 0; i < 4; i++) HIP_CHECK(hipEventCreateWithFlags(&cx.side_ev[i], hipEventDisableTiming));
         }
         return cx.side_stream;
     };
@@ -581,6 +581,19 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     fa.n_slots = n_slots; fa.slot_user = slot_user; fa.slot_chunk = slot_chunk;
     fa.stream_slot0 = stream_slot0;
     if (want_auc && n_slots > 0) fa.auc_part = (AucPart *)ws.get("auc_part", sizeof(AucPart) * (size_t)n_slots);
+    // ideal-DCG values of the users with very long test rows (k_top_values: a wavefront per such user, a chain of K dependent
+    // rounds -- latency, 0.16 ms at BASELINE C2): they depend on the test rows alone, so they are computed on the side stream
+    // beside the preparation kernels instead of between the sweep and k_finalize, which waits for them
+    bool topv_pending = false;
+    if (fa.ndcg && hp.n_heavy > 0) {
+        fa.heavy_topv = (T *)ws.get("heavy_topv", sizeof(T) * (size_t)m * std::min(K, FIN_TOPV));
+        fa.heavy_nan = (unsigned char *)ws.get("heavy_nan", (size_t)m);
+        fa.heavy_users = heavy_users; fa.n_heavy = hp.n_heavy;
+        hipStream_t tv_stream = stream;
+        if (use_side) tv_stream = fork_side();
+        hipLaunchKernelGGL((k_top_values<T, T>), dim3(cdiv((long long)hp.n_heavy * WAVE, 256)), dim3(256), 0, tv_stream, fa);
+        if (use_side) { HIP_CHECK(hipEventRecord(cx.side_ev[3], tv_stream)); topv_pending = true; }
+    }
     const int stream_parts = (int)cdiv(n, STREAM_RANK_THREADS * STREAM_RANK_ITEMS);
     const int stream_ipt = ((int)cdiv(n, (long long)stream_parts * STREAM_RANK_THREADS) + 7) / 8 * 8;     // equal pieces of the row
     auto rank_streamed_rows = [&](int r0, int r1, hipStream_t st) {
@@ -748,7 +761,9 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     hipStream_t rank_stream = stream;
     if (ranks_beside) { rank_stream = fork_side(); rank_streamed_rows(0, n_stream, rank_stream); }
     if (mask_test) {
-        hipLaunchKernelGGL((k_merge_positives<T, T>), dim3(cdiv(n_slots, MERGE_WAVES)), dim3(MERGE_WAVES * WAVE), 0, stream, fa, hist, n_part - 1);
+        // (the table users' test items were put back by the sweep, rm_sweep.hpp; the streamed users' are this kernel's)
+        if (n_slots > stream_slot0)
+            hipLaunchKernelGGL((k_merge_positives<T, T>), dim3(cdiv(n_slots - stream_slot0, MERGE_WAVES)), dim3(MERGE_WAVES * WAVE), 0, stream, fa, n_part - 1, stream_slot0);
         if (ranks_beside && auc_launch) {                          // (it counts the streamed users' own test items: before k_auc_streamed)
             HIP_CHECK(hipEventRecord(cx.side_ev[2], stream));
             HIP_CHECK(hipStreamWaitEvent(rank_stream, cx.side_ev[2], 0));
@@ -756,11 +771,9 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     }
     if (ranks_beside && auc_launch) auc_streamed_rows(0, n_stream, rank_stream);
     hipLaunchKernelGGL((k_finalize_skipped<T, T>), dim3(cdiv(m, 256)), dim3(256), 0, stream, fa);
-    if (fa.ndcg && hp.n_heavy > 0) {                            // ideal-DCG values of the users with very long test rows
-        fa.heavy_topv = (T *)ws.get("heavy_topv", sizeof(T) * (size_t)m * std::min(K, FIN_TOPV));
-        fa.heavy_nan = (unsigned char *)ws.get("heavy_nan", (size_t)m);
-        fa.heavy_users = heavy_users; fa.n_heavy = hp.n_heavy;
-        hipLaunchKernelGGL((k_top_values<T, T>), dim3(cdiv((long long)hp.n_heavy * WAVE, 256)), dim3(256), 0, stream, fa);
+    if (topv_pending) {                                           // (k_top_values, launched beside the preparation)
+        HIP_CHECK(hipStreamWaitEvent(stream, cx.side_ev[3], 0));
+        if (!ranks_beside) side_guard.open = false;               // the main stream is behind everything the side stream was given
     }
     if (n_slots > 0 && ext_topk) {
         int sel_ld = 2;

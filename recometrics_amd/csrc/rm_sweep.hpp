@@ -912,6 +912,35 @@ void k_sweep(SweepArgs a)
             }
         }
     }
+    // The users' own TEST items, which a sweep over dense rows that mark them never saw (a.part_extra; rm_lib.hip `mask_test`), come
+    // back here for the table users -- once per user, in the block of its first item range, by the lane that owns the user: the
+    // group's table of sorted positives is in LDS, row i (ascending (score, item desc) order) outranks exactly the positives of the
+    // rows below it and so counts in bin i like any candidate with i positives below it; the rows walked downwards are the test items
+    // in (score desc, item asc) order, of which the first K are the extra part of the user's top-K lists and the first / last
+    // the maximum / minimum of the part's validity statistics.  +inf rows (padding, or a test item that is also a train item) are no
+    // candidates.  (Streamed users: k_merge_positives, rm_finalize.hpp.  This was that kernel's job for everybody: 0.25 ms per
+    // step at BASELINE C2, one wavefront per user re-reading from HBM what the block holds in LDS.)
+    if (AUC && a.part_extra && split == 0 && sub == 0 && h == 0 && slot_ok && slot < a.stream_slot0) {
+        const int pe = n_part - 1;
+        ListEntry *dx = a.pl + ((size_t)slot * n_part + pe) * K;
+        const unsigned hcol = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)(histL + gi * (PLmax + 1) * GROUP_USERS + ul);
+        float bmax = neg_inf_f(), bmin = pos_inf_f();
+        int filled = 0;
+        for (int i = PLb - 1; i >= 0; i--) {
+            const float x = *(LdsF32Ptr)(pos_addr + (unsigned)i * 128u);
+            if (x < pos_inf_f()) {
+                if (filled == 0) bmax = x;
+                bmin = x;
+                asm volatile("ds_add_u32 %0, %1" :: "v"(hcol + (unsigned)i * 128u), "v"(1u) : "memory");
+                if (filled < K) { dx[filled].s = x; dx[filled].idx = pos_item_g[i * GROUP_USERS]; }
+                filled++;
+            }
+        }
+        for (int i = filled; i < K; i++) { dx[i].s = neg_inf_f(); dx[i].idx = IDX_EMPTY; }
+        PartialStat<float> ps;
+        ps.vmax = bmax; ps.vmin = bmin; ps.rocsum = 0; ps.has_nan = 0; ps.pad = 0;
+        a.pst[(size_t)slot * n_part + pe] = ps;
+    }
     if (!LLDS && !buffered) {
         if (slot_ok && h == 0) {
             ListEntry *dst = a.pl + ((size_t)slot * n_part + part) * K;

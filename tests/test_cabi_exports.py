@@ -36,6 +36,17 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert lib.rm_last_error() is not None
 
 
+def test_the_library_is_built_from_the_sources_as_they_are():
+    """build() decides on content, and records what it compiled: the digest in csrc/build_stamp.json must be the digest of the
+    sources in the tree (a stale .so next to newer sources -- or next to a reverted file with an old mtime -- is rebuilt)"""
+    from recometrics_amd import build as rb
+    rb.build()
+    st = rb.read_stamp()
+    assert st is not None and st["sources_sha256"] == rb.sources_digest()
+    assert st["library_bytes"] == os.path.getsize(rb.LIB) and not rb.needs_build()
+    assert set(st["translation_units"]) == set(rb.SOURCES)
+
+
 def test_no_device_is_a_loud_error_not_a_fallback():
     """Without a GPU the product path must raise (status != 0, message set), never compute on the CPU."""
     import numpy as np
