@@ -1,16 +1,16 @@
 #!/bin/bash
-# A/B of one library under an environment switch: bash scratch/ab_env.sh <out> "<wl users>;..." <ENVVAR>   (min sweep ms over 4 steps, two rounds)
-out=$1; wls=$2; var=$3
+# A/B of environment switches on one library: bash scratch/ab_env.sh <out> "<wl users>;..." <rounds> "<ENV=1 ...>" "<...>"   ("-" = no switch)
+out=$1; wls=$2; rounds=$3; shift; shift; shift
+variants=("$@")
 mkdir -p gpurun_out/$out
-for round in 1 2; do
-for mode in off on; do
+for round in $(seq 1 $rounds); do
+for envs in "${variants[@]}"; do
   IFS=';' read -ra W <<< "$wls"
   for wl in "${W[@]}"; do
-    set -- $wl
-    if [ $mode = on ]; then export $var=1; else unset $var; fi
-    python3 scratch/ns.py $1 $2 4 2>>gpurun_out/$out/err.txt | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$var=$mode', d['workload'], d['users'], round(d['sweep_ms'],3), round(d['frac'],4), round(d['users_per_s']))" >> gpurun_out/$out/ab.txt
+    read -r name users <<< "$wl"
+    e=""; [ "$envs" != "-" ] && e="$envs"
+    env $e python3 scratch/ns.py $name $users 3 2>>gpurun_out/$out/err.txt | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print('[$envs]', d['workload'], d['users'], round(d['sweep_ms'],3), round(d['frac'],4), round(d['users_per_s']))" >> gpurun_out/$out/ab_env.txt
   done
 done
 done
-unset $var
-cat gpurun_out/$out/ab.txt
+cat gpurun_out/$out/ab_env.txt
