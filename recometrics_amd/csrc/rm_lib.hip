@@ -93,7 +93,7 @@ struct Ctx {
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false, ev_recorded = false;
     hipStream_t side_stream = nullptr;      // second sweep launch of a depth-split call runs beside the first
-    hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t side_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t done = nullptr;               // end of the device work of the most recent call on this context
     hipStream_t own_stream = nullptr;        // stream of a shard worker (multi-device calls)
     hipStream_t up_stream = nullptr;         // host-pointer calls: uploads of the NEXT user batch run beside the current batch's kernels
@@ -301,23 +301,29 @@ inline long long stream_budget_bytes(const Workspace &ws)
 // Dense train rows for the fp32 sweep when they are small (m * n / 8 bytes <= 1 GiB, e.g. 463 MB at BASELINE C2): with ~100
 // train items per user among 27k items, some lane of a wave has one in nearly every 32-item sub-tile, and the per-item walk of
 // the CSR cursor (compare, consume, reload, loop) was 9 % of the C2 sweep; one word per lane and tile replaces it.
-inline bool dense_rows_fit(int m, long long n_pad)
+// (rows are padded to 192 items = a whole tile of either size, 64 or 96: the row stride does not depend on the sweep's geometry,
+// which is only known behind the plan read-back -- the rows are built before it, beside the plan kernels)
+inline long long dense_row_words(long long n) { return (n + 191) / 192 * 6; }
+inline bool dense_rows_fit(int m, long long n)
 {
-    const long long words = (n_pad + 31) / 32;
+    const long long words = dense_row_words(n);
     return (size_t)m * (size_t)words * 4 <= ((size_t)1 << 30) && words <= TRAIN_BITS_MAX_WORDS && !getenv("RM_DEBUG_NO_TRAIN_BITS");
 }
 // `mask_test`: the rows mark the users' TEST items as well (k_merge_positives puts them back after the sweep; rm_noise.hpp clears
 // the test items' bits in its own copy of a row)
-template <class C> inline void set_train_bits(SweepArgs &sa, Ctx &cx, const C &c, int m, int n, long long n_pad, hipStream_t stream, bool mask_test)
+// `early`: the rows were launched before the plan was known (run(): on the side stream, beside the plan kernels) with the guess
+// `early_masked`; when the guess holds nothing is launched here
+template <class C> inline void set_train_bits(SweepArgs &sa, Ctx &cx, const C &c, int m, int n, hipStream_t stream, bool mask_test, bool early = false, bool early_masked = false)
 {
     Workspace &ws = cx.ws;
-    const long long words = (n_pad + 31) / 32;
+    const long long words = dense_row_words(n);
     const size_t bytes = (size_t)m * (size_t)words * 4;
     sa.train_bits = nullptr; sa.train_words = 0;
-    if (!dense_rows_fit(m, n_pad)) { cx.bits_tag = 0; return; }
+    if (!dense_rows_fit(m, n)) { cx.bits_tag = 0; return; }
     unsigned *bits = (unsigned *)ws.get("train_bits", bytes);
     // (the exact second pass of the tie noise evaluates a subset of the same users: the rows of the first pass are still there)
-    const bool ready = c.same_train_rows && cx.bits_ptr == (const void *)bits && cx.bits_words == words && cx.bits_m == m && cx.bits_masked == mask_test;
+    const bool ready = (early && early_masked == mask_test) ||
+                       (c.same_train_rows && cx.bits_ptr == (const void *)bits && cx.bits_words == words && cx.bits_m == m && cx.bits_masked == mask_test);
     if (!ready) {
         const unsigned blocks = (unsigned)std::min<long long>(((long long)m + TRAIN_BITS_WAVES - 1) / TRAIN_BITS_WAVES, 256 * 8);
         hipLaunchKernelGGL(k_train_bits, dim3(blocks), dim3(TRAIN_BITS_WAVES * WAVE), sizeof(unsigned) * (size_t)TRAIN_BITS_WAVES * (size_t)words, stream,
@@ -327,7 +333,7 @@ template <class C> inline void set_train_bits(SweepArgs &sa, Ctx &cx, const C &c
     cx.bits_tag = c.items_tag; cx.bits_train_p = c.train_p;
     sa.train_bits = bits; sa.train_words = (int)words;
 }
-template <class C> inline void set_train_bits(Sweep64Args &, Ctx &, const C &, int, int, long long, hipStream_t, bool) {}
+template <class C> inline void set_train_bits(Sweep64Args &, Ctx &, const C &, int, int, hipStream_t, bool, bool = false, bool = false) {}
 inline void set_part_extra(SweepArgs &sa, int extra) { sa.part_extra = extra; }
 inline void set_part_extra(Sweep64Args &, int) {}
 inline void set_ext_bits(SweepArgs &sa, const unsigned *bits, int words) { sa.train_bits = bits; sa.train_words = words; }
@@ -369,17 +375,17 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     auto side_stream = [&]() -> hipStream_t {
         if (!cx.side_stream) {
             HIP_CHECK(hipStreamCreateWithFlags(&cx.side_stream, hipStreamNonBlocking));
-            for (int i = 0; i < 4; i++) HIP_CHECK(hipEventCreateWithFlags(&cx.side_ev[i], hipEventDisableTiming));
+            for (int i = 0; i < 5; i++) HIP_CHECK(hipEventCreateWithFlags(&cx.side_ev[i], hipEventDisableTiming));
         }
         return cx.side_stream;
     };
     // (an error between a fork and its join must not leave the side stream reading the call's buffers behind the caller's back)
     struct SideGuard {
-        Ctx &cx; bool open = false;
-        ~SideGuard() { if (open && cx.side_stream) (void)hipStreamSynchronize(cx.side_stream); }
+        Ctx &cx; int pending = 0;                               // pieces of side-stream work the main stream has not been told to wait for yet
+        ~SideGuard() { if (pending > 0 && cx.side_stream) (void)hipStreamSynchronize(cx.side_stream); }
     } side_guard{cx};
-    auto fork_side = [&]() { hipStream_t sd = side_stream(); HIP_CHECK(hipEventRecord(cx.side_ev[0], stream)); HIP_CHECK(hipStreamWaitEvent(sd, cx.side_ev[0], 0)); side_guard.open = true; return sd; };
-    auto join_side = [&]() { HIP_CHECK(hipEventRecord(cx.side_ev[1], cx.side_stream)); HIP_CHECK(hipStreamWaitEvent(stream, cx.side_ev[1], 0)); side_guard.open = false; };
+    auto fork_side = [&]() { hipStream_t sd = side_stream(); HIP_CHECK(hipEventRecord(cx.side_ev[0], stream)); HIP_CHECK(hipStreamWaitEvent(sd, cx.side_ev[0], 0)); side_guard.pending++; return sd; };
+    auto join_side = [&]() { HIP_CHECK(hipEventRecord(cx.side_ev[1], cx.side_stream)); HIP_CHECK(hipStreamWaitEvent(stream, cx.side_ev[1], 0)); side_guard.pending = 0; };
     const bool use_side = !getenv("RM_DEBUG_NO_SIDE");
 
     // ---- plan ----
@@ -399,6 +405,24 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     // k_metrics beyond the sweep's lists (append buffers + wave compaction reach 256): every user is streamed and
     // k_select_topk picks its top-K from the stored row -- any k_metrics <= n, at one score row of HBM per user
     const bool ext_topk = K > 256 || getenv("RM_DEBUG_EXT_TOPK") != nullptr;
+    // Dense train rows (fp32, small item counts; set_train_bits) depend on the CSR inputs alone: they are built on the side stream
+    // BESIDE the plan kernels and the plan read-back (0.17 ms of preparation at BASELINE C2 that used to sit behind it).  Whether the
+    // rows also mark the test items (`mask_test`) is only decided behind the read-back; the guess here is the usual answer, and a
+    // wrong guess costs one more launch of the kernel behind it.
+    bool bits_early = false, bits_early_masked = false;
+    if (std::is_same<T, float>::value && use_side && !c.ext_bits && dense_rows_fit(m, n) && !getenv("RM_DEBUG_NO_EARLY_BITS")) {
+        SweepArgs probe{};
+        const bool guess = want_auc && !ext_topk && !getenv("RM_DEBUG_NO_TEST_MASK");
+        const unsigned *had = (const unsigned *)cx.bits_ptr;
+        const bool reuse = c.same_train_rows && had && cx.bits_words == dense_row_words(n) && cx.bits_m == m && cx.bits_masked == guess &&
+                           had == (const unsigned *)ws.get("train_bits", (size_t)m * (size_t)dense_row_words(n) * 4);
+        if (!reuse) {
+            hipStream_t sd = fork_side();
+            set_train_bits(probe, cx, c, m, n, sd, guess);
+            HIP_CHECK(hipEventRecord(cx.side_ev[4], sd));
+            bits_early = true; bits_early_masked = guess;
+        }
+    }
     if (want_auc || ext_topk) {
         const long long cap = stream_budget_bytes(ws) / (stream_ld_max * (long long)sizeof(T));
         // (a pass over a subset of the users -- the exact second pass of the fp32 tie noise -- stores rows for that subset only)
@@ -532,11 +556,11 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     // train row is marked +inf in the tables), not with chunked long rows (more slots than users: their best positives are not in the primary slot),
     // not beyond the lists (k_select_topk works on the stored rows).
     bool mask_test = std::is_same<T, float>::value && want_auc && !ext_topk && !check_nan && n_slots > 0 &&
-                     dense_rows_fit(m, (long long)tiles_total * tile_items) && hp.n_slots == hp.n_active && hp.n_only_ndcg == 0 &&
+                     dense_rows_fit(m, n) && hp.n_slots == hp.n_active && hp.n_only_ndcg == 0 &&
                      nsub * part_splits + 1 <= MAX_PARTS && !getenv("RM_DEBUG_NO_TEST_MASK");
     // rows handed over by another pass: usable when they were built the way this pass would build them (unmasked rows are
     // always valid: the old scheme)
-    const bool use_ext_bits = c.ext_bits != nullptr && c.ext_words == ((long long)tiles_total * tile_items + 31) / 32 && (!c.ext_masked || mask_test);
+    const bool use_ext_bits = c.ext_bits != nullptr && c.ext_words == dense_row_words(n) && (!c.ext_masked || mask_test);
     if (use_ext_bits) mask_test = c.ext_masked;
     const int n_part = nsub * part_splits + (mask_test ? 1 : 0);
     const int part_extra = mask_test ? 1 : 0;
@@ -622,8 +646,12 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         // ---- dense train rows (fp32, small item counts) ----
         // (measured: on the side stream beside the positives' kernels they gain nothing -- both are bound by memory; r3_ab_c2.txt)
         typename P::Args sa{};
-        if (use_ext_bits && dense_rows_fit(m, (long long)tiles_total * tile_items)) set_ext_bits(sa, c.ext_bits, (int)c.ext_words);
-        else set_train_bits(sa, cx, c, m, n, (long long)tiles_total * tile_items, stream, mask_test);
+        if (bits_early) {                                             // (launched beside the plan kernels: the sweep is behind them)
+            HIP_CHECK(hipStreamWaitEvent(stream, cx.side_ev[4], 0));
+            side_guard.pending--;
+        }
+        if (use_ext_bits && dense_rows_fit(m, n)) set_ext_bits(sa, c.ext_bits, (int)c.ext_words);
+        else set_train_bits(sa, cx, c, m, n, stream, mask_test, bits_early, bits_early_masked);
 
         // ---- positives ----
         if (want_auc) {
@@ -773,7 +801,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     hipLaunchKernelGGL((k_finalize_skipped<T, T>), dim3(cdiv(m, 256)), dim3(256), 0, stream, fa);
     if (topv_pending) {                                           // (k_top_values, launched beside the preparation)
         HIP_CHECK(hipStreamWaitEvent(stream, cx.side_ev[3], 0));
-        if (!ranks_beside) side_guard.open = false;               // the main stream is behind everything the side stream was given
+        side_guard.pending--;
     }
     if (n_slots > 0 && ext_topk) {
         int sel_ld = 2;

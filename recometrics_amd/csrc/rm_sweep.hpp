@@ -154,7 +154,6 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
 #else
         #pragma unroll
         for (int r = 0; r < 16; r++) pv[r] = *(LdsF32Ptr)(at[r] + (st - 1) * 128);
-#endif
         #pragma unroll
         for (int i = 0; i < 16 + 2; i++) {
             // s_waitcnt lgkmcnt(12 / 8 / 4 / 0) with the other counters left alone (gfx9 encoding, see WAIT_VMCNT0)
@@ -168,6 +167,7 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
             }
         }
     }
+#endif
     // exact score tie with a positive (row `base` is the first positive not below s; the table has one +inf pad
     // row, so the read is always in range): the total order is (score desc, item asc), i.e. the candidate also
     // outranks the equal-scored positives with a LARGER item id.  Rare; positives' item ids stay in HBM.  Detection: the
