@@ -169,9 +169,22 @@ def timings():
     return {k: buf[i] for i, k in enumerate(keys[:n])}
 
 
+def _csr_lib():
+    """librecometrics_hip.so, or -- RECOMETRICS_SPLIT_LIB -- the sanitizer build of the host-only units (oracle/Makefile)"""
+    lib = _load_split()
+    if not getattr(lib, "_csr_ready", False):
+        vp, i32, ci = C.c_void_p, C.c_int32, C.c_int
+        lib.rm_csr_rows_sorted.argtypes = [vp, vp, i32, i32]
+        lib.rm_csr_rows_sorted.restype = ci
+        lib.rm_csr_sort_rows.argtypes = [vp, vp, vp, i32, i32, i32]
+        lib.rm_csr_sort_rows.restype = ci
+        lib._csr_ready = True
+    return lib
+
+
 def csr_rows_sorted(indptr, indices, nthreads=0):
     """True when the column indices of every row of an int32 CSR ascend (rm_csr_rows_sorted: multi-threaded pass)."""
-    lib = load()
+    lib = _csr_lib()
     assert indptr.dtype == np.int32 and indices.dtype == np.int32
     rc = lib.rm_csr_rows_sorted(_p(indptr), _p(indices), indptr.shape[0] - 1, int(nthreads))
     if rc < 0:
@@ -181,14 +194,14 @@ def csr_rows_sorted(indptr, indices, nthreads=0):
 
 def csr_sort_rows(indptr, indices, data, nthreads=0):
     """Sorts every row's (index, value) pairs by index, in place (rm_csr_sort_rows); `data` may be None."""
-    lib = load()
+    lib = _csr_lib()
     assert indptr.dtype == np.int32 and indices.dtype == np.int32 and indices.flags.writeable
     vb = 0 if data is None else data.dtype.itemsize
     if vb not in (0, 4, 8):
         raise ValueError("values must be 4 or 8 bytes wide")
     rc = lib.rm_csr_sort_rows(_p(indptr), _p(indices), None if data is None else _p(data), vb, indptr.shape[0] - 1, int(nthreads))
     if rc:
-        _raise(lib, rc)
+        raise (MemoryError if rc == 3 else ValueError)("rm_csr_sort_rows failed (status %d)" % rc)
 
 
 def _suffix(dtype):

@@ -64,3 +64,32 @@ def test_reference_api_outputs(entry):
         assert [str(c) for c in df.columns] == entry["df_columns"]
         assert [str(t) for t in df.dtypes] == entry["df_dtypes"]
         assert list(df.shape) == entry["df_shape"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("entry", [e for e in INDEX if not e["error"]][:4], ids=lambda e: e["name"])
+def test_unsorted_and_wide_index_matrices_give_the_reference_outputs(entry):
+    """the reference sorts the column indices of X_train / X_test itself (recometrics/__init__.py:35-41); here that pass runs in the
+    library (csrc/rm_csr.cpp).  Rows shuffled, int64 index arrays, SciPy's sortedness flag unknown: same outputs, bit for bit"""
+    from scipy.sparse import csr_array
+    from recometrics_amd import calc_reco_metrics
+    z, Xtr, Xte, A, B, kw = _inputs(entry)
+    rng = np.random.default_rng(5)
+
+    def scrambled(X):
+        ip, ix, d = X.indptr.astype(np.int64), X.indices.astype(np.int64).copy(), X.data.copy()
+        for r in range(X.shape[0]):
+            a, e = ip[r], ip[r + 1]
+            perm = rng.permutation(e - a)
+            ix[a:e], d[a:e] = ix[a:e][perm], d[a:e][perm]
+        return csr_array((d, ix, ip), shape=X.shape)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        d = calc_reco_metrics(scrambled(Xtr), scrambled(Xte), A, B, as_df=False, **kw)
+    for key in entry["dict_keys"]:
+        if key == "K":
+            continue
+        want, got = z["out__" + key], np.asarray(d[key])
+        assert_close(got, want, 1e-5, key)
+        if key != "ROC_AUC":
+            assert_same_bits(got, want, key + " (bitwise, scrambled input)")

@@ -1,7 +1,7 @@
 """CPU-only: the host-side C++ of the repo under AddressSanitizer + UndefinedBehaviorSanitizer.
 
 oracle/Makefile's `sanitize` target builds the oracle restatement and the product's train/test splitting
-(recometrics_amd/csrc/rm_split.cpp) with -fsanitize=address,undefined; every golden fixture of both is then replayed through
+(recometrics_amd/csrc/rm_split.cpp) and CSR normalisation (csrc/rm_csr.cpp) with -fsanitize=address,undefined; every golden fixture of both is then replayed through
 those builds in a child process with the ASan runtime preloaded.  Any out-of-bounds access, use-after-free or undefined
 arithmetic aborts the child.  (GPU sanitizers are not available on this pool; the device code is covered by the parity tests.)"""
 import os
@@ -29,7 +29,8 @@ def test_host_code_under_asan_and_ubsan():
                RECOMETRICS_ORACLE_LIB=os.path.join(ROOT, "oracle", "_san", "librecometrics_oracle_san.so"),
                RECOMETRICS_SPLIT_LIB=os.path.join(ROOT, "oracle", "_san", "librm_split_san.so"))
     res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider",
-                          os.path.join(ROOT, "tests", "test_oracle_golden.py"), os.path.join(ROOT, "tests", "test_split_cpu.py")],
+                          os.path.join(ROOT, "tests", "test_oracle_golden.py"), os.path.join(ROOT, "tests", "test_split_cpu.py"),
+                          os.path.join(ROOT, "tests", "test_csr_cpu.py")],
                          env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     assert "passed" in res.stdout
