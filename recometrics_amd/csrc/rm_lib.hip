@@ -405,24 +405,6 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     // k_metrics beyond the sweep's lists (append buffers + wave compaction reach 256): every user is streamed and
     // k_select_topk picks its top-K from the stored row -- any k_metrics <= n, at one score row of HBM per user
     const bool ext_topk = K > 256 || getenv("RM_DEBUG_EXT_TOPK") != nullptr;
-    // Dense train rows (fp32, small item counts; set_train_bits) depend on the CSR inputs alone: they are built on the side stream
-    // BESIDE the plan kernels and the plan read-back (0.17 ms of preparation at BASELINE C2 that used to sit behind it).  Whether the
-    // rows also mark the test items (`mask_test`) is only decided behind the read-back; the guess here is the usual answer, and a
-    // wrong guess costs one more launch of the kernel behind it.
-    bool bits_early = false, bits_early_masked = false;
-    if (std::is_same<T, float>::value && use_side && !c.ext_bits && dense_rows_fit(m, n) && !getenv("RM_DEBUG_NO_EARLY_BITS")) {
-        SweepArgs probe{};
-        const bool guess = want_auc && !ext_topk && !getenv("RM_DEBUG_NO_TEST_MASK");
-        const unsigned *had = (const unsigned *)cx.bits_ptr;
-        const bool reuse = c.same_train_rows && had && cx.bits_words == dense_row_words(n) && cx.bits_m == m && cx.bits_masked == guess &&
-                           had == (const unsigned *)ws.get("train_bits", (size_t)m * (size_t)dense_row_words(n) * 4);
-        if (!reuse) {
-            hipStream_t sd = fork_side();
-            set_train_bits(probe, cx, c, m, n, sd, guess);
-            HIP_CHECK(hipEventRecord(cx.side_ev[4], sd));
-            bits_early = true; bits_early_masked = guess;
-        }
-    }
     if (want_auc || ext_topk) {
         const long long cap = stream_budget_bytes(ws) / (stream_ld_max * (long long)sizeof(T));
         // (a pass over a subset of the users -- the exact second pass of the fp32 tie noise -- stores rows for that subset only)
@@ -478,6 +460,26 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     for (int i = 0; i < K; i++) lt[i] = std::log2(i + 2);
     double *log2tab = (double *)ws.get("log2tab", sizeof(double) * (size_t)K);
     HIP_CHECK(hipMemcpyAsync(log2tab, lt.data(), sizeof(double) * (size_t)K, hipMemcpyHostToDevice, stream));
+    // Dense train rows (fp32, small item counts; set_train_bits) depend on the CSR inputs alone: they are launched on the side stream
+    // behind the plan kernels, so that they run during the plan read-back -- the host's one wait of the call, otherwise an idle
+    // device -- and beside the packing kernels (0.17 ms of preparation at BASELINE C2 that used to sit behind the read-back; in
+    // front of the plan kernels they slowed those down by as much as they saved).  Whether the rows also mark the test items
+    // (`mask_test`) is only decided behind the read-back; the guess here is the usual answer, and a wrong guess costs one more
+    // launch of the kernel behind it.
+    bool bits_early = false, bits_early_masked = false;
+    if (std::is_same<T, float>::value && use_side && !c.ext_bits && dense_rows_fit(m, n) && !getenv("RM_DEBUG_NO_EARLY_BITS")) {
+        SweepArgs probe{};
+        const bool guess = want_auc && !ext_topk && !getenv("RM_DEBUG_NO_TEST_MASK");
+        const unsigned *had = (const unsigned *)cx.bits_ptr;
+        const bool reuse = c.same_train_rows && had && cx.bits_words == dense_row_words(n) && cx.bits_m == m && cx.bits_masked == guess &&
+                           had == (const unsigned *)ws.get("train_bits", (size_t)m * (size_t)dense_row_words(n) * 4);
+        if (!reuse) {
+            hipStream_t sd = fork_side();
+            set_train_bits(probe, cx, c, m, n, sd, guess);
+            HIP_CHECK(hipEventRecord(cx.side_ev[4], sd));
+            bits_early = true; bits_early_masked = guess;
+        }
+    }
     Plan hp;
     HIP_CHECK(hipMemcpyAsync(&hp, plan, sizeof(Plan), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
@@ -667,23 +669,30 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
                           flags, user_nslots, uslot_base, slot_index, grow, pos_tmp, pos_order, pos_score, pos_item, GU};
             pa.noise_row = c.noise_row; pa.noise_row0 = c.noise_row0; pa.noise_E = c.noise_E; pa.noise_ld = c.noise_ld;
             pa.noise_flag = c.noise_flag; pa.plan = plan;
-            if (stream_slot0 > 0) {
-                hipLaunchKernelGGL(k_pos_scores<T>, dim3(cdiv(stream_slot0, POSS_WAVES)), dim3(POSS_WAVES * WAVE), 0, stream, pa, slot_user, slot_chunk, stream_slot0);
-                hipLaunchKernelGGL(k_pos_place<T>, dim3(cdiv((long long)stream_slot0 * WAVE, 256)), dim3(256), 0, stream, pa, slot_user, slot_chunk, stream_slot0);
-            }
+            // The streamed users' positives (scores, then the all-pairs rank of long test rows: vector work) run on the side stream
+            // beside the table users' (whose scoring is an L2 gather): two chains of two kernels each instead of four kernels in a row
+            hipStream_t ps = stream;
+            const bool pos_beside = use_side && n_stream > 0 && stream_slot0 > 0 && !getenv("RM_DEBUG_NO_POS_BESIDE");
             if (n_stream > 0) {
                 const size_t nz = (size_t)std::max<long long>(c.nnz_test, 1);
                 spos_score = (T *)ws.get("spos_score", sizeof(T) * nz);
                 spos_item = (int *)ws.get("spos_item", sizeof(int) * nz);
                 shist = (unsigned *)ws.get("shist", sizeof(unsigned) * nz);
-                HIP_CHECK(hipMemsetAsync(shist, 0, sizeof(unsigned) * nz, stream));
+                if (pos_beside) ps = fork_side();
+                HIP_CHECK(hipMemsetAsync(shist, 0, sizeof(unsigned) * nz, ps));
                 // (+inf in every rank: entries that repeat an item -- a non-canonical CSR row -- share a rank and leave one unused)
-                hipLaunchKernelGGL(k_fill<T>, dim3(cdiv((long long)nz, 256)), dim3(256), 0, stream, spos_score, (T)INFINITY, (long long)nz);
-                pa.stream = 1; pa.spos_score = spos_score; pa.spos_item = spos_item;
+                hipLaunchKernelGGL(k_fill<T>, dim3(cdiv((long long)nz, 256)), dim3(256), 0, ps, spos_score, (T)INFINITY, (long long)nz);
+                PosArgs<T> pb = pa;
+                pb.stream = 1; pb.spos_score = spos_score; pb.spos_item = spos_item;
                 const int nsc = hp.n_stream_chunks;
-                hipLaunchKernelGGL(k_pos_scores<T>, dim3(cdiv(nsc, POSS_WAVES)), dim3(POSS_WAVES * WAVE), 0, stream, pa, sc_user, sc_chunk, nsc);
-                hipLaunchKernelGGL(k_pos_place<T>, dim3(cdiv((long long)nsc * WAVE, 256)), dim3(256), 0, stream, pa, sc_user, sc_chunk, nsc);
+                hipLaunchKernelGGL(k_pos_scores<T>, dim3(cdiv(nsc, POSS_WAVES)), dim3(POSS_WAVES * WAVE), 0, ps, pb, sc_user, sc_chunk, nsc);
+                hipLaunchKernelGGL(k_pos_place<T>, dim3(cdiv((long long)nsc * WAVE, 256)), dim3(256), 0, ps, pb, sc_user, sc_chunk, nsc);
             }
+            if (stream_slot0 > 0) {
+                hipLaunchKernelGGL(k_pos_scores<T>, dim3(cdiv(stream_slot0, POSS_WAVES)), dim3(POSS_WAVES * WAVE), 0, stream, pa, slot_user, slot_chunk, stream_slot0);
+                hipLaunchKernelGGL(k_pos_place<T>, dim3(cdiv((long long)stream_slot0 * WAVE, 256)), dim3(256), 0, stream, pa, slot_user, slot_chunk, stream_slot0);
+            }
+            if (pos_beside) { join_side(); topv_pending = false; }       // (the join also covers k_top_values, launched there earlier)
         }
 
         if (n_stream > 0) stream_scores = (T *)ws.get("stream_scores", sizeof(T) * (size_t)n_stream * (size_t)stream_ld);

@@ -31,16 +31,23 @@ __device__ __forceinline__ int chunk_depth(int pc)      // smallest j with 2^j -
 // decision whether their score rows fit the HBM budget (`cap` rows)
 __global__ void k_count_long(int m, const int *test_p, Plan *plan, const unsigned char *only)
 {
+    // (one atomic pair per BLOCK: atomics of thousands of waves on the same two words serialise -- 30 us at BASELINE C2 with one
+    // pair per wave)
+    __shared__ int blk_cnt, blk_max;
+    if (threadIdx.x == 0) { blk_cnt = 0; blk_max = 0; }
+    __syncthreads();
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     const int npos = (u < m && !(only && !only[u])) ? test_p[u + 1] - test_p[u] : 0;
     const bool lng = npos > POS_CHUNK;
     const unsigned long long mk = __ballot(lng);
-    if (mk) {                                                  // one atomic pair per wave that has any
+    if (mk) {
         int mx = lng ? npos : 0;
         #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
-        if ((threadIdx.x & 63) == __ffsll((long long)mk) - 1) { atomicAdd(&plan->n_long, __popcll(mk)); atomicMax(&plan->max_npos, mx); }
+        if ((threadIdx.x & 63) == __ffsll((long long)mk) - 1) { atomicAdd(&blk_cnt, __popcll(mk)); atomicMax(&blk_max, mx); }
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && blk_cnt) { atomicAdd(&plan->n_long, blk_cnt); atomicMax(&plan->max_npos, blk_max); }
 }
 __global__ void k_decide_stream(Plan *plan, long long cap) { plan->stream_enable = plan->n_long > 0 && plan->n_long <= cap; }
 
@@ -285,10 +292,21 @@ __global__ void k_absmax(const T *X, size_t ld, long long rows, int k, unsigned 
     }
     #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+    // one atomic per BLOCK (the waves of a block meet in LDS first): thousands of atomics on one word serialise -- the kernel over
+    // the 6.8 MB of BASELINE C2's item factors took longer (49 us) than the one over 35 MB of user factors with half the waves
+    __shared__ unsigned long long blk_max;
+    __shared__ int blk_bad;
+    if (threadIdx.x == 0) { blk_max = 0ull; blk_bad = 0; }
+    __syncthreads();
     const bool anybad = __any(bad);
     if ((threadIdx.x & 63) == 0) {
-        if (!anybad) atomicMax(amax_bits, (unsigned long long)__double_as_longlong(mx));
-        else atomicOr(nonfinite, 1);
+        if (!anybad) atomicMax(&blk_max, (unsigned long long)__double_as_longlong(mx));
+        else atomicOr(&blk_bad, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (blk_bad) atomicOr(nonfinite, 1);
+        else if (blk_max) atomicMax(amax_bits, blk_max);
     }
 }
 
