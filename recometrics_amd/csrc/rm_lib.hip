@@ -669,6 +669,8 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
                           flags, user_nslots, uslot_base, slot_index, grow, pos_tmp, pos_order, pos_score, pos_item, GU};
             pa.noise_row = c.noise_row; pa.noise_row0 = c.noise_row0; pa.noise_E = c.noise_E; pa.noise_ld = c.noise_ld;
             pa.noise_flag = c.noise_flag; pa.plan = plan;
+            if (sizeof(T) == 4 && !getenv("RM_DEBUG_NO_POS_KEYS"))
+                pa.pos_key = (unsigned long long *)ws.get("pos_key", 8 * ((size_t)std::max<long long>(c.nnz_test, 1) + 8));
             // The streamed users' positives (scores, then the all-pairs rank of long test rows: vector work) run on the side stream
             // beside the table users' (whose scoring is an L2 gather): two chains of two kernels each instead of four kernels in a row
             hipStream_t ps = stream;

@@ -526,6 +526,8 @@ template <class T> struct PosArgs {
     int stream;          // 1 = the work list is the streamed users' chunk list
     T *spos_score;       // [nnz_test] at test_p[u] + rank: scores ascending, order (score asc, item desc)
     int *spos_item;      // [nnz_test] their item ids
+    unsigned long long *pos_key;   // fp32: [nnz_test + 8] the entry's packed key, (order-preserving score bits << 32) | ~item: an entry's rank in
+                                   // (score asc, item desc) order is the number of smaller keys (k_pos_place reads them through the scalar cache)
 };
 
 __device__ __forceinline__ bool in_sorted_row(const int *row, int len, int item)
@@ -592,7 +594,11 @@ __global__ __launch_bounds__(POSS_WAVES * WAVE) void k_pos_scores(PosArgs<T> a, 
     if (mine && !masked && a.noise_flag && (s < (T)0 ? -s : s) < (T)6.103515625e-05f) {
         if (atomicExch(&a.noise_flag[u], 1) == 0) atomicAdd(&a.plan->n_noise_flagged, 1);
     }
-    if (mine) a.pos_tmp[e] = masked ? (T)__int_as_float(0x7f800000) : s;
+    if (mine) {
+        const T sv = masked ? (T)__int_as_float(0x7f800000) : s;
+        a.pos_tmp[e] = sv;
+        if (sizeof(T) == 4 && a.pos_key) a.pos_key[e] = ((unsigned long long)ord_key((float)sv) << 32) | (unsigned)~item;
+    }
 }
 
 // One wavefront per SLOT (= up to 63 test entries of one user, by row position): rank of each of them among ALL the
@@ -612,9 +618,25 @@ __global__ void k_pos_place(PosArgs<T> a, const int *slot_user, const int *slot_
     const T s = mine ? a.pos_tmp[e] : (T)0;
     const int item = mine ? a.test_i[e] : 0;
     int rank = 0;
-    if (sizeof(T) == 4) {
-        // fp32: (score asc, item desc) is the order of the packed key (ordered score bits << 32) | ~item, so an entry's rank
-        // is the number of smaller keys: one 64-bit compare per pair (scores are never -0: the chain starts at +0)
+    if (sizeof(T) == 4 && a.pos_key) {
+        // fp32: (score asc, item desc) is the order of the packed key (ordered score bits << 32) | ~item, so an entry's rank is the
+        // number of smaller keys.  The keys of the row (written by k_pos_scores) are read with a wave-uniform index -- scalar
+        // loads, eight keys per instruction -- and each costs one 64-bit compare and one add-with-carry: 2 vector instructions
+        // per pair instead of the 5 of a lane broadcast (two v_readlane, compare, add), which made the all-pairs rank of the
+        // streamed users' long rows 0.19 ms at BASELINE C2.  (Scores are never -0: the chain starts at +0.)
+        const unsigned long long key = ((unsigned long long)ord_key((float)s) << 32) | (unsigned)~item;
+        const unsigned long long *keys = a.pos_key + te0;
+        const int P = te1 - te0;
+        int j = 0;
+        for (; j + 8 <= P; j += 8) {
+            unsigned long long k8[8];
+            #pragma unroll
+            for (int q = 0; q < 8; q++) k8[q] = __builtin_nontemporal_load(keys + j + q);
+            #pragma unroll
+            for (int q = 0; q < 8; q++) rank += k8[q] < key;
+        }
+        for (; j < P; j++) rank += __builtin_nontemporal_load(keys + j) < key;
+    } else if (sizeof(T) == 4) {
         const unsigned long long key = ((unsigned long long)ord_key((float)s) << 32) | (unsigned)~item;
         for (int f0 = te0; f0 < te1; f0 += WAVE) {
             const int f = f0 + lane;
