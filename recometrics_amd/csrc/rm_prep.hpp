@@ -541,18 +541,24 @@ __device__ __forceinline__ bool in_sorted_row(const int *row, int len, int item)
 __device__ __forceinline__ float fma_chain_step(float a, float b, float s) { return __builtin_fmaf(a, b, s); }
 __device__ __forceinline__ double fma_chain_step(double a, double b, double s) { return __builtin_fma(a, b, s); }
 
-// The item-factor rows of the wave's test items are fetched 64 bytes at a time, COALESCED (one load instruction covers
-// that piece of 4 (fp32) or 8 (fp64) rows), into a padded LDS image, and each lane then walks its own row out of LDS; the
-// user's factors ride in one register and are broadcast.  A per-lane gather (16 bytes of 60-odd different rows per
-// instruction) thrashes the vector L1.  The accumulate chain is chain_dot's: k-ordered fma from +0.
+// The item-factor rows of the wave's test items are fetched 128 bytes at a time, COALESCED and WIDE: eight lanes cover that piece of
+// a row with 16 bytes each, one load instruction covers it for 8 rows, eight instructions for all 63 -- a quarter of the load
+// instructions of 4-byte lanes, which is what bound this kernel (an L2 gather of nnz_test rows: 1.5 GB at BASELINE C2).  The pieces
+// go into a padded LDS image and each lane then walks its own row out of LDS; the user's factors ride in one register and are
+// broadcast.  (A per-lane gather -- 16 bytes of 60-odd different rows per instruction -- thrashes the vector L1.)  The accumulate
+// chain is chain_dot's: k-ordered fma from +0.  Rows that are not 16-byte aligned take element loads.
 constexpr int POSS_WAVES = 4;                                   // wavefronts (slots) per block
 template <class T>
 __global__ __launch_bounds__(POSS_WAVES * WAVE) void k_pos_scores(PosArgs<T> a, const int *slot_user, const int *slot_chunk, int n_slots)
 {
-    constexpr int CH = 64 / (int)sizeof(T);                     // factors per staged piece: 64 B of a row
-    constexpr int RPI = WAVE / CH;                              // rows covered by one load instruction
-    constexpr int LD = CH + 1;                                  // padded row stride in LDS (conflict-free row walks)
-    __shared__ T rows[POSS_WAVES][WAVE][LD];
+    constexpr int PB = 128;                                     // bytes of a row per staged piece
+    constexpr int CH = PB / (int)sizeof(T);                     // factors per piece: 32 floats / 16 doubles
+    constexpr int VE = 16 / (int)sizeof(T);                     // factors per 16-byte vector
+    constexpr int LPR = PB / 16;                                // lanes per row piece
+    constexpr int RPI = WAVE / LPR;                             // rows covered by one load instruction: 8
+    constexpr int LD = CH + VE;                                 // padded row stride in LDS (144 B: conflict-free vector writes and row walks)
+    typedef T VT __attribute__((ext_vector_type(16 / sizeof(T))));
+    __shared__ __attribute__((aligned(16))) T rows[POSS_WAVES][WAVE][LD];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int w = blockIdx.x * POSS_WAVES + wv;
     if (w >= n_slots) return;
@@ -566,24 +572,37 @@ __global__ __launch_bounds__(POSS_WAVES * WAVE) void k_pos_scores(PosArgs<T> a, 
     const int item = mine ? a.test_i[e] : 0;
     const bool masked = mine && ntr && in_sorted_row(a.train_i + tr0, ntr, item);
     const T *Au = a.A + (size_t)u * a.lda;
-    const int f = lane % CH, sub = lane / CH;
+    const int f = lane % CH, rsub = lane / LPR, piece = lane % LPR;
+    const bool vec_ok = ((((size_t)a.B) | (a.ldb * sizeof(T))) & 15) == 0;
+    // the row this lane helps to fetch in each of the eight load instructions of a piece (same for every piece)
+    const T *brow[WAVE / RPI];
+    #pragma unroll
+    for (int q = 0; q < WAVE / RPI; q++) {
+        const int p = q * RPI + rsub;
+        brow[q] = a.B + (size_t)__shfl(item, p < np ? p : 0) * a.ldb;
+    }
     T s = 0;
     for (int k0 = 0; k0 < a.k; k0 += CH) {
         const T av = k0 + f < a.k ? Au[k0 + f] : (T)0;
-        for (int p0 = 0; p0 < np; p0 += 8 * RPI) {             // eight loads in flight per lane
-            T bv[8];
+        const int e0 = k0 + piece * VE;                             // first factor of this lane's 16 bytes
+        VT bv[WAVE / RPI];
+        #pragma unroll
+        for (int q = 0; q < WAVE / RPI; q++) {
+            const int p = q * RPI + rsub;
+            VT x;
             #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int p = p0 + q * RPI + sub;
-                const int it = __shfl(item, p < np ? p : 0);
-                bv[q] = (p < np && k0 + f < a.k) ? a.B[(size_t)it * a.ldb + k0 + f] : (T)0;
+            for (int i = 0; i < VE; i++) x[i] = (T)0;
+            if (p < np && e0 < a.k) {
+                if (vec_ok && e0 + VE <= a.k) x = *(const VT *)(brow[q] + e0);
+                else {
+                    #pragma unroll
+                    for (int i = 0; i < VE; i++) if (e0 + i < a.k) x[i] = brow[q][e0 + i];
+                }
             }
-            #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int p = p0 + q * RPI + sub;
-                rows[wv][p < np ? p : WAVE - 1][f] = bv[q];
-            }
+            bv[q] = x;
         }
+        #pragma unroll
+        for (int q = 0; q < WAVE / RPI; q++) *(VT *)&rows[wv][q * RPI + rsub][piece * VE] = bv[q];
         const int kc = min(CH, a.k - k0);
         for (int t = 0; t < kc; t++) s = fma_chain_step(lane_bcast<T>(av, t), rows[wv][mine ? lane : 0][t], s);
     }
