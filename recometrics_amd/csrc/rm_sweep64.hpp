@@ -68,10 +68,14 @@ __device__ __forceinline__ void auc_pass64(const double (&v)[8], const char *pos
     #pragma unroll
     for (int r = 0; r < 8; r++) tie |= __ballot(nx[r] == v[r]);
     if (tie) {
+        // (the tile's first item made opaque inside the rare branch: visible, the eight item ids are loop-invariant code the compiler
+        // hoists onto the common path in front of the switch over the table depths -- see the fp32 sweep, rm_sweep.hpp auc_pass)
+        int sb_walk = sb;
+        asm volatile("" : "+s"(sb_walk));
         #pragma unroll
         for (int r = 0; r < 8; r++) {
             if (nx[r] == v[r]) {
-                const int item = sb + (r >> 2) * 16 + q + 4 * (r & 3);
+                const int item = sb_walk + (r >> 2) * 16 + q + 4 * (r & 3);
                 unsigned t = base[r];
                 while (t < (unsigned)(((1 << J) - 1) * 128) && *(const double *)(posb + t) == v[r] &&
                        pos_item_g[(t >> 7) * GROUP_USERS64] > item) t += 128;
@@ -582,7 +586,10 @@ void k_sweep64(Sweep64Args a)
                 ps.vmax = neg_inf_d(); ps.vmin = pos_inf_d(); ps.has_nan = 0;
                 a.pst[(size_t)slot * n_part + sp * 2 + sub] = ps;
                 Entry<double> *de = a.pl + ((size_t)slot * n_part + sp * 2 + sub) * K;
-                if (a.pl) { de[0].s = neg_inf_d(); de[0].idx = IDX_EMPTY; }          // (an empty part is marked by its first entry alone)
+                // (k_finalize looks at the first entry of an empty part only, and the fp32 sweep writes no more than that; here the
+                // K-entry loop stays: with the single store this kernel's k_metrics > 32 instantiation came out 1.2 % slower at
+                // BASELINE C5 -- register allocation, profiles/r4_ab_c2.txt r4s)
+                if (a.pl) for (int i = 0; i < K; i++) { de[i].s = neg_inf_d(); de[i].idx = IDX_EMPTY; }
             }
         }
     }
