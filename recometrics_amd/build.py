@@ -9,8 +9,10 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "librecometrics_hip.so")
-SOURCES = ["rm_lib.hip", "rm_sweep32.hip", "rm_sweep32_hbm.hip", "rm_sweep32_n3.hip", "rm_sweep32_large.hip",
-           "rm_sweep64_small.hip", "rm_sweep64_large.hip", "rm_split.cpp", "rm_csr.cpp"]
+SOURCES = ["rm_lib.hip", "rm_sweep32.hip", "rm_sweep32_large.hip", "rm_sweep64_small.hip", "rm_sweep64_small_s1.hip", "rm_sweep64_large.hip", "rm_sweep64_large_s1.hip",
+           # the fp32 sweep families x the specialisations of the epilogue's switches (rm_sweep.hpp k_sweep SPEC): one unit each
+           "rm_sweep32_n3.hip", "rm_sweep32_n3_s1.hip", "rm_sweep32_n3_s2.hip", "rm_sweep32_lds.hip", "rm_sweep32_lds_s1.hip", "rm_sweep32_lds_s2.hip",
+           "rm_sweep32_hbm.hip", "rm_sweep32_hbm_s1.hip", "rm_sweep32_hbm_s2.hip", "rm_split.cpp", "rm_csr.cpp"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-inline-asm"]   # m0 is clobbered by the LDS-DMA asm on purpose
 
 
@@ -84,7 +86,7 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
         return LIB
     import time
     t_start = time.time()
-    with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
         results = list(ex.map(lambda s: _compile(s, extra_flags), SOURCES))
     if verbose:
         for _, err in results:

@@ -13,6 +13,7 @@ struct SweepArgs {
     int n, K;
     int ngt;                              // factor groups of 8 when the kernel takes them at run time (more than 512 factors)
     int ext_topk;                         // 1 = no top-K lists here: every lane streams its scores, k_select_topk picks the top-K
+    int spec;                             // specialisation of the epilogue's switches (k_sweep SPEC): 0 read them here, 1 / 2 the usual cases
     int n_slots, n_groups, n_ublocks;     // n_ublocks = user blocks of THIS launch (ceil(n_groups / 4) when there is one)
     int ublock0;                          // first user block of this launch (depth-split calls launch twice)
     int n_splits, tiles_total;            // item splits of the main part of the grid
@@ -55,6 +56,7 @@ struct Sweep64Args {
     int n, K;
     int ngt;                              // factor groups of 8 when the kernel takes them at run time (more than 512 factors)
     int ext_topk;                         // 1 = no top-K lists here: every lane streams its scores, k_select_topk picks the top-K
+    int spec;                             // specialisation of the epilogue's switches (k_sweep64 SPEC): 0 read them here, 1 the usual case
     int n_slots, n_groups, n_ublocks;     // n_ublocks = user blocks of THIS launch
     int ublock0;                          // first user block of this launch (depth-split calls launch twice)
     int n_splits, tiles_total;
@@ -84,11 +86,20 @@ struct Sweep64Args {
 
 // return 0 = launched, -1 = unsupported factor-group count, otherwise a hipError_t
 int launch_sweep32(bool auc, bool dump, int lmode, int nsub, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa);
-int launch_sweep32_hbm(bool auc, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa);
-int launch_sweep32_n3(bool auc, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa);
+int launch_sweep32_hbm_s0(bool auc, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa);
+int launch_sweep32_hbm_s1(bool auc, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa);
+int launch_sweep32_hbm_s2(bool auc, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa);
+int launch_sweep32_lds_s0(bool auc, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa);
+int launch_sweep32_lds_s1(bool auc, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa);
+int launch_sweep32_lds_s2(bool auc, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa);
+int launch_sweep32_n3_s0(bool auc, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa);
+int launch_sweep32_n3_s1(bool auc, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa);
+int launch_sweep32_n3_s2(bool auc, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa);
 int launch_sweep32_large(bool auc, bool dump, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa);
 int launch_sweep64(bool auc, bool dump, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa);
-int launch_sweep64_small(bool auc, bool dump, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa);
-int launch_sweep64_large(bool auc, bool dump, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa);
+int launch_sweep64_small_s0(bool auc, bool dump, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa);
+int launch_sweep64_small_s1(bool auc, bool dump, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa);
+int launch_sweep64_large_s0(bool auc, bool dump, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa);
+int launch_sweep64_large_s1(bool auc, bool dump, int lmode, int NG, dim3 grid, size_t lds, hipStream_t stream, const Sweep64Args &sa);
 
 } // namespace rm

@@ -336,6 +336,13 @@ template <class C> inline void set_train_bits(SweepArgs &sa, Ctx &cx, const C &c
 template <class C> inline void set_train_bits(Sweep64Args &, Ctx &, const C &, int, int, hipStream_t, bool, bool = false, bool = false) {}
 inline void set_part_extra(SweepArgs &sa, int extra) { sa.part_extra = extra; }
 inline void set_part_extra(Sweep64Args &, int) {}
+// the sweep variant with the epilogue's switches as constants (rm_sweep.hpp k_sweep SPEC): 1 = dense train rows, 2 = CSR cursor,
+// both with every score finite, no tie noise and the top-K lists in reach; anything else reads the switches at run time
+inline void set_spec(SweepArgs &sa)
+{
+    sa.spec = (sa.check_nan || sa.noise_E || sa.ext_topk || getenv("RM_DEBUG_NO_SPEC")) ? 0 : (sa.train_bits ? 1 : 2);
+}
+inline void set_spec(Sweep64Args &sa) { sa.spec = (sa.check_nan || sa.noise_E || sa.ext_topk || getenv("RM_DEBUG_NO_SPEC")) ? 0 : 1; }
 inline void set_ext_bits(SweepArgs &sa, const unsigned *bits, int words) { sa.train_bits = bits; sa.train_words = words; }
 inline void set_ext_bits(Sweep64Args &, const unsigned *, int) {}
 
@@ -723,6 +730,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         sa.stream_slot0 = stream_slot0; sa.stream_ld = stream_ld; sa.stream_scores = stream_scores;
         set_part_extra(sa, part_extra);
         sa.noise_row = c.noise_row; sa.noise_row0 = c.noise_row0; sa.noise_E = c.noise_E; sa.noise_ld = c.noise_ld;
+        set_spec(sa);
 
         if (c.flag_snapshot) {
             HIP_CHECK(hipMemcpyAsync(c.flag_snapshot, c.noise_flag, sizeof(int) * (size_t)m, hipMemcpyDeviceToDevice, stream));

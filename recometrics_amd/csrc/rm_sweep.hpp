@@ -246,11 +246,20 @@ __device__ unsigned long long g_stats[16];
 // NSUB = 32-item sub-tiles per step (2 or 3): a block is 4 user groups x NSUB sub-tiles = 4 NSUB waves, NSUB per SIMD.
 // Three need the LDS room and <= 168 VGPRs, i.e. k <= 64: there the epilogue dominates, two waves per SIMD leave the
 // vector pipe idle a third of the time (profiles/r1_pmc_sq_C2.json), and the third wave fills it.
-template <int NGT, bool AUC, bool DUMP, int LMODE, int NSUB>
+// SPEC: the run-time switches of the epilogue as compile-time constants of the two usual cases.  0 = every switch read from the
+// argument block; 1 = dense train rows, every score provably finite, no tie noise, top-K lists in reach (small item counts:
+// BASELINE C1 / C2); 2 = the same with the CSR cursor instead of dense rows (large item counts: the north-star shape, C3, C4).  The
+// host picks the variant (SweepArgs::spec).  The switches cost a scalar branch each per tile and, held as lane masks across the tile
+// loop, a dozen SGPR pairs of a kernel that spills SGPRs as it is: as constants 2.6 % at C2, 4.1 % at the north-star shape, 4.4 %
+// at C3 (profiles/r4_ab_c2.txt, r4v / r4w).
+template <int NGT, bool AUC, bool DUMP, int LMODE, int NSUB, int SPEC = 0>
 __global__ __launch_bounds__(256 * NSUB)
 void k_sweep(SweepArgs a)
 {
     constexpr int TILE = 32 * NSUB;                             // items per step and per packed tile
+    static_assert(SPEC >= 0 && SPEC <= 2 && !(SPEC && DUMP), "unknown specialisation");
+    const bool f_bits = SPEC == 1 ? true : (SPEC == 2 ? false : a.train_bits != nullptr);
+    const bool f_nan = SPEC ? false : a.check_nan != 0, f_noise = SPEC ? false : a.noise_E != nullptr, f_ext = SPEC ? false : a.ext_topk != 0;
 #ifdef RM_STATS
     const unsigned long long prof_t0 = __builtin_readcyclecounter();
 #endif
@@ -330,7 +339,7 @@ void k_sweep(SweepArgs a)
     const unsigned *tb_row = (a.train_bits && user >= 0) ? a.train_bits + (size_t)user * a.train_words : nullptr;
     // (the rows are <= 1 GiB in all: a 32-bit word index, advanced by NSUB per tile, addresses them)
     unsigned tb_idx = (a.train_bits && user >= 0) ? (unsigned)user * (unsigned)a.train_words + (unsigned)(t0 * NSUB + sub) : 0u;
-    if (user >= 0 && !a.train_bits) {
+    if (user >= 0 && !f_bits) {
         ntc = a.train_p[user]; nte = a.train_p[user + 1];
         // first train item at or after this wave's first item (lower_bound)
         const int first_item = t0 * TILE;
@@ -521,7 +530,7 @@ void k_sweep(SweepArgs a)
             // Dense train rows: a masked item's accumulator STARTS as the all-ones NaN instead of +0 and the matrix
             // instructions carry the NaN through -- masking costs the one v_bfe that replaces the zero, not a v_bfe and a
             // v_or per score after the fact (16 fewer vector instructions per tile; unmasked chains still start at +0).
-            if (a.train_bits) {
+            if (f_bits) {
                 // (`tile_bits` arrives shifted by the lane half already -- see the loads: a shift here lands in the register
                 // the allocator has just freed, accumulator 0, and costs sixteen moves to get out of the way again)
                 const int mb = (int)tile_bits;
@@ -598,10 +607,10 @@ void k_sweep(SweepArgs a)
 #ifdef RM_ABL_NO_MASK
         const bool slow = false;
 #else
-        const bool slow = !a.train_bits && (__any(nt < sb + 32) || (sb + 32 > n));
+        const bool slow = !f_bits && (__any(nt < sb + 32) || (sb + 32 > n));
 #endif
-        if (a.train_bits) {                                       // masked in the accumulators already (do_mfma)
-            if (a.check_nan) {
+        if (f_bits) {                                             // masked in the accumulators already (do_mfma)
+            if (f_nan) {
                 const int mb = (int)tile_bits;
                 #pragma unroll
                 for (int r = 0; r < 16; r++) nanmask |= __ballot(!__builtin_amdgcn_sbfe(mb, (r & 3) + 8 * (r >> 2), 1) && (v[r] != v[r]));
@@ -629,10 +638,10 @@ void k_sweep(SweepArgs a)
             #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int mk = __builtin_amdgcn_sbfe(mb, (r & 3) + 8 * (r >> 2), 1);          // 0 or -1
-                if (a.check_nan) nanmask |= __ballot(!mk && (v[r] != v[r]));
+                if (f_nan) nanmask |= __ballot(!mk && (v[r] != v[r]));
                 v[r] = __int_as_float(__float_as_int(v[r]) | mk);
             }
-        } else if (a.check_nan) {
+        } else if (f_nan) {
             #pragma unroll
             for (int r = 0; r < 16; r++) nanmask |= __ballot(v[r] != v[r]);
         }
@@ -659,10 +668,10 @@ void k_sweep(SweepArgs a)
             const float tmin = hw_min3(hw_min3(v[0], v[1], v[2]), hw_min3(v[3], v[4], v[5]), hw_min3(v[6], v[7], v[8]));
             const float tmin2 = hw_min3(hw_min3(v[9], v[10], v[11]), hw_min3(v[12], v[13], v[14]), v[15]);
             vmin = hw_min3(vmin, tmin, tmin2);
-            if (!a.check_nan) track_min = __any(slot_ok && !(vmax > vmin));
+            if (!f_nan) track_min = __any(slot_ok && !(vmax > vmin));
         }
         // tie noise (reference :531-534: added AFTER the validity scan, in real_t): wave-uniform branch, exact passes only
-        if (a.noise_E) {
+        if (f_noise) {
             if (noise_lane) {
                 #pragma unroll
                 for (int q4 = 0; q4 < 4; q4++) {
@@ -683,7 +692,7 @@ void k_sweep(SweepArgs a)
         // of them is a valid lower bound of the final K-th best, so it filters for all of them
         if (primary && thr_seen > thr_pub) { thr_pub = thr_seen; const float t = ord_unkey(thr_seen); thr = t > thr ? t : thr; }
         // (a.ext_topk: k_metrics beyond the lists' reach -- every lane streams its scores and k_select_topk picks the top-K)
-        const unsigned long long cm = a.ext_topk ? 0ull : __ballot(tmax >= thr);
+        const unsigned long long cm = f_ext ? 0ull : __ballot(tmax >= thr);
         RM_STAT(0, 1); RM_STAT(1, cm != 0); RM_STAT(2, __popcll(cm));
         if (cm && pend_cap) {
             unsigned ov = 0;                                    // score registers that did not fit the lane's buffer

@@ -6,10 +6,10 @@
 
 namespace rm {
 
-template <int NGV, bool AUC, bool DUMP, int LMODE, int NSUB>
+template <int NGV, bool AUC, bool DUMP, int LMODE, int NSUB, int SPEC = 0>
 static int launch_one(dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa)
 {
-    auto kern = k_sweep<NGV, AUC, DUMP, LMODE, NSUB>;
+    auto kern = k_sweep<NGV, AUC, DUMP, LMODE, NSUB, SPEC>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, grid, dim3(256 * NSUB), lds, stream, sa);
@@ -17,14 +17,14 @@ static int launch_one(dim3 grid, size_t lds, hipStream_t stream, const SweepArgs
 }
 
 // factor-group counts 2, 4, 8 (and 16 when WITH16): the kernels for up to 64 (128) factors
-template <bool AUC, bool DUMP, int LMODE, int NSUB, bool WITH16>
+template <bool AUC, bool DUMP, int LMODE, int NSUB, bool WITH16, int SPEC = 0>
 static int launch_small(int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa)
 {
     switch (NG) {
-        case 2: return launch_one<2, AUC, DUMP, LMODE, NSUB>(grid, lds, stream, sa);
-        case 4: return launch_one<4, AUC, DUMP, LMODE, NSUB>(grid, lds, stream, sa);
-        case 8: return launch_one<8, AUC, DUMP, LMODE, NSUB>(grid, lds, stream, sa);
-        case 16: return WITH16 ? launch_one<WITH16 ? 16 : 8, AUC, DUMP, LMODE, NSUB>(grid, lds, stream, sa) : -1;
+        case 2: return launch_one<2, AUC, DUMP, LMODE, NSUB, SPEC>(grid, lds, stream, sa);
+        case 4: return launch_one<4, AUC, DUMP, LMODE, NSUB, SPEC>(grid, lds, stream, sa);
+        case 8: return launch_one<8, AUC, DUMP, LMODE, NSUB, SPEC>(grid, lds, stream, sa);
+        case 16: return WITH16 ? launch_one<WITH16 ? 16 : 8, AUC, DUMP, LMODE, NSUB, SPEC>(grid, lds, stream, sa) : -1;
         default: return -1;
     }
 }

@@ -1,15 +1,6 @@
-// rm_sweep32_n3.hip -- fp32 sweep, up to 64 factors, LDS lists, three item sub-tiles per step (12 waves per block).
-#include "rm_sweep32_launch.hpp"
-
-namespace rm {
-
-int launch_sweep32_n3(bool auc, int NG, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs &sa)
-{
-    return auc ? launch_small<true, false, LM_LDS, 3, false>(NG, grid, lds, stream, sa)
-               : launch_small<false, false, LM_LDS, 3, false>(NG, grid, lds, stream, sa);
-}
-
-} // namespace rm
+// rm_sweep32_n3.hip -- specialisation 0 of the fp32 sweep family "n3" (see the .inc)
+#define RM_SPEC 0
+#include "rm_sweep32_n3_body.inc"
 
 #ifdef RM_STATS
 extern "C" int rm_debug_stats_n3(unsigned long long *out, int reset)

@@ -88,10 +88,14 @@ __device__ __forceinline__ void auc_pass64(const double (&v)[8], const char *pos
         __hip_atomic_fetch_add((unsigned *)(histb + (base[r] >> 1)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int NGT, bool AUC, bool DUMP, int LMODE>
+// SPEC = 1: every score provably finite, no tie noise, top-K lists in reach -- the epilogue's run-time switches as constants (see
+// the fp32 sweep, rm_sweep.hpp k_sweep SPEC); 0 = read from the argument block.  Picked by the host (Sweep64Args::spec).
+template <int NGT, bool AUC, bool DUMP, int LMODE, int SPEC = 0>
 __global__ __launch_bounds__(SWEEP_THREADS, 2)
 void k_sweep64(Sweep64Args a)
 {
+    static_assert(SPEC >= 0 && SPEC <= 1 && !(SPEC && DUMP), "unknown specialisation");
+    const bool f_nan = SPEC ? false : a.check_nan != 0, f_noise = SPEC ? false : a.noise_E != nullptr, f_ext = SPEC ? false : a.ext_topk != 0;
     constexpr bool LLDS = LMODE == LM_LDS;
     constexpr bool buffered = LMODE == LM_HBM_APPEND;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -320,10 +324,10 @@ void k_sweep64(Sweep64Args a)
             #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const bool mk = (mbits >> ((r >> 2) * 16 + q + 4 * (r & 3))) & 1u;
-                if (a.check_nan) nanmask |= __ballot(!mk && (v[r] != v[r]));
+                if (f_nan) nanmask |= __ballot(!mk && (v[r] != v[r]));
                 v[r] = mk ? nan_sentinel_d() : v[r];
             }
-        } else if (a.check_nan) {
+        } else if (f_nan) {
             #pragma unroll
             for (int r = 0; r < 8; r++) nanmask |= __ballot(v[r] != v[r]);
         }
@@ -341,13 +345,13 @@ void k_sweep64(Sweep64Args a)
             asm("v_max_f64 %0, %1, %2" : "=v"(vmax) : "v"(vmax), "v"(m01)); asm("v_min_f64 %0, %1, %2" : "=v"(vmin) : "v"(vmin), "v"(n01));
         }
         // tie noise (reference :531-534: added AFTER the validity scan, in real_t)
-        if (a.noise_E && noise_lane) {
+        if (f_noise && noise_lane) {
             #pragma unroll
             for (int r = 0; r < 8; r++) v[r] += noise_lane[sb + (r >> 2) * 16 + q + 4 * (r & 3)];
         }
         if (primary && thr_seen > thr_pub) { thr_pub = thr_seen; const double t = ord_unkey(thr_seen); thr = t > thr ? t : thr; }
         unsigned long long cm = 0;
-        if (!a.ext_topk) {                                      // (ext_topk: see the fp32 sweep)
+        if (!f_ext) {                                           // (ext_topk: see the fp32 sweep)
             #pragma unroll
             for (int r = 0; r < 8; r++) cm |= __ballot(v[r] >= thr);
         }
