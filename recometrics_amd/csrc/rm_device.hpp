@@ -103,6 +103,11 @@ template <> __device__ __forceinline__ double lane_bcast<double>(double v, int s
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// "some lane": the lane mask of the condition itself tested by the scalar unit.  (HIP's __any() and __ballot() take an int: a
+// condition that is already a lane mask is turned into a 0 / 1 vector and compared again -- two vector instructions more per
+// use, and the sweeps ask several times per tile.)
+__device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+
 // row of accumulator register r in a 32x32 MFMA result for the lane half h (cdna_hip_programming.md section 3)
 __device__ __forceinline__ constexpr int mfma32_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

@@ -196,7 +196,7 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
 #ifdef RM_ABL_NOTIE
     if (false) {
 #else
-    if (__any(dmin == 0.f)) {
+    if (wave_any(dmin == 0.f)) {
 #endif
         // (the tile's first item made opaque INSIDE the rare branch: left visible, the sixteen item ids of the walk are loop-invariant
         // code the compiler hoists in front of the switch over the table depths -- 24 v_or per tile on the common path, 6 % of the
@@ -214,12 +214,12 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
                 at[r] = pos_addr + t;
             }
         };
-        if (__any(m0 == 0.f)) { walk(0); walk(1); walk(2); }
-        if (__any(m1 == 0.f)) { walk(3); walk(4); walk(5); }
-        if (__any(m2 == 0.f)) { walk(6); walk(7); walk(8); }
-        if (__any(m3 == 0.f)) { walk(9); walk(10); walk(11); }
-        if (__any(m4 == 0.f)) { walk(12); walk(13); walk(14); }
-        if (__any(df[15] == 0.f)) walk(15);
+        if (wave_any(m0 == 0.f)) { walk(0); walk(1); walk(2); }
+        if (wave_any(m1 == 0.f)) { walk(3); walk(4); walk(5); }
+        if (wave_any(m2 == 0.f)) { walk(6); walk(7); walk(8); }
+        if (wave_any(m3 == 0.f)) { walk(9); walk(10); walk(11); }
+        if (wave_any(m4 == 0.f)) { walk(12); walk(13); walk(14); }
+        if (wave_any(df[15] == 0.f)) walk(15);
     }
     // (inline asm: the six instantiations of this pass share one tail after the compiler's merge of the switch, which turned
     // the compile-time distance into a register and an address add per score)
@@ -432,7 +432,7 @@ void k_sweep(SweepArgs a)
         const int lim = h == 0 ? (pcnt > pc ? pcnt : pc) : 0;
         RM_STAT(5, 1);
         list_acquire();
-        for (int i = 0; __any(i < lim); i++) {
+        for (int i = 0; wave_any(i < lim); i++) {
             RM_STAT(6, 1);
             if (h == 0) {
                 if (i < pcnt) offer_key(Pp[i * WAVE]);
@@ -468,7 +468,7 @@ void k_sweep(SweepArgs a)
     // its masked scores to the user's row in HBM and k_rank_streamed counts from there.  Wave-uniform flag: a wave with
     // none of them (all but the last few user blocks) pays one scalar branch per tile.
     const bool stream_lane = slot_ok && slot >= a.stream_slot0;
-    const bool wave_streams = __any(stream_lane);
+    const bool wave_streams = wave_any(stream_lane);
     float *stream_row = stream_lane ? a.stream_scores + (size_t)(slot - a.stream_slot0) * (size_t)a.stream_ld : nullptr;
     // tie noise (rm_noise.hpp), exact passes only: the lane's user's row of per-item noise values
     const float *noise_lane = (a.noise_E && user >= 0)
@@ -588,7 +588,9 @@ void k_sweep(SweepArgs a)
     };
 
     // ---- epilogue of one 32-item x 32-user tile ----
-    unsigned thr_pub = 0;                                       // last key this lane published / observed
+    // last key this lane published / observed (lanes that own no list never follow the shared bound: all ones, so that the test
+    // below is ONE compare whose lane mask the scalar unit can look at)
+    unsigned thr_pub = primary ? 0u : 0xffffffffu;
     auto do_epi = [&](const f32x16 &acc, int tile, unsigned thr_seen, unsigned tile_bits) {
         const int sb = tile * TILE + sub * 32;            // first item of this wave's sub-tile
         float v[16];
@@ -607,7 +609,7 @@ void k_sweep(SweepArgs a)
 #ifdef RM_ABL_NO_MASK
         const bool slow = false;
 #else
-        const bool slow = !f_bits && (__any(nt < sb + 32) || (sb + 32 > n));
+        const bool slow = !f_bits && (wave_any(nt < sb + 32) || (sb + 32 > n));
 #endif
         if (f_bits) {                                             // masked in the accumulators already (do_mfma)
             if (f_nan) {
@@ -668,7 +670,7 @@ void k_sweep(SweepArgs a)
             const float tmin = hw_min3(hw_min3(v[0], v[1], v[2]), hw_min3(v[3], v[4], v[5]), hw_min3(v[6], v[7], v[8]));
             const float tmin2 = hw_min3(hw_min3(v[9], v[10], v[11]), hw_min3(v[12], v[13], v[14]), v[15]);
             vmin = hw_min3(vmin, tmin, tmin2);
-            if (!f_nan) track_min = __any(slot_ok && !(vmax > vmin));
+            if (!f_nan) track_min = wave_any(slot_ok && !(vmax > vmin));
         }
         // tie noise (reference :531-534: added AFTER the validity scan, in real_t): wave-uniform branch, exact passes only
         if (f_noise) {
@@ -690,7 +692,12 @@ void k_sweep(SweepArgs a)
         // also takes its partner's candidate.
         // every partial list of the user (other sub-tile wave, other item splits) publishes its K-th best; the largest
         // of them is a valid lower bound of the final K-th best, so it filters for all of them
-        if (primary && thr_seen > thr_pub) { thr_pub = thr_seen; const float t = ord_unkey(thr_seen); thr = t > thr ? t : thr; }
+        // (behind a wave-level test: the shared bound moves a few dozen times per sweep, the seven vector instructions of the update
+        // were paid on every tile)
+        if (wave_any(thr_seen > thr_pub)) {
+            asm volatile("" ::: "memory");                     // (a real branch: the compiler would turn the block into selects again)
+            if (thr_seen > thr_pub) { thr_pub = thr_seen; const float t = ord_unkey(thr_seen); thr = t > thr ? t : thr; }
+        }
         // (a.ext_topk: k_metrics beyond the lists' reach -- every lane streams its scores and k_select_topk picks the top-K)
         const unsigned long long cm = f_ext ? 0ull : __ballot(tmax >= thr);
         RM_STAT(0, 1); RM_STAT(1, cm != 0); RM_STAT(2, __popcll(cm));
@@ -711,8 +718,8 @@ void k_sweep(SweepArgs a)
                     }
                 }
             }
-            bool more = __any(ov != 0);
-            if (more || __any(pcnt >= pend_cap - 1)) merge_pending();
+            bool more = wave_any(ov != 0);
+            if (more || wave_any(pcnt >= pend_cap - 1)) merge_pending();
             while (more) {                                      // warm-up only: more candidates in one tile than a buffer holds
                 unsigned ov2 = 0;
                 #pragma unroll
@@ -725,7 +732,7 @@ void k_sweep(SweepArgs a)
                         }
                     }
                 }
-                ov = ov2; more = __any(ov != 0);
+                ov = ov2; more = wave_any(ov != 0);
                 merge_pending();
             }
         } else if (cm) {

@@ -235,7 +235,7 @@ void k_sweep64(Sweep64Args a)
         const int c1 = __shfl(pcnt, ul + 16), c2 = __shfl(pcnt, ul + 32), c3 = __shfl(pcnt, ul + 48);
         const int m01 = pcnt > c1 ? pcnt : c1, m23 = c2 > c3 ? c2 : c3;
         const int lim = q == 0 ? (m01 > m23 ? m01 : m23) : 0;
-        for (int i = 0; __any(i < lim); i++) {
+        for (int i = 0; wave_any(i < lim); i++) {
             if (q == 0) {
                 if (i < pcnt) offer_entry(Ps[i * WAVE], Pi[i * WAVE]);
                 if (i < c1) offer_entry(Ps[i * WAVE + 16], Pi[i * WAVE + 16]);
@@ -260,7 +260,7 @@ void k_sweep64(Sweep64Args a)
     const int *pos_item_g = (AUC && group_ok) ? a.pos_item + (a.grow[group] + group) * GU + ul : nullptr;
     // streamed users (see the fp32 sweep): the lane writes its masked scores to the user's row in HBM
     const bool stream_lane = slot_ok && slot >= a.stream_slot0;
-    const bool wave_streams = __any(stream_lane);
+    const bool wave_streams = wave_any(stream_lane);
     double *stream_row = stream_lane ? a.stream_scores + (size_t)(slot - a.stream_slot0) * (size_t)a.stream_ld : nullptr;
     // tie noise (rm_noise.hpp): the lane's user's row of per-item noise values
     const double *noise_lane = (a.noise_E && user >= 0)
@@ -307,7 +307,7 @@ void k_sweep64(Sweep64Args a)
             }
             return;
         }
-        const bool slow = __any(nt < sb + 32) || (sb + 32 > n);
+        const bool slow = wave_any(nt < sb + 32) || (sb + 32 > n);
         if (slow) {
             unsigned mbits = 0;
             auto consume = [&]() {                                  // first consumption of a step peeled: see the fp32 sweep
@@ -367,8 +367,8 @@ void k_sweep64(Sweep64Args a)
                     }
                 }
             }
-            bool more = __any(ov != 0);
-            if (more || __any(pcnt >= pend_cap - 1)) merge_pending();
+            bool more = wave_any(ov != 0);
+            if (more || wave_any(pcnt >= pend_cap - 1)) merge_pending();
             while (more) {                                      // warm-up only
                 unsigned ov2 = 0;
                 #pragma unroll
@@ -381,13 +381,13 @@ void k_sweep64(Sweep64Args a)
                         }
                     }
                 }
-                ov = ov2; more = __any(ov != 0);
+                ov = ov2; more = wave_any(ov != 0);
                 merge_pending();
             }
         } else if (cm) {
             #pragma unroll
             for (int r = 0; r < 8; r++) {
-                if (__any(v[r] >= thr)) {
+                if (wave_any(v[r] >= thr)) {
                     const double o1 = __shfl(v[r], ul + 16), o2 = __shfl(v[r], ul + 32), o3 = __shfl(v[r], ul + 48);
                     if (q == 0 && primary) {
                         const int ib = sb + (r >> 2) * 16 + 4 * (r & 3);
