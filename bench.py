@@ -441,6 +441,7 @@ def measure(torch, dist, binding, prob, steps, warmup, world, gather_buf):
         last = (count[0] - 1) % len(outs)
         if last != 0:
             prob.out.copy_(outs[last])                      # parity_check reads prob.out
+    measure.last_sweep_ms = [float(x) for x in sweep_ms]      # per-step launch durations of the run just timed (the compact legs quote them)
     return dt, float(np.mean(sweep_ms)), float(np.mean(prep_ms)), float(np.mean(fin_ms)), binding.timings()
 
 
@@ -638,11 +639,14 @@ def main():
                 tmo = binding.timings()
                 sho = (tmo.get("timed_slots") or 0) / tmo["total_slots"] if tmo.get("total_slots") else 1.0
                 pk = PEAK_FP32_MFMA_TFLOPS if dto == np.float32 else PEAK_FP64_MFMA_TFLOPS
+                per_step = list(getattr(measure, "last_sweep_ms", [swo]))
                 tfo = 2.0 * no * ko * mo * sho / (swo * 1e-3) / 1e12
                 others[wname] = {"workload": what, "users": mo, "n_items": no, "n_factors": ko, "k_metrics": Ko, "cumulative": cum,
                                  "dtype": "f32" if dto == np.float32 else "f64", "steps": 3, "warmup": 1,
                                  "users_per_s": mo * 3 / dto_, "ms_per_step": dto_ / 3 * 1e3, "sweep_ms": swo, "prep_ms": pro, "finalize_ms": fio,
-                                 "mfma_TFLOPs": tfo, "mfma_peak_TFLOPs": pk, "mfma_frac": tfo / pk}
+                                 "mfma_TFLOPs": tfo, "mfma_peak_TFLOPs": pk, "mfma_frac": tfo / pk,
+                                 # (three steps: one slow step -- seen once at C5, 108 ms among 86 ms ones -- moves the mean by 8 %)
+                                 "sweep_ms_per_step": per_step, "mfma_frac_best_step": tfo / pk * swo / min(per_step)}
                 if args.parity_users > 0:
                     others[wname]["parity"] = parity_check(po, po.out, min(args.parity_users, 512), cpu_seconds=5.0, binding=binding)
                     failed = failed or not others[wname]["parity"]["ok"]
