@@ -304,22 +304,32 @@ inline long long stream_budget_bytes(const Workspace &ws)
 // (rows are padded to 192 items = a whole tile of either size, 64 or 96: the row stride does not depend on the sweep's geometry,
 // which is only known behind the plan read-back -- the rows are built before it, beside the plan kernels)
 inline long long dense_row_words(long long n) { return (n + 191) / 192 * 6; }
-inline bool dense_rows_fit(int m, long long n)
+// Up to 1 GiB of rows always; beyond that (many users at a small item count: 1M users x 27k items = 3.4 GB) when they take no more
+// than a quarter of the HBM that is free -- what the workspace already holds of the rows and of the streamed users' score rows counts
+// as free, so that equal calls get equal answers -- and no more than 8 GiB: the sweep indexes the rows by 32-bit word offsets.
+// (One answer per call: run_call asks once.)
+inline bool dense_rows_fit(const Workspace &ws, int m, long long n)
 {
     const long long words = dense_row_words(n);
-    return (size_t)m * (size_t)words * 4 <= ((size_t)1 << 30) && words <= TRAIN_BITS_MAX_WORDS && !getenv("RM_DEBUG_NO_TRAIN_BITS");
+    if (words > TRAIN_BITS_MAX_WORDS || getenv("RM_DEBUG_NO_TRAIN_BITS")) return false;
+    const unsigned long long bytes = (unsigned long long)m * (unsigned long long)words * 4ull;
+    unsigned long long always = 1ull << 30;
+    if (const char *e = getenv("RM_DEBUG_DENSE_ALWAYS_MB")) always = (unsigned long long)atoll(e) << 20;      // (tests: the branch below at small sizes)
+    if (bytes <= always) return true;
+    if (bytes > (8ull << 30)) return false;
+    return (long long)bytes <= free_plus_owned(ws, {"train_bits", "stream_scores", "sel_hi", "sel_lo"}) / 4;
 }
 // `mask_test`: the rows mark the users' TEST items as well (k_merge_positives puts them back after the sweep; rm_noise.hpp clears
 // the test items' bits in its own copy of a row)
 // `early`: the rows were launched before the plan was known (run(): on the side stream, beside the plan kernels) with the guess
 // `early_masked`; when the guess holds nothing is launched here
-template <class C> inline void set_train_bits(SweepArgs &sa, Ctx &cx, const C &c, int m, int n, hipStream_t stream, bool mask_test, bool early = false, bool early_masked = false)
+template <class C> inline void set_train_bits(SweepArgs &sa, Ctx &cx, const C &c, int m, int n, bool fit, hipStream_t stream, bool mask_test, bool early = false, bool early_masked = false)
 {
     Workspace &ws = cx.ws;
     const long long words = dense_row_words(n);
     const size_t bytes = (size_t)m * (size_t)words * 4;
     sa.train_bits = nullptr; sa.train_words = 0;
-    if (!dense_rows_fit(m, n)) { cx.bits_tag = 0; return; }
+    if (!fit) { cx.bits_tag = 0; return; }
     unsigned *bits = (unsigned *)ws.get("train_bits", bytes);
     // (the exact second pass of the tie noise evaluates a subset of the same users: the rows of the first pass are still there)
     const bool ready = (early && early_masked == mask_test) ||
@@ -333,7 +343,7 @@ template <class C> inline void set_train_bits(SweepArgs &sa, Ctx &cx, const C &c
     cx.bits_tag = c.items_tag; cx.bits_train_p = c.train_p;
     sa.train_bits = bits; sa.train_words = (int)words;
 }
-template <class C> inline void set_train_bits(Sweep64Args &, Ctx &, const C &, int, int, hipStream_t, bool, bool = false, bool = false) {}
+template <class C> inline void set_train_bits(Sweep64Args &, Ctx &, const C &, int, int, bool, hipStream_t, bool, bool = false, bool = false) {}
 inline void set_part_extra(SweepArgs &sa, int extra) { sa.part_extra = extra; }
 inline void set_part_extra(Sweep64Args &, int) {}
 // the sweep variant with the epilogue's switches as constants (rm_sweep.hpp k_sweep SPEC): 1 = dense train rows, 2 = CSR cursor,
@@ -474,7 +484,8 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     // (`mask_test`) is only decided behind the read-back; the guess here is the usual answer, and a wrong guess costs one more
     // launch of the kernel behind it.
     bool bits_early = false, bits_early_masked = false;
-    if (std::is_same<T, float>::value && use_side && !c.ext_bits && dense_rows_fit(m, n) && !getenv("RM_DEBUG_NO_EARLY_BITS")) {
+    const bool dense_ok = std::is_same<T, float>::value && dense_rows_fit(ws, m, n);
+    if (std::is_same<T, float>::value && use_side && !c.ext_bits && dense_ok && !getenv("RM_DEBUG_NO_EARLY_BITS")) {
         SweepArgs probe{};
         const bool guess = want_auc && !ext_topk && !getenv("RM_DEBUG_NO_TEST_MASK");
         const unsigned *had = (const unsigned *)cx.bits_ptr;
@@ -482,7 +493,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
                            had == (const unsigned *)ws.get("train_bits", (size_t)m * (size_t)dense_row_words(n) * 4);
         if (!reuse) {
             hipStream_t sd = fork_side();
-            set_train_bits(probe, cx, c, m, n, sd, guess);
+            set_train_bits(probe, cx, c, m, n, dense_ok, sd, guess);
             HIP_CHECK(hipEventRecord(cx.side_ev[4], sd));
             bits_early = true; bits_early_masked = guess;
         }
@@ -565,7 +576,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     // train row is marked +inf in the tables), not with chunked long rows (more slots than users: their best positives are not in the primary slot),
     // not beyond the lists (k_select_topk works on the stored rows).
     bool mask_test = std::is_same<T, float>::value && want_auc && !ext_topk && !check_nan && n_slots > 0 &&
-                     dense_rows_fit(m, n) && hp.n_slots == hp.n_active && hp.n_only_ndcg == 0 &&
+                     dense_ok && hp.n_slots == hp.n_active && hp.n_only_ndcg == 0 &&
                      nsub * part_splits + 1 <= MAX_PARTS && !getenv("RM_DEBUG_NO_TEST_MASK");
     // rows handed over by another pass: usable when they were built the way this pass would build them (unmasked rows are
     // always valid: the old scheme)
@@ -659,8 +670,8 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             HIP_CHECK(hipStreamWaitEvent(stream, cx.side_ev[4], 0));
             side_guard.pending--;
         }
-        if (use_ext_bits && dense_rows_fit(m, n)) set_ext_bits(sa, c.ext_bits, (int)c.ext_words);
-        else set_train_bits(sa, cx, c, m, n, stream, mask_test, bits_early, bits_early_masked);
+        if (use_ext_bits && dense_ok) set_ext_bits(sa, c.ext_bits, (int)c.ext_words);
+        else set_train_bits(sa, cx, c, m, n, dense_ok, stream, mask_test, bits_early, bits_early_masked);
 
         // ---- positives ----
         if (want_auc) {

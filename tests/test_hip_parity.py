@@ -677,6 +677,58 @@ def test_baseline_c5_item_count(hip, oracle):
     _check_against_oracle(hip, oracle, pr, 50, dtype=np.float64)
 
 
+_DENSE_ROWS_SCRIPT = r"""
+import json, os, sys, numpy as np
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import torch                                           # (before the library: the order bench.py loads them in)
+import bench
+from recometrics_amd import _binding as hip
+from _util import same_bits
+torch.cuda.set_device(0); hip.load(); hip.set_device(0)
+m, n = 360_000, 100_000
+prob = bench.DeviceProblem(torch, torch.device("cuda", 0), m, n, 16, 20, 4242, 10)
+stream = torch.cuda.current_stream().cuda_stream
+def run(env):
+    os.environ.update(env)
+    assert hip.load().rm_release_workspace() == 0
+    free0 = torch.cuda.mem_get_info(0)[0]
+    out = torch.empty_like(prob.out)
+    prob.step(hip, stream, out)
+    torch.cuda.synchronize()
+    used = free0 + out.numel() * out.element_size() - torch.cuda.mem_get_info(0)[0]
+    for key in env:
+        del os.environ[key]
+    return out, used
+cursor, used_cursor = run({"RM_DEBUG_NO_TRAIN_BITS": "1"})
+dense, used_dense = run({})
+res = bench.parity_check(prob, dense, 600, binding=hip)
+print(json.dumps({"used_dense": used_dense, "used_cursor": used_cursor, "rows_bytes": m * ((n + 191) // 192 * 6) * 4,
+                  "same_bits": bool(same_bits(dense.cpu().numpy(), cursor.cpu().numpy()).all()), "parity": res}))
+"""
+
+
+def test_dense_train_rows_of_many_users_in_one_call(hip):
+    """360,000 users x 100,000 items x 16 factors through the device entry in ONE call: the dense train rows of the fp32 sweep are
+    4.5 GB -- beyond the 1 GiB they always get (rm_lib.hip dense_rows_fit: a quarter of the free HBM, 8 GiB at most), row offsets
+    beyond 2^32 bytes -- checked against the compiled reference on a stratified sample that holds the first and the last user
+    block, and bit for bit against the same call over the CSR cursor (RM_DEBUG_NO_TRAIN_BITS).  The workspace grows by the rows.
+    (A process of its own: the inputs live in torch tensors, and torch wants to be loaded before the library.)"""
+    import json
+    import subprocess
+    import sys
+    from oracle.oracle import reference_available
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # (the score rows of streamed users get a fixed budget in both runs, so that the two workspaces differ by the train rows alone)
+    env = dict(os.environ, RM_STREAM_BUDGET_MB="4096")
+    res = subprocess.run([sys.executable, "-c", _DENSE_ROWS_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    got = json.loads(res.stdout.strip().splitlines()[-1])
+    assert got["rows_bytes"] > 2 ** 32 and got["used_dense"] - got["used_cursor"] > 0.9 * got["rows_bytes"], got
+    assert got["same_bits"], "dense train rows and the CSR cursor disagree"
+    assert got["parity"]["ok"] and (got["parity"]["checker"] == "reference") == reference_available(), got
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # boundary behaviour (reference src/recometrics.hpp:359-436, recometrics/wrapper.pyx:226-323)
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
