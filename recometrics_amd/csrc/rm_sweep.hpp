@@ -337,7 +337,7 @@ void k_sweep(SweepArgs a)
 
     // dense train rows (small item counts): one word per lane and tile instead of the cursor below
     const unsigned *tb_row = (a.train_bits && user >= 0) ? a.train_bits + (size_t)user * a.train_words : nullptr;
-    // (the rows are <= 1 GiB in all: a 32-bit word index, advanced by NSUB per tile, addresses them)
+    // (the rows are <= 8 GiB in all, rm_lib.hip dense_rows_fit: a 32-bit word index, advanced by NSUB per tile, addresses them)
     unsigned tb_idx = (a.train_bits && user >= 0) ? (unsigned)user * (unsigned)a.train_words + (unsigned)(t0 * NSUB + sub) : 0u;
     if (user >= 0 && !f_bits) {
         ntc = a.train_p[user]; nte = a.train_p[user + 1];
@@ -708,13 +708,13 @@ void k_sweep(SweepArgs a)
                 if (!__ballot(qmax[qd] >= thr)) continue;         // no lane has a candidate among these four registers
                 #pragma unroll
                 for (int r = 4 * qd; r < 4 * qd + 4; r++) {
+                    // (the lane test alone: wrapped in a wave-level test it compiled into five scalar instructions in front of the
+                    // same exec-mask branch)
                     const bool c = v[r] >= thr;
-                    if (__ballot(c)) {
-                        RM_STAT(3, 1); RM_STAT(4, __popcll(__ballot(c)));
-                        if (c) {
-                            if (pcnt < pend_cap) { Pp[pcnt * WAVE] = pack_key(v[r], sb + mfma32_row(r, h)); pcnt++; }
-                            else ov |= 1u << r;
-                        }
+                    RM_STAT(3, __ballot(c) != 0); RM_STAT(4, __popcll(__ballot(c)));
+                    if (c) {
+                        if (pcnt < pend_cap) { Pp[pcnt * WAVE] = pack_key(v[r], sb + mfma32_row(r, h)); pcnt++; }
+                        else ov |= 1u << r;
                     }
                 }
             }
