@@ -519,7 +519,7 @@ void k_sweep(SweepArgs a)
     // would never arrive and hang the sub-tile barrier)
     static_assert(!EARLY_ARRIVE || NG % 2 == 0, "early arrival needs an even number of factor groups");
     LdsU32Ptr arrive_p = (LdsU32Ptr)(smem + a.sync_off) + sub;
-    auto do_mfma = [&](f32x16 &acc, int buf, int chunk, unsigned tile_bits, bool bits_in_flight) {
+    auto do_mfma = [&](f32x16 &acc, int buf, int chunk, unsigned tile_bits) {
         const float4 *bb = ldsB + buf * BUF_F4 + sub * NG * 64 + h * 32 + ul;      // LDS image [sub][g][h][32 items]
         constexpr int G_STRIDE = 64;
         if (!AF_RESIDENT && !AF_PREFETCH) {
@@ -558,9 +558,7 @@ void k_sweep(SweepArgs a)
             // sweep, where four barriers per tile made it worth 5 %; here +0.6 % at the north-star shape; r3_ab_c2.txt r3zs)
             if (EARLY_ARRIVE && g == NG - 2) {
                 __builtin_amdgcn_sched_barrier(0);
-                // operands landed, and the next tile's DMA share: vmcnt(0) lgkmcnt(0) -- or vmcnt(1) when the unit's newest vector-memory
-                // operation is the dense-row word of the tile after the next (BITS_AHEAD), which nothing here needs yet
-                if (bits_in_flight) __builtin_amdgcn_s_waitcnt(0x0071); else __builtin_amdgcn_s_waitcnt(0x0070);
+                __builtin_amdgcn_s_waitcnt(0x0070);                  // vmcnt(0) lgkmcnt(0): operands landed, and the next tile's DMA share
                 if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"((unsigned)(__UINTPTR_TYPE__)arrive_p), "v"(1u) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -816,20 +814,6 @@ void k_sweep(SweepArgs a)
     if (ntiles > 0) stage(t0 * NC, 0);
     // first tile's word of the dense train row, shifted so that bit (r & 3) + 8 (r >> 2) is accumulator r's item for this lane half
     unsigned tile_bits = (tb_row && ntiles > 0) ? a.train_bits[tb_idx] >> (4 * h) : 0u;
-    // Dense train rows come from HBM (475 MB at C2: no cache holds them) and a word requested one tile ahead is waited for at that
-    // tile's arrive point together with the DMA share -- behind ~1,500 cycles of matrix instructions, less than a loaded HBM round
-    // trip.  BITS_AHEAD: the word of tile i + 2 is requested during tile i as the unit's LAST vector-memory operation and the arrive
-    // point waits for all but that one (loads return in order), so a word has a whole tile more to land.  Not in waves that
-    // stream score rows: their stores share the counter and need not complete in order with the loads.
-#ifdef RM_NO_BITS_AHEAD
-    constexpr bool BITS_AHEAD = false;
-#else
-    constexpr bool BITS_AHEAD = EARLY_ARRIVE && SPEC == 1;      // (resident user factors: one unit per tile; dense rows for sure)
-#endif
-    // (one data flow for every wave of such a kernel; what differs is only whether the arrive point may leave the word in flight)
-    const bool may_fly = BITS_AHEAD && !wave_streams && wave_any(tb_row != nullptr);       // wave-uniform
-    unsigned bits_n1 = 0u;                                            // (BITS_AHEAD) the word of the next tile, requested a tile ago
-    if (BITS_AHEAD && tb_row && ntiles > 1) bits_n1 = a.train_bits[tb_idx + NSUB];
     // vmcnt(0) through the builtin (not asm) so that the compiler's own wait-count bookkeeping sees the drain: every
     // load it issued before this point is known complete and needs no further wait inside the loop.
     __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);
@@ -844,9 +828,6 @@ void k_sweep(SweepArgs a)
 #endif
     };
     unsigned thr_seen = load_thr();                             // (the seeded bound counts from the first tile on)
-    // (BITS_AHEAD: this load drained here, once per block -- left pending across the loop's entry, the compiler's wait-count
-    // bookkeeping answers the first use of the bound inside the loop with a vmcnt(0) per tile, which would also wait for the word)
-    if (BITS_AHEAD) __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);
 #ifdef RM_STATS
     const unsigned long long prof_t1 = __builtin_readcyclecounter();
 #endif
@@ -884,20 +865,13 @@ void k_sweep(SweepArgs a)
             // the NEXT tile's word of the dense train row (the accumulators start from it): in flight during the MFMA phase,
             // drained by the wait at the arrive point
             unsigned bits_next = 0u;
-            bool bits_in_flight = false;
-            if (BITS_AHEAD) {
-                if (tb_row && i + 2 < ntiles) bits_next = a.train_bits[tb_idx + 2 * NSUB];     // (this unit's newest vector-memory operation)
-                bits_in_flight = may_fly && i + 2 < ntiles;
-                tb_idx += NSUB;
-            } else if (c == NC - 1 && tb_row && i + 1 < ntiles) { tb_idx += NSUB; bits_next = a.train_bits[tb_idx]; }      // (shifted once it has landed, below)
+            if (c == NC - 1 && tb_row && i + 1 < ntiles) { tb_idx += NSUB; bits_next = a.train_bits[tb_idx]; }      // (shifted once it has landed, below)
 #ifndef RM_ABL_NO_MFMA
-            do_mfma(acc, unit & 1, c, tile_bits, bits_in_flight);
+            do_mfma(acc, unit & 1, c, tile_bits);
 #endif
 #if !defined(RM_FULL_BARRIER) && !defined(RM_ABL_NO_BARRIER)
 #ifndef RM_ABL_NO_ARRIVE_WAIT
-            // arrive half: the next unit's DMA share has landed (early arrival: waited for inside do_mfma -- what is left here is the
-            // shared bound and the dense-row word, and a word requested two tiles ahead stays in flight)
-            if (!(EARLY_ARRIVE && bits_in_flight)) __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);
+            __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                              // arrive half: the next unit's DMA share has landed
 #endif
             // (a bare ds_add: the builtin goes through the compiler's wave-aggregation of atomics, a dozen instructions per tile;
             // the wave's LDS operations are issued in order, so the arrival cannot overtake its operand reads)
@@ -906,8 +880,7 @@ void k_sweep(SweepArgs a)
 #ifndef RM_ABL_NO_EPI
             if (c == NC - 1) do_epi(acc, t0 + i, thr_seen, tile_bits);
 #endif
-            if (BITS_AHEAD) { tile_bits = bits_n1 >> (4 * h); bits_n1 = bits_next; }
-            else if (c == NC - 1) tile_bits = bits_next >> (4 * h);
+            if (c == NC - 1) tile_bits = bits_next >> (4 * h);
 #if defined(RM_FULL_BARRIER)
             __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                              // the DMA of the next unit has landed
             __syncthreads();
