@@ -24,6 +24,7 @@ if ROOT not in sys.path:
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, chip table: dense f32-input MFMA
 PEAK_FP64_MFMA_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
+BARE_CHAIN_TFLOPS = {"f32": 148.4, "f64": 65.6}      # profiles/r4_peak_f64_mfma.txt: v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64 alone
 
 
 def parse():
@@ -546,7 +547,11 @@ def main():
                                         "profile, not a counter of this run)" % load_traffic(args.workload, m)[1]) if load_traffic(args.workload, m)[1] else None,
                      "kernel": "k_sweep (main launch: %.1f %% of the users)" % (100 * share), "avg_launch_ms": sweep_ms, "flops_per_launch": flops_per_launch,
                      "hbm_equiv_GBs": n * k * esize * m * share / (sweep_ms * 1e-3) / 1e9,
-                     "hbm_equiv_frac": n * k * esize * m * share / (sweep_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+                     "hbm_equiv_frac": n * k * esize * m * share / (sweep_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                     # context, never `frac`: what a bare chain of this matrix instruction sustains on this part under its own power
+                     # limit (a constant of a committed microbenchmark, not a measurement of this run)
+                     "bare_mfma_chain_TFLOPs": BARE_CHAIN_TFLOPS[dname], "frac_of_bare_chain": achieved_tf / BARE_CHAIN_TFLOPS[dname],
+                     "bare_chain_source": "profiles/r4_peak_f64_mfma.txt (scratch/peak_f64.hip on one MI355X)"},
         "stage_ms": {"prep": prep_ms, "sweep": sweep_ms, "finalize": fin_ms, "item_splits": tm.get("item_splits"),
                      "sweep_blocks": tm.get("sweep_blocks"), "lds_bytes": tm.get("lds_bytes")},
     }
