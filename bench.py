@@ -666,12 +666,33 @@ def main():
         # the first real multi-GPU run checks itself: the same workload through rm_set_devices([0 .. N-1]) in ONE (torch-free)
         # process must equal the unsharded call bit for bit -- two distinct devices, peer copies of the item factors over xGMI
         line["multi_gpu_self_check"] = self_check
+        # (every device idle first; the other ranks then wait for the leg on the process group's store -- a host-side wait -- and
+        # not inside a collective, whose kernel would spin on the very devices the child is about to use)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        store = None
+        try:
+            store = dist.distributed_c10d._get_default_store()
+        except Exception:       # noqa: BLE001
+            store = None
         if rank == 0:
             try:
                 # (a separate leg: its verdict is in the line -- `bitwise_equal_to_unsharded` -- and does not void the timed number)
                 line["sharded_host"] = run_child(args, m, ["--sharded-child", str(world)])
             except Exception as e:      # noqa: BLE001
                 line["sharded_host"] = {"error": repr(e)}
+            if store is not None:
+                try:
+                    store.set("rm_bench_sharded_leg", "done")
+                except Exception:       # noqa: BLE001
+                    pass
+        elif store is not None:
+            try:
+                import datetime
+                store.wait(["rm_bench_sharded_leg"], datetime.timedelta(seconds=960))
+            except Exception:       # noqa: BLE001
+                pass
         dist.barrier()
 
     if rank == 0 and world == 1 and not args.no_cpu:
