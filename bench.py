@@ -344,11 +344,11 @@ def sharded_child_main(args):
                       "what": "rm_calc_metrics_* (host pointers) with rm_set_devices(%s) against rm_set_devices([0]); second call of each" % devices}))
 
 
-def run_child(args, m, extra):
+def run_child(args, m, extra, timeout=900):
     """Runs a leg as a child process (started from this one, which keeps running: never an exec)."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--users", str(m)] + extra
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     if res.returncode != 0 or not lines:
         return {"error": "child failed (%d): %s" % (res.returncode, res.stderr[-400:])}
@@ -679,7 +679,9 @@ def main():
         if rank == 0:
             try:
                 # (a separate leg: its verdict is in the line -- `bitwise_equal_to_unsharded` -- and does not void the timed number)
-                line["sharded_host"] = run_child(args, m, ["--sharded-child", str(world)])
+                # (bounded: an informational leg must not cost the timed line its place in the driver's record if a first-ever
+                # device-to-device copy stalls; it takes ~15 s)
+                line["sharded_host"] = run_child(args, m, ["--sharded-child", str(world)], timeout=240)
             except Exception as e:      # noqa: BLE001
                 line["sharded_host"] = {"error": repr(e)}
             if store is not None:
@@ -690,7 +692,7 @@ def main():
         elif store is not None:
             try:
                 import datetime
-                store.wait(["rm_bench_sharded_leg"], datetime.timedelta(seconds=960))
+                store.wait(["rm_bench_sharded_leg"], datetime.timedelta(seconds=300))
             except Exception:       # noqa: BLE001
                 pass
         dist.barrier()
