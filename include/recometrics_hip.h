@@ -142,6 +142,11 @@ int rm_get_devices(int32_t *devices, int32_t cap);      /* returns the length of
  * src/recometrics.hpp:114-174); they return RM_ERR_INTERRUPTED. */
 void rm_request_interrupt(void);
 
+/* Test hook: the RM_DEBUG_* / RM_*_MB switches (tests and A/B timing; they choose among code paths with
+ * identical results) are read from the environment once, when the library is loaded; this reads them again.  Not for use
+ * while a call is running. */
+void rm_debug_reload_switches(void);
+
 /* Timings of the most recent successful call on this thread, milliseconds measured with HIP events on the call's
  * stream: out[0] plan+pack+positives, out[1] sweep kernel, out[2] finalize, out[3] whole device section;
  * out[4] = launches of the sweep kernel, out[5] = item splits, out[6] = sweep blocks, out[7] = dynamic LDS bytes,

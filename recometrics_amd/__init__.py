@@ -41,13 +41,31 @@ def _row_major_with_ld(X):
     return np.ascontiguousarray(X), X.shape[1]          # reversed / overlapping / unaligned rows: a size_t cannot express them
 
 
-def _sorted_csr_int32(X, nthreads=0):
-    """CSR with sorted column indices and int32 index arrays (reference __init__.py:26-41; sorts in place, like it).
+def _csr_int32(X):
+    """CSR with int32 index arrays over contiguous buffers (reference __init__.py:26-41), rows AS THEY ARE.
 
-    SciPy's `sort_indices()` walks every stored entry on one thread whenever it does not already know the answer (26-33 ms
-    for the two matrices of BASELINE C2 in front of a 10 ms device call): a matrix whose flag is set is trusted, otherwise the
-    check -- and the sort, should it be needed -- run in the library on `nthreads` host threads (csrc/rm_csr.cpp) and the
-    flag is set, so the next call on the same matrix is free, as with SciPy."""
+    The reference sorts the column indices of every row with SciPy's `sort_indices()` -- one thread walking every stored entry
+    whenever SciPy does not already know the answer, 26-33 ms for the two matrices of BASELINE C2 in front of a 10 ms device
+    call.  Here the rows go to the library as they come: it validates them on the device (sorted? every index in range? index
+    pointers monotone?  csrc/rm_prep.hpp k_check_csr_*, ~40 us) and only when some row is not sorted does it sort a COPY on
+    the host (csrc/rm_csr.cpp) and run again.  Unlike the reference, the caller's matrix is never modified."""
+    from scipy.sparse import csr_array, issparse
+    X = X.tocsr() if issparse(X) and X.format != "csr" else (X if issparse(X) else csr_array(X))
+    if X.indptr.dtype != np.int32 or X.indices.dtype != np.int32:
+        X = csr_array((X.data, X.indices.astype(np.int32), X.indptr.astype(np.int32)), shape=X.shape, copy=False)
+    return X
+
+
+def _sorted_csr_int32(X, nthreads=0):
+    """CSR with sorted column indices and int32 index arrays (reference __init__.py:26-41), for the HOST-side split
+    (split.py: its C++ walks the rows on the CPU and must see what the reference sees).
+
+    A matrix whose index arrays are int32 already is sorted in place, like the reference does; one with int64 indices is
+    copied first (the reference sorts the caller's matrix, then copies).  SciPy's cached answer (`_has_sorted_indices`, the
+    attribute behind the public `has_sorted_indices` property, whose getter runs SciPy's single-threaded check when the answer
+    is unknown) is trusted when it says True; tests/test_csr_cpu.py pins the attribute's name for the installed SciPy --
+    should a release rename it, every call merely pays for the library's check again.  Otherwise the check -- and the sort,
+    should it be needed -- run in the library on `nthreads` host threads (csrc/rm_csr.cpp) and the flag is set."""
     from scipy.sparse import csr_array, issparse
     X = X.tocsr() if issparse(X) and X.format != "csr" else (X if issparse(X) else csr_array(X))
     if X.indptr.dtype != np.int32 or X.indices.dtype != np.int32:
@@ -156,7 +174,8 @@ def calc_reco_metrics(
     cut-off.  Returns a ``pandas.DataFrame`` with one row per user (``as_df=True``) or a dict of arrays plus the
     entry ``"K"``.  Users that cannot be evaluated get NaN.
 
-    Differences from the CPU reference, all documented in DESIGN.md: ``nthreads`` is accepted and ignored;
+    Differences from the CPU reference, all documented in DESIGN.md: ``nthreads`` only drives the host-side sort of a matrix
+    whose rows turn out unsorted (the reference sorts ``X_train`` / ``X_test`` in place; here they are never modified);
     ``break_ties_with_noise`` adds the reference's own noise (``std::mt19937(seed + user)``, reproduced bit for bit on
     the device), scores that are still exactly equal afterwards are ordered by item id; ``hit`` / ``rr`` requested
     alone are computed (the reference leaves them uninitialised) and ``pr_auc`` without ``roc_auc`` is computed from
@@ -222,18 +241,19 @@ def calc_reco_metrics(
     if item_biases is not None:
         A, B = _fold_item_biases(A, B, item_biases, n_items, dtype)
 
-    # ---- normalise storage: sorted int32 CSR, test values and factors in `dtype`, row-major factors ----
-    X_train = _sorted_csr_int32(X_train, nthreads)
+    # ---- normalise storage: int32 CSR (the library validates and, if need be, sorts the rows), test values and factors in
+    # `dtype`, row-major factors; nothing is copied that already has the right type and layout ----
+    X_train = _csr_int32(X_train)
     if X_train.shape[0] > n_users:
-        X_train = _sorted_csr_int32(X_train[:n_users], nthreads)
-    X_test = _sorted_csr_int32(X_test, nthreads)
-    if X_test.dtype != dtype:
-        X_test = X_test.astype(dtype)
+        X_train = _csr_int32(X_train[:n_users])
+    X_test = _csr_int32(X_test)
+    test_values = X_test.data if X_test.data.dtype == dtype else X_test.data.astype(dtype)
     A, lda = _row_major_with_ld(A.astype(dtype, copy=False))
     B, ldb = _row_major_with_ld(B.astype(dtype, copy=False))
+    c = np.ascontiguousarray
 
     arrays = _binding.calc_metrics(
-        A, lda, B, ldb, X_train.indptr, X_train.indices, X_test.indptr, X_test.indices, X_test.data,
+        A, lda, B, ldb, c(X_train.indptr), c(X_train.indices), c(X_test.indptr), c(X_test.indices), c(test_values),
         k, {short: requested[name] for name, short, _ in _METRICS}, bool(cumulative), bool(break_ties_with_noise),
         bool(consider_cold_start), min_items_pool, min_pos_test, nthreads, seed)
 

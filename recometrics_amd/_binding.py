@@ -19,7 +19,7 @@ EXPORTS = (
     "rm_calc_metrics_f32", "rm_calc_metrics_f64", "rm_calc_metrics_dev_f32", "rm_calc_metrics_dev_f64",
     "rm_rank_f32", "rm_rank_f64", "rm_debug_scores_f32", "rm_debug_scores_f64", "rm_has_openmp",
     "rm_last_error", "rm_device_count", "rm_set_device", "rm_set_devices", "rm_get_devices", "rm_request_interrupt",
-    "rm_get_timings", "rm_release_workspace",
+    "rm_get_timings", "rm_release_workspace", "rm_debug_reload_switches",
     "rm_split_f32", "rm_split_f64", "rm_split_size", "rm_split_copy", "rm_split_free", "rm_split_last_error",
     "rm_csr_rows_sorted", "rm_csr_sort_rows",
 )
@@ -75,6 +75,7 @@ def load():
     lib.rm_set_devices.argtypes = [C.POINTER(i32), i32]
     lib.rm_get_devices.argtypes = [C.POINTER(i32), i32]
     lib.rm_request_interrupt.restype = None
+    lib.rm_debug_reload_switches.restype = None
     _lib = lib
     return lib
 
@@ -158,6 +159,11 @@ def get_devices():
 
 def request_interrupt():
     load().rm_request_interrupt()
+
+
+def reload_switches():
+    """Test hook: the library reads its RM_DEBUG_* switches from the environment when it is loaded; this reads them again."""
+    load().rm_debug_reload_switches()
 
 
 def timings():

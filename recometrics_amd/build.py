@@ -51,14 +51,19 @@ def read_stamp():
         return None
 
 
-def needs_build():
-    """The library is rebuilt when it is missing or when it was not built from the sources as they are now: the decision is
-    made on CONTENT (the digest build() records next to the library, csrc/build_stamp.json), not on modification times -- a
-    checkout, a copy to another box or a touched file must neither force nor hide a rebuild."""
+def needs_build(extra_flags=()):
+    """The library is rebuilt when it is missing or when it was not built from the sources as they are now, with the flags asked
+    for: the decision is made on CONTENT (the digest build() records next to the library, csrc/build_stamp.json), not on
+    modification times -- a checkout, a copy to another box or a touched file must neither force nor hide a rebuild.  A library
+    WITHOUT a stamp (a prebuilt .so copied without it: the stamp is git-ignored) is judged by the old rule instead of being
+    rebuilt unconditionally -- it is kept when it is newer than every source."""
     if not os.path.exists(LIB):
         return True
     st = read_stamp()
-    return not st or st.get("sources_sha256") != sources_digest() or st.get("library_bytes") != os.path.getsize(LIB)
+    if not st:
+        return os.path.getmtime(LIB) < max(os.path.getmtime(p) for p in _deps()) or bool(extra_flags)
+    return (st.get("sources_sha256") != sources_digest() or st.get("library_bytes") != os.path.getsize(LIB)
+            or list(st.get("extra_flags", [])) != list(extra_flags))
 
 
 # the sweeps: no SLP vectorisation -- it pairs independent f32 adds into v_pk_add_f32, which issue at less than half the rate of
@@ -82,7 +87,7 @@ def _compile(src, extra):
 
 def build(force=False, verbose=False, extra_flags=(), out=None):
     out = out or LIB
-    if not force and out == LIB and not needs_build():
+    if not force and out == LIB and not needs_build(extra_flags):
         return LIB
     import time
     t_start = time.time()
@@ -95,12 +100,11 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
                          capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
-    if out == LIB and not extra_flags:
+    if out == LIB:                  # every build into LIB leaves its stamp, debug / ablation flags included (`extra_flags`)
         import json
-        import time
         ver = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True).stdout.splitlines()
         json.dump({"sources_sha256": sources_digest(), "library_bytes": os.path.getsize(LIB), "built_at": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
-                   "translation_units": SOURCES, "flags": FLAGS, "sweep_flags": SWEEP_FLAGS, "hipcc": ver[0] if ver else "?",
+                   "translation_units": SOURCES, "flags": FLAGS, "sweep_flags": SWEEP_FLAGS, "extra_flags": list(extra_flags), "hipcc": ver[0] if ver else "?",
                    "seconds": round(time.time() - t_start, 1)}, open(STAMP, "w"), indent=1)
     return out
 

@@ -10,6 +10,9 @@
 #include <atomic>
 #include <cstdint>
 #include <cstring>
+#include <exception>
+#include <mutex>
+#include <system_error>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -42,16 +45,35 @@ inline int pick_threads(int32_t nthreads, int64_t nnz)
     return std::max(nt, 1);
 }
 
+// Runs f(r0, r1) over row ranges on up to `nthreads` threads.  Nothing a worker throws leaves its thread (that would be
+// std::terminate, i.e. the death of the Python process): the first exception is kept and rethrown on the calling thread once
+// every worker has been joined.  A thread that cannot be started (std::system_error: thread or pid limit) is not fatal either:
+// the threads already running are joined by the guard, and the ranges nobody took are run inline.
 template <class F> void parallel_rows(const int32_t *p, int32_t m, int32_t nthreads, F &&f)
 {
     const int nt = pick_threads(nthreads, p[m]);
     if (nt == 1) { f(0, m); return; }
     std::vector<int32_t> cuts;
     row_ranges(p, m, nt, cuts);
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; t++) th.emplace_back([&, t] { f(cuts[t], cuts[t + 1]); });
-    f(cuts[0], cuts[1]);
-    for (auto &x : th) x.join();
+    std::mutex err_mu;
+    std::exception_ptr err;
+    auto guarded = [&](int t) {
+        try { f(cuts[t], cuts[t + 1]); }
+        catch (...) { std::lock_guard<std::mutex> lk(err_mu); if (!err) err = std::current_exception(); }
+    };
+    struct Joiner {
+        std::vector<std::thread> th;
+        ~Joiner() { for (auto &x : th) if (x.joinable()) x.join(); }
+    } workers;
+    workers.th.reserve((size_t)nt);
+    int started = 1;                                             // range 0 is the calling thread's
+    try {
+        for (int t = 1; t < nt; t++) { workers.th.emplace_back(guarded, t); started = t + 1; }
+    } catch (const std::system_error &) { /* no more threads: the rest runs inline below */ }
+    guarded(0);
+    for (int t = started; t < nt; t++) guarded(t);
+    for (auto &x : workers.th) x.join();
+    if (err) std::rethrow_exception(err);
 }
 
 template <class V> void sort_row(int32_t *idx, V *val, int32_t len, std::vector<std::pair<int32_t, V>> &tmp)
@@ -72,6 +94,7 @@ extern "C" int rm_csr_rows_sorted(const int32_t *indptr, const int32_t *indices,
     if (m == 0 || indptr[m] == 0) return 1;
     if (!indices) return -1;
     std::atomic<int> ok{1};
+    try {
     parallel_rows(indptr, m, nthreads, [&](int32_t r0, int32_t r1) {
         for (int32_t r = r0; r < r1 && ok.load(std::memory_order_relaxed); r++) {
             const int32_t *a = indices + indptr[r], *b = indices + indptr[r + 1];
@@ -80,6 +103,7 @@ extern "C" int rm_csr_rows_sorted(const int32_t *indptr, const int32_t *indices,
             if (bad) { ok.store(0, std::memory_order_relaxed); return; }
         }
     });
+    } catch (...) { return -1; }
     return ok.load();
 }
 

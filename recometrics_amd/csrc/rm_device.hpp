@@ -73,7 +73,13 @@ struct Plan {                                     // produced on device, read ba
     int n_heavy;                        // evaluated users with more than HEAVY_NPOS test items (listed by k_classify)
     int n_only_ndcg;                    // evaluated users whose train and test rows cover every item (no tables of positives)
     unsigned long long amax_a, amax_b;  // bit patterns of max|A|, max|B| as doubles (non-negative doubles order like u64)
+    int csr_bad;                        // CSR_* bits: what k_check_csr_ptr / k_check_csr_rows found wrong with the caller's CSR arrays
+    int csr_where;                      // a user (row) that shows the defect, for the message
 };
+// Validation of the caller's CSR arrays on the device (the reference's callers guarantee sorted rows, recometrics/__init__.py:35-41,
+// :553-558, and nobody range-checks: on the CPU a bad index is a segfault).  INDPTR / INDEX defects end the call with RM_ERR_INVALID;
+// rows that are merely unsorted are sorted by the library (host side, csrc/rm_csr.cpp) and the call runs again.
+enum : int { CSR_BAD_INDPTR = 1, CSR_BAD_INDEX = 2, CSR_UNSORTED_TRAIN = 4, CSR_UNSORTED_TEST = 8 };
 
 __device__ __forceinline__ float nan_sentinel_f() { return __int_as_float(0xffffffff); }
 __device__ __forceinline__ float pos_inf_f() { return __int_as_float(0x7f800000); }

@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <csignal>
 #include <functional>
+#include <limits>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -45,13 +46,50 @@ struct RmError { int code; std::string msg; };
                           std::string(#expr) + ": " + hipGetErrorString(e_)};                             \
     } while (0)
 
+// ---- switches of tests and A/B timing ----------------------------------------------------------------------------------
+// The environment is read ONCE, when the library is loaded (and again only when a test asks: rm_debug_reload_switches), never on
+// the path of a call.  Every switch chooses among code paths that produce the same results (DESIGN.md section 7 lists them;
+// tests/test_switches_cpu.py compares this table with that list); nothing here turns a feature of the call off -- the timing
+// builds that drop the tie noise are compiled with -DRM_ABL_NOISE_OFF=1 (scratch/build_abl.py), not switched at run time.
+#ifndef RM_ABL_NOISE_OFF
+#define RM_ABL_NOISE_OFF 0
+#endif
+struct Switches {
+    bool no_train_bits, no_spec, no_side, ext_topk, no_early_bits, no_test_mask, hbm_lists, nsub2, no_pending, no_pos_keys, no_pos_beside,
+         no_seed, no_depth_split, rank_generic, no_fused_auc, no_defer_auc, noise_sequential, no_ext_bits, one_context, noise_per_batch,
+         host_trace, no_noise_beside_last;
+    long long free_mb, stream_budget_mb, dense_always_mb, noise_budget_mb;      // -1 = not set
+    double batch_users;                                                        // 0 = not set
+    int ramp;                                                                  // 0 = not set
+    std::string splits;
+    static bool on(const char *name) { return getenv(name) != nullptr; }
+    static long long num(const char *name) { const char *e = getenv(name); return e ? atoll(e) : -1; }
+    void load()
+    {
+        no_train_bits = on("RM_DEBUG_NO_TRAIN_BITS"); no_spec = on("RM_DEBUG_NO_SPEC"); no_side = on("RM_DEBUG_NO_SIDE");
+        ext_topk = on("RM_DEBUG_EXT_TOPK"); no_early_bits = on("RM_DEBUG_NO_EARLY_BITS"); no_test_mask = on("RM_DEBUG_NO_TEST_MASK");
+        hbm_lists = on("RM_DEBUG_HBM_LISTS"); nsub2 = on("RM_DEBUG_NSUB2"); no_pending = on("RM_DEBUG_NO_PENDING");
+        no_pos_keys = on("RM_DEBUG_NO_POS_KEYS"); no_pos_beside = on("RM_DEBUG_NO_POS_BESIDE"); no_seed = on("RM_DEBUG_NO_SEED");
+        no_depth_split = on("RM_DEBUG_NO_DEPTH_SPLIT"); rank_generic = on("RM_DEBUG_RANK_GENERIC"); no_fused_auc = on("RM_DEBUG_NO_FUSED_AUC");
+        no_defer_auc = on("RM_DEBUG_NO_DEFER_AUC"); noise_sequential = on("RM_DEBUG_NOISE_SEQUENTIAL"); no_ext_bits = on("RM_DEBUG_NO_EXT_BITS");
+        one_context = on("RM_DEBUG_ONE_CONTEXT"); noise_per_batch = on("RM_DEBUG_NOISE_PER_BATCH"); host_trace = on("RM_HOST_TRACE");
+        no_noise_beside_last = on("RM_DEBUG_NO_NOISE_BESIDE_LAST");
+        free_mb = num("RM_DEBUG_FREE_MB"); stream_budget_mb = num("RM_STREAM_BUDGET_MB"); dense_always_mb = num("RM_DEBUG_DENSE_ALWAYS_MB");
+        noise_budget_mb = num("RM_NOISE_BUDGET_MB");
+        const char *b = getenv("RM_BATCH_USERS"); batch_users = b ? atof(b) : 0.0;
+        const char *r = getenv("RM_DEBUG_RAMP"); ramp = r ? atoi(r) : 0;
+        const char *s = getenv("RM_DEBUG_SPLITS"); splits = s ? s : "";
+    }
+    Switches() { load(); }
+};
+Switches g_sw;
+
 // bytes the cached workspaces of ALL contexts hold (RM_DEBUG_FREE_MB: tests simulate a device with that much memory, so that
 // the memory-bound regimes -- user batches sized by the score rows of k_metrics > 256 -- are reached with small inputs)
 std::atomic<long long> g_ws_bytes{0};
 inline long long debug_free_cap()
 {
-    const char *e = getenv("RM_DEBUG_FREE_MB");
-    return e ? (atoll(e) << 20) : -1;
+    return g_sw.free_mb >= 0 ? (g_sw.free_mb << 20) : -1;
 }
 
 // ---- cached device workspace (per device), so that repeated calls do not pay hipMalloc ----
@@ -117,6 +155,7 @@ struct Ctx {
     const void *bits_ptr = nullptr; long long bits_words = 0; int bits_m = 0;      // dense train rows as last built (set_train_bits)
     unsigned long long bits_tag = 0; const int *bits_train_p = nullptr;             // ... by which call (Call::items_tag) and for which rows
     bool bits_masked = false;                                                       // ... with the test items marked too
+    bool bits_partial = false;                                                      // ... for a subset of the users only (Call::only_users)
     unsigned long long packed_amax_b = 0; int packed_nonfinite_b = 0;
 };
 std::mutex g_ctx_mu;
@@ -177,7 +216,14 @@ template <class T> struct Call {          // one calc_metrics call; every pointe
     // touch in this array (its slice of a range-wide one); the exact pass over all flagged users of the range follows the
     // last batch (noise_exact_pass) -- per batch it costs two host-side waits that keep the next batch from being enqueued
     int *first_pass_flags = nullptr;
+    // the CSR arrays of these users have been validated by an earlier pass of the same call (plan kernels k_check_csr_*)
+    bool csr_checked = false;
+    // dense train rows: decided once per call (-1 = not yet: run() asks dense_rows_fit itself) -- every pass of a call gets the
+    // answer the first one got, whatever the passes in between have allocated
+    int dense_fit = -1;
 };
+// internal status: some CSR row is not sorted (the entry points sort a copy of the rows and run again; never returned to a caller)
+constexpr int RM_INTERNAL_UNSORTED = 1000;
 
 inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
@@ -294,7 +340,7 @@ inline long long free_plus_owned(const Workspace &ws, std::initializer_list<cons
 }
 inline long long stream_budget_bytes(const Workspace &ws)
 {
-    if (const char *e = getenv("RM_STREAM_BUDGET_MB")) return atoll(e) << 20;
+    if (g_sw.stream_budget_mb >= 0) return g_sw.stream_budget_mb << 20;
     return free_plus_owned(ws, {"stream_scores", "sel_hi", "sel_lo"}) / 3;
 }
 
@@ -307,14 +353,14 @@ inline long long dense_row_words(long long n) { return (n + 191) / 192 * 6; }
 // Up to 1 GiB of rows always; beyond that (many users at a small item count: 1M users x 27k items = 3.4 GB) when they take no more
 // than a quarter of the HBM that is free -- what the workspace already holds of the rows and of the streamed users' score rows counts
 // as free, so that equal calls get equal answers -- and no more than 8 GiB: the sweep indexes the rows by 32-bit word offsets.
-// (One answer per call: run_call asks once.)
+// (One answer per call: the first pass asks, Call::dense_fit carries the answer to the others.)
 inline bool dense_rows_fit(const Workspace &ws, int m, long long n)
 {
     const long long words = dense_row_words(n);
-    if (words > TRAIN_BITS_MAX_WORDS || getenv("RM_DEBUG_NO_TRAIN_BITS")) return false;
+    if (words > TRAIN_BITS_MAX_WORDS || g_sw.no_train_bits) return false;
     const unsigned long long bytes = (unsigned long long)m * (unsigned long long)words * 4ull;
     unsigned long long always = 1ull << 30;
-    if (const char *e = getenv("RM_DEBUG_DENSE_ALWAYS_MB")) always = (unsigned long long)atoll(e) << 20;      // (tests: the branch below at small sizes)
+    if (g_sw.dense_always_mb >= 0) always = (unsigned long long)g_sw.dense_always_mb << 20;      // (tests: the branch below at small sizes)
     if (bytes <= always) return true;
     if (bytes > (8ull << 30)) return false;
     return (long long)bytes <= free_plus_owned(ws, {"train_bits", "stream_scores", "sel_hi", "sel_lo"}) / 4;
@@ -333,11 +379,13 @@ template <class C> inline void set_train_bits(SweepArgs &sa, Ctx &cx, const C &c
     unsigned *bits = (unsigned *)ws.get("train_bits", bytes);
     // (the exact second pass of the tie noise evaluates a subset of the same users: the rows of the first pass are still there)
     const bool ready = (early && early_masked == mask_test) ||
-                       (c.same_train_rows && cx.bits_ptr == (const void *)bits && cx.bits_words == words && cx.bits_m == m && cx.bits_masked == mask_test);
+                       (c.same_train_rows && !cx.bits_partial && cx.bits_ptr == (const void *)bits && cx.bits_words == words && cx.bits_m == m && cx.bits_masked == mask_test);
     if (!ready) {
         const unsigned blocks = (unsigned)std::min<long long>(((long long)m + TRAIN_BITS_WAVES - 1) / TRAIN_BITS_WAVES, 256 * 8);
         hipLaunchKernelGGL(k_train_bits, dim3(blocks), dim3(TRAIN_BITS_WAVES * WAVE), sizeof(unsigned) * (size_t)TRAIN_BITS_WAVES * (size_t)words, stream,
-                           m, n, (int)words, c.train_p, c.train_i, mask_test ? c.test_p : nullptr, c.test_i, bits);
+                           m, n, (int)words, c.train_p, c.train_i, mask_test ? c.test_p : nullptr, c.test_i, bits,
+                           (const Plan *)ws.get("plan", sizeof(Plan)), c.only_users);
+        cx.bits_partial = c.only_users != nullptr;
     }
     cx.bits_ptr = (const void *)bits; cx.bits_words = words; cx.bits_m = m; cx.bits_masked = mask_test;
     cx.bits_tag = c.items_tag; cx.bits_train_p = c.train_p;
@@ -350,9 +398,9 @@ inline void set_part_extra(Sweep64Args &, int) {}
 // both with every score finite, no tie noise and the top-K lists in reach; anything else reads the switches at run time
 inline void set_spec(SweepArgs &sa)
 {
-    sa.spec = (sa.check_nan || sa.noise_E || sa.ext_topk || getenv("RM_DEBUG_NO_SPEC")) ? 0 : (sa.train_bits ? 1 : 2);
+    sa.spec = (sa.check_nan || sa.noise_E || sa.ext_topk || g_sw.no_spec) ? 0 : (sa.train_bits ? 1 : 2);
 }
-inline void set_spec(Sweep64Args &sa) { sa.spec = (sa.check_nan || sa.noise_E || sa.ext_topk || getenv("RM_DEBUG_NO_SPEC")) ? 0 : 1; }
+inline void set_spec(Sweep64Args &sa) { sa.spec = (sa.check_nan || sa.noise_E || sa.ext_topk || g_sw.no_spec) ? 0 : 1; }
 inline void set_ext_bits(SweepArgs &sa, const unsigned *bits, int words) { sa.train_bits = bits; sa.train_words = words; }
 inline void set_ext_bits(Sweep64Args &, const unsigned *, int) {}
 
@@ -403,7 +451,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     } side_guard{cx};
     auto fork_side = [&]() { hipStream_t sd = side_stream(); HIP_CHECK(hipEventRecord(cx.side_ev[0], stream)); HIP_CHECK(hipStreamWaitEvent(sd, cx.side_ev[0], 0)); side_guard.pending++; return sd; };
     auto join_side = [&]() { HIP_CHECK(hipEventRecord(cx.side_ev[1], cx.side_stream)); HIP_CHECK(hipStreamWaitEvent(stream, cx.side_ev[1], 0)); side_guard.pending = 0; };
-    const bool use_side = !getenv("RM_DEBUG_NO_SIDE");
+    const bool use_side = !g_sw.no_side;
 
     // ---- plan ----
     int *flags = (int *)ws.get("flags", sizeof(int) * (size_t)m);
@@ -415,13 +463,20 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     ClassifyArgs ca{m, n, K, c.train_p, c.test_p, req, c.cold ? 1 : 0, min_items_pool, min_pos_test, want_auc ? 1 : 0,
                     flags, user_nslots, heavy_users, plan};
     ca.only = c.only_users;
+    // the caller's CSR arrays are validated here, in front of everything that indexes by them (an out-of-range column index in
+    // k_train_bits would be a memory fault; on the CPU reference it is a segfault): 80 MB of indices at BASELINE C2, ~40 us
+    if (!c.csr_checked) {
+        hipLaunchKernelGGL(k_check_csr_ptr, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, c.train_p, c.nnz_train, c.test_p, c.nnz_test, plan);
+        hipLaunchKernelGGL(k_check_csr_rows, dim3((unsigned)std::min<long long>(((long long)m * CHECK_ROW_LANES + 255) / 256, 256 * 16)), dim3(256), 0, stream,
+                           m, n, c.train_p, c.train_i, c.test_p, c.test_i, plan, c.only_users);
+    }
     // Users with more than POS_CHUNK test items are "streamed" (rm_device.hpp STREAM_CLASS) when a score row for each of
     // them fits the HBM budget: a third of the free memory unless RM_STREAM_BUDGET_MB says otherwise (0 = never; such
     // users then take one sweep slot per chunk of their test row -- same results, the contraction repeated per chunk).
     const long long stream_ld_max = ((long long)n + 191) / 192 * 192;             // row stride for either tile size (64 / 96 items)
     // k_metrics beyond the sweep's lists (append buffers + wave compaction reach 256): every user is streamed and
     // k_select_topk picks its top-K from the stored row -- any k_metrics <= n, at one score row of HBM per user
-    const bool ext_topk = K > 256 || getenv("RM_DEBUG_EXT_TOPK") != nullptr;
+    const bool ext_topk = K > 256 || g_sw.ext_topk;
     if (want_auc || ext_topk) {
         const long long cap = stream_budget_bytes(ws) / (stream_ld_max * (long long)sizeof(T));
         // (a pass over a subset of the users -- the exact second pass of the fp32 tie noise -- stores rows for that subset only)
@@ -484,12 +539,14 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     // (`mask_test`) is only decided behind the read-back; the guess here is the usual answer, and a wrong guess costs one more
     // launch of the kernel behind it.
     bool bits_early = false, bits_early_masked = false;
-    const bool dense_ok = std::is_same<T, float>::value && dense_rows_fit(ws, m, n);
-    if (std::is_same<T, float>::value && use_side && !c.ext_bits && dense_ok && !getenv("RM_DEBUG_NO_EARLY_BITS")) {
+    // (one answer per call: a later pass -- the exact passes of the tie noise, on this or on a peer context with less free memory --
+    // carries the first pass's answer; rows handed over by another pass are proof that they fit)
+    const bool dense_ok = std::is_same<T, float>::value && (c.ext_bits ? true : c.dense_fit >= 0 ? c.dense_fit != 0 : dense_rows_fit(ws, m, n));
+    if (std::is_same<T, float>::value && use_side && !c.ext_bits && dense_ok && !g_sw.no_early_bits) {
         SweepArgs probe{};
-        const bool guess = want_auc && !ext_topk && !getenv("RM_DEBUG_NO_TEST_MASK");
+        const bool guess = want_auc && !ext_topk && !g_sw.no_test_mask;
         const unsigned *had = (const unsigned *)cx.bits_ptr;
-        const bool reuse = c.same_train_rows && had && cx.bits_words == dense_row_words(n) && cx.bits_m == m && cx.bits_masked == guess &&
+        const bool reuse = c.same_train_rows && had && !cx.bits_partial && cx.bits_words == dense_row_words(n) && cx.bits_m == m && cx.bits_masked == guess &&
                            had == (const unsigned *)ws.get("train_bits", (size_t)m * (size_t)dense_row_words(n) * 4);
         if (!reuse) {
             hipStream_t sd = fork_side();
@@ -501,6 +558,13 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     Plan hp;
     HIP_CHECK(hipMemcpyAsync(&hp, plan, sizeof(Plan), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
+    if (hp.csr_bad) { cx.bits_tag = 0; cx.bits_ptr = nullptr; }          // (dense train rows launched beside the plan were not built)
+    if (hp.csr_bad & CSR_BAD_INDPTR)
+        throw RmError{RM_ERR_INVALID, "CSR index pointers of row " + std::to_string((long long)c.user0 + hp.csr_where) + " are negative, decreasing or beyond the index array"};
+    if (hp.csr_bad & CSR_BAD_INDEX)
+        throw RmError{RM_ERR_INVALID, "CSR column index out of range [0, " + std::to_string(n) + ") in row " + std::to_string((long long)c.user0 + hp.csr_where)};
+    if (hp.csr_bad & (CSR_UNSORTED_TRAIN | CSR_UNSORTED_TEST))
+        throw RmError{RM_INTERNAL_UNSORTED, "CSR rows are not sorted"};
 
     const int n_slots = hp.n_slots, n_groups = hp.n_groups;
     const int jmax = want_auc ? hp.jmax : 0;
@@ -527,7 +591,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         return want_auc ? (head + tb - 1) / tb * tb + (size_t)GROUPS_PER_BLOCK * (1 << j) * GU * (sizeof(T) + 4) : head;
     };
     auto lds_need_n = [&](bool with_lists, int ns) { return lds_need_j(with_lists, ns, jmax); };
-    if (!ext_topk && P::max_nsub >= 3 && NG <= 8 && lds_need_n(true, 3) + SYNC_BYTES <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS") && !getenv("RM_DEBUG_NSUB2"))
+    if (!ext_topk && P::max_nsub >= 3 && NG <= 8 && lds_need_n(true, 3) + SYNC_BYTES <= LDS_LIMIT && !g_sw.hbm_lists && !g_sw.nsub2)
         nsub = 3;
     const int tile_items = 32 * nsub, n_waves = 4 * nsub;
     const int tiles_total = (n + tile_items - 1) / tile_items;
@@ -562,7 +626,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             }
         }
     }
-    if (const char *e = getenv("RM_DEBUG_SPLITS")) {                                // A/B timing and tests: "S" or "S,tail_ublocks,tail_splits"
+    if (const char *e = g_sw.splits.empty() ? nullptr : g_sw.splits.c_str()) {                                // A/B timing and tests: "S" or "S,tail_ublocks,tail_splits"
         int v[3] = {1, 0, 0};
         sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]);
         n_splits = std::max(1, std::min(v[0], std::max(1, MAX_PARTS / nsub)));
@@ -577,7 +641,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     // not beyond the lists (k_select_topk works on the stored rows).
     bool mask_test = std::is_same<T, float>::value && want_auc && !ext_topk && !check_nan && n_slots > 0 &&
                      dense_ok && hp.n_slots == hp.n_active && hp.n_only_ndcg == 0 &&
-                     nsub * part_splits + 1 <= MAX_PARTS && !getenv("RM_DEBUG_NO_TEST_MASK");
+                     nsub * part_splits + 1 <= MAX_PARTS && !g_sw.no_test_mask;
     // rows handed over by another pass: usable when they were built the way this pass would build them (unmasked rows are
     // always valid: the old scheme)
     const bool use_ext_bits = c.ext_bits != nullptr && c.ext_words == dense_row_words(n) && (!c.ext_masked || mask_test);
@@ -585,11 +649,11 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     const int n_part = nsub * part_splits + (mask_test ? 1 : 0);
     const int part_extra = mask_test ? 1 : 0;
     auto lds_need = [&](bool with_lists) { return lds_need_n(with_lists, nsub); };
-    const bool list_in_lds = !ext_topk && lds_need(true) + SYNC_BYTES <= LDS_LIMIT && !getenv("RM_DEBUG_HBM_LISTS");
+    const bool list_in_lds = !ext_topk && lds_need(true) + SYNC_BYTES <= LDS_LIMIT && !g_sw.hbm_lists;
     size_t lds_total = lds_need(list_in_lds);
     // per-lane pending buffers for top-K candidates behind everything else when 2..8 keys per lane still fit
     // (fp32: not for the append-buffer lists of K > 32, whose appends are already single stores)
-    const bool want_pending = !ext_topk && P::has_pending && (list_in_lds || K <= 32 || P::pending_for_append) && !getenv("RM_DEBUG_NO_PENDING");
+    const bool want_pending = !ext_topk && P::has_pending && (list_in_lds || K <= 32 || P::pending_for_append) && !g_sw.no_pending;
     const size_t per_key = (size_t)n_waves * WAVE * P::pend_key_bytes;            // one key per lane and wave
     int pend_cap = 0; size_t pend_off = 0, sync_off = 0;
     if (P::block_carve) {
@@ -687,12 +751,12 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
                           flags, user_nslots, uslot_base, slot_index, grow, pos_tmp, pos_order, pos_score, pos_item, GU};
             pa.noise_row = c.noise_row; pa.noise_row0 = c.noise_row0; pa.noise_E = c.noise_E; pa.noise_ld = c.noise_ld;
             pa.noise_flag = c.noise_flag; pa.plan = plan;
-            if (sizeof(T) == 4 && !getenv("RM_DEBUG_NO_POS_KEYS"))
+            if (sizeof(T) == 4 && !g_sw.no_pos_keys)
                 pa.pos_key = (unsigned long long *)ws.get("pos_key", 8 * ((size_t)std::max<long long>(c.nnz_test, 1) + 8));
             // The streamed users' positives (scores, then the all-pairs rank of long test rows: vector work) run on the side stream
             // beside the table users' (whose scoring is an L2 gather): two chains of two kernels each instead of four kernels in a row
             hipStream_t ps = stream;
-            const bool pos_beside = use_side && n_stream > 0 && stream_slot0 > 0 && !getenv("RM_DEBUG_NO_POS_BESIDE");
+            const bool pos_beside = use_side && n_stream > 0 && stream_slot0 > 0 && !g_sw.no_pos_beside;
             if (n_stream > 0) {
                 const size_t nz = (size_t)std::max<long long>(c.nnz_test, 1);
                 spos_score = (T *)ws.get("spos_score", sizeof(T) * nz);
@@ -727,7 +791,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         typedef typename std::remove_pointer<decltype(typename P::Args{}.thr_shared)>::type ThrT;
         ThrT *thr_shared = (ThrT *)ws.get("thr_shared", sizeof(ThrT) * (size_t)n_slots);
         HIP_CHECK(hipMemsetAsync(thr_shared, 0, sizeof(ThrT) * (size_t)n_slots, stream));
-        if (want_auc && !ext_topk && !getenv("RM_DEBUG_NO_SEED"))
+        if (want_auc && !ext_topk && !g_sw.no_seed)
             hipLaunchKernelGGL((k_seed_thresholds<T, ThrT>), dim3(cdiv(n_slots, 256)), dim3(256), 0, stream, n_slots, stream_slot0, K, GU, slot_user, slot_chunk,
                                user_nslots, flags, c.test_p, grow, pos_score, spos_score, thr_shared);
         sa.thr_shared = thr_shared;
@@ -753,7 +817,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         // the tables per block), the shallow blocks [0, u_split) get their own launch with LDS lists.  The two launches
         // run side by side on two streams so that neither pays a partially filled last round of its own.
         int u_split = 0, j_shallow = -1;
-        if (P::block_carve && !list_in_lds && K <= 32 && want_auc && !getenv("RM_DEBUG_HBM_LISTS") && !getenv("RM_DEBUG_NO_DEPTH_SPLIT")) {
+        if (P::block_carve && !list_in_lds && K <= 32 && want_auc && !g_sw.hbm_lists && !g_sw.no_depth_split) {
             for (int j = jmax - 1; j >= 0 && j_shallow < 0; j--)
                 if (lds_need_j(true, nsub, j) + SYNC_BYTES <= LDS_LIMIT) j_shallow = j;
             if (j_shallow >= 0) u_split = hp.class_offset[j_shallow + 1] / (GROUPS_PER_BLOCK * GU);
@@ -804,12 +868,12 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     // the streamed users' ranks (HBM-bound: the stored score rows) run on the side stream beside the short kernels of the others
     fa.stream_slot0 = stream_slot0; fa.stream_scores = stream_scores; fa.stream_ld = stream_ld;
     fa.spos_score = spos_score; fa.spos_item = spos_item; fa.shist = shist;
-    fa.rank_generic = getenv("RM_DEBUG_RANK_GENERIC") ? 1 : 0;
+    fa.rank_generic = (g_sw.rank_generic ? 1 : 0);
     const bool ranks_beside = use_side && n_slots > 0 && want_auc && n_stream > 0;
     // one block of k_rank_streamed per row (rows up to 32,768 items) with the user's table in LDS: the block also walks its counts
     // (k_auc_streamed's job); k_auc_streamed is then only launched when some row is too long for that
     bool auc_launch = true;
-    if (stream_parts == 1 && !getenv("RM_DEBUG_NO_FUSED_AUC")) {
+    if (stream_parts == 1 && !g_sw.no_fused_auc) {
         fa.fused_auc = 1 | (mask_test ? 2 : 0);
         long long top = 1;
         while (top <= hp.max_npos) top <<= 1;
@@ -854,7 +918,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             hipLaunchKernelGGL((k_finalize<T, T>), dim3(cdiv(s1 - s0, FIN_THREADS)), dim3(FIN_THREADS), fin_lds, stream, fa);
         };
         fa.auc_defer_slot0 = n_slots;
-        if (ranks_beside && (req & (RQ_ROC | RQ_PR)) && !getenv("RM_DEBUG_NO_DEFER_AUC")) {
+        if (ranks_beside && (req & (RQ_ROC | RQ_PR)) && !g_sw.no_defer_auc) {
             // nothing of k_finalize but the two AUC values of the streamed users needs the side stream: it runs for everybody while
             // their ranks are still being counted there, and a short kernel fills those two in behind the join
             fa.auc_defer_slot0 = stream_slot0;
@@ -897,7 +961,7 @@ template <class T> struct NoiseGeom {
         d_ld = ((long long)n * per + MT_N - 1) / MT_N * MT_N;
         const long long row_bytes = e_ld * (long long)sizeof(T) + d_ld * 4;
         long long budget;
-        if (const char *e = getenv("RM_NOISE_BUDGET_MB")) budget = atoll(e) << 20;
+        if (g_sw.noise_budget_mb >= 0) budget = g_sw.noise_budget_mb << 20;
         else budget = free_plus_owned(ws, {"noise_draws", "noise_rows"}) / 3;
         cap = std::max<long long>(1, std::min<long long>(budget / row_bytes, 1 << 20));
     }
@@ -905,14 +969,17 @@ template <class T> struct NoiseGeom {
 // per-user mt19937(seed + user) draws -> per-item noise rows for `rows` users (row_user: their indices, null = users 0 .. rows - 1)
 template <class T>
 void noise_make_rows(Ctx &cx, const Call<T> &c0, const NoiseGeom<T> &g, const int *row_user, int rows, const int *train_p, long long user0,
-                     unsigned *D, T *E, hipStream_t stream)
+                     unsigned *D, T *E, hipStream_t stream, const unsigned *own_bits = nullptr, long long own_words = 0)
 {
     const int n = c0.n, m = c0.m;
     hipLaunchKernelGGL(k_mt_draws, dim3(cdiv(rows, MT_WAVES)), dim3(MT_WAVES * WAVE), 0, stream, row_user, rows, c0.seed, user0,
                        train_p, n, g.per, D, g.d_ld);
     // the dense train rows of this call's own first pass (fp32, small item counts), when they cover exactly these users
-    const bool dense = cx.bits_tag != 0 && cx.bits_tag == c0.items_tag && cx.bits_train_p == train_p && cx.bits_m == m && row_user != nullptr;
-    if (dense)
+    const bool dense = cx.bits_tag != 0 && cx.bits_tag == c0.items_tag && cx.bits_train_p == train_p && cx.bits_m == m && row_user != nullptr && !cx.bits_partial;
+    if (own_bits)                                                  // unmasked dense rows built for exactly these users (run_host_range)
+        hipLaunchKernelGGL(k_noise_rows_bits<T>, dim3(rows), dim3(NOISE_ROWS_THREADS), sizeof(int) * (size_t)(2 * own_words + 1), stream, row_user, rows,
+                           own_bits, (int)own_words, n, 0, train_p, c0.train_i, c0.test_p, c0.test_i, D, g.d_ld, E, g.e_ld);
+    else if (dense)
         hipLaunchKernelGGL(k_noise_rows_bits<T>, dim3(rows), dim3(NOISE_ROWS_THREADS), sizeof(int) * (size_t)(2 * cx.bits_words + 1), stream, row_user, rows,
                            (const unsigned *)cx.bits_ptr, (int)cx.bits_words, n, cx.bits_masked ? 1 : 0, train_p, c0.train_i, c0.test_p, c0.test_i,
                            D, g.d_ld, E, g.e_ld);
@@ -953,6 +1020,7 @@ int noise_exact_pass(const Call<T> &c0, const int *flag, const int *skip, int n_
         c.only_users = only; c.noise_row = noise_row; c.noise_row0 = (int)r0; c.noise_E = E; c.noise_ld = g.e_ld; c.noise_flag = nullptr;
         c.first_pass_flags = nullptr; c.flag_snapshot = nullptr;
         c.eval_users = rows;
+        c.csr_checked = true;                                        // (the first pass looked at every row)
         run<T>(c, stream, cx);
     }
     return n_flagged;
@@ -966,7 +1034,7 @@ template <class T>
 void run_call(const Call<T> &c_in, hipStream_t stream, Ctx &cx, std::function<bool()> *defer = nullptr)
 {
     if (defer) *defer = nullptr;
-    if (!c_in.noise || getenv("RM_NOISE_OFF")) { run<T>(c_in, stream, cx); return; }     // RM_NOISE_OFF: A/B timing only
+    if (!c_in.noise || RM_ABL_NOISE_OFF) { run<T>(c_in, stream, cx); return; }
     Call<T> c0 = c_in;
     if (c0.items_tag == 0) c0.items_tag = g_call_counter.fetch_add(1);                   // (a device-pointer call: its passes share B)
     Workspace &ws = cx.ws;
@@ -982,6 +1050,7 @@ void run_call(const Call<T> &c_in, hipStream_t stream, Ctx &cx, std::function<bo
         run<T>(c1, stream, cx);
         return;
     }
+    if (sizeof(T) == 4 && c0.dense_fit < 0) c0.dense_fit = dense_rows_fit(ws, m, c0.n) ? 1 : 0;
     const NoiseGeom<T> g(ws, c0.n);
     const long long e_ld = g.e_ld, d_ld = g.d_ld, cap = g.cap;
     auto make_rows_into = [=, &cx](const int *row_user, int rows, const int *train_p, long long user0, unsigned *D, T *E, hipStream_t st) {
@@ -1018,7 +1087,7 @@ void run_call(const Call<T> &c_in, hipStream_t stream, Ctx &cx, std::function<bo
     // own, and a scatter behind both puts its results over the first pass's.  Users flagged only by the first pass's
     // k_finalize (a top-K score in the zone) get the sequential exact pass below, as does everybody when the ranking outputs
     // of rm_rank_* are wanted.
-    const bool beside = !c0.topk_idx && !c0.only_users && !getenv("RM_DEBUG_NOISE_SEQUENTIAL");
+    const bool beside = !c0.topk_idx && !c0.only_users && !g_sw.noise_sequential;
     int *snap = nullptr;
     if (beside) {
         snap = (int *)ws.get("noise_flag_snap", sizeof(int) * (size_t)m);
@@ -1061,7 +1130,8 @@ void run_call(const Call<T> &c_in, hipStream_t stream, Ctx &cx, std::function<bo
             }
             c.only_users = only; c.noise_row = noise_row; c.noise_row0 = 0; c.noise_E = E; c.noise_ld = e_ld; c.noise_flag = nullptr;
             c.eval_users = n_early;
-            if (cx.bits_tag != 0 && cx.bits_tag == c0.items_tag && cx.bits_train_p == c0.train_p && cx.bits_m == m && !getenv("RM_DEBUG_NO_EXT_BITS")) {
+            c.csr_checked = true;
+            if (cx.bits_tag != 0 && cx.bits_tag == c0.items_tag && cx.bits_train_p == c0.train_p && cx.bits_m == m && !cx.bits_partial && !g_sw.no_ext_bits) {
                 c.ext_bits = (const unsigned *)cx.bits_ptr; c.ext_words = cx.bits_words; c.ext_masked = cx.bits_masked;      // the first pass's rows
             }
             // (whatever fails in there -- the peer context duplicates workspace under memory pressure --, nothing of it may still be
@@ -1281,8 +1351,8 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     // largest batch: ~0.4 s of device work at the rate the sweep sustains (2 n k flop per user), whole user blocks
     const double rate = std::is_same<T, float>::value ? 6.0e13 : 2.5e13;
     double bu = 0.4 * rate / (2.0 * (double)n * (double)k);
-    const char *forced = getenv("RM_BATCH_USERS");                   // tests: equal batches of this size
-    if (forced) bu = atof(forced);
+    const bool forced = g_sw.batch_users > 0;                        // tests: equal batches of this size
+    if (forced) bu = g_sw.batch_users;
     long long batch = (long long)std::min<double>(std::max(bu, 1024.0), 2.0e9);
     batch = (batch + 1023) / 1024 * 1024;
     if (K > 256) {                                                   // one score row per user of the batch (run(): ext_topk),
@@ -1296,8 +1366,7 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     // (profiles/r3_host_entry.txt)
     std::vector<long long> cuts{0};
     {
-        const char *ramp = getenv("RM_DEBUG_RAMP");                 // A/B timing: another first fraction (default: an eighth)
-        const int r0 = ramp ? std::max(2, atoi(ramp)) : 8;
+        const int r0 = g_sw.ramp > 0 ? std::max(2, g_sw.ramp) : 8;    // (RM_DEBUG_RAMP, A/B timing: another first fraction; default: an eighth)
         long long next = (forced || m <= 16384) ? batch : std::min<long long>(batch, std::max<long long>(8192, ((long long)m / r0 + 1023) / 1024 * 1024));
         while (cuts.back() < m) {
             long long b1 = std::min<long long>(m, cuts.back() + next);
@@ -1318,8 +1387,8 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     std::unique_lock<std::mutex> peer_lock;
     // (not with k_metrics > 256: a batch is then sized by the score rows ONE context may hold -- a third of the free memory --
     // and a second context holding as much again leaves the first one's next batch short: RM_ERR_NOMEM on the third batch)
-    const bool rows_bound = K > 256 || getenv("RM_DEBUG_EXT_TOPK") != nullptr;
-    if (n_batches > 1 && !rows_bound && !getenv("RM_DEBUG_ONE_CONTEXT")) {
+    const bool rows_bound = K > 256 || g_sw.ext_topk;
+    if (n_batches > 1 && !rows_bound && !g_sw.one_context) {
         Ctx &pc = peer_context(cx);
         peer_lock = std::unique_lock<std::mutex>(pc.mu);
         if (!pc.own_stream) HIP_CHECK(hipStreamCreateWithFlags(&pc.own_stream, hipStreamNonBlocking));
@@ -1337,12 +1406,25 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     // slice of `range_flag`; ONE exact pass over the flagged users of the whole range follows the last batch.  (Per batch, the
     // exact pass costs two waits on the host -- for the flags, for its own plan -- during which the next batch is not enqueued:
     // 14.6 ms against 10.2 without noise at BASELINE C2, profiles/r4_host_entry.txt.)  Not with the ranking outputs of rm_rank_*.
-    const bool range_noise = h.noise && std::is_same<T, float>::value && n_batches > 1 && !h.topk_idx && !getenv("RM_NOISE_OFF") &&
-                             !getenv("RM_DEBUG_NOISE_PER_BATCH");
-    int *range_flag = nullptr;
+    const bool range_noise = h.noise && std::is_same<T, float>::value && n_batches > 1 && !h.topk_idx && !RM_ABL_NOISE_OFF &&
+                             !g_sw.noise_per_batch;
+    int *range_flag = nullptr, *range_snap = nullptr;
+    // ... and the users flagged by the time the LAST batch launches its sweep -- every user with a test item in the noise zone, in
+    // practice all of them -- are evaluated exactly BESIDE that sweep on a context of their own (`besides` below), as the device entry
+    // does (run_call); what remains behind the last batch is the host-side scatter of their values, and an exact pass over the few
+    // users only a batch's k_finalize flagged (a top-K score in the zone), usually none
+    const bool beside_last = range_noise && !g_sw.no_noise_beside_last;
     if (range_noise) {
         range_flag = (int *)ws.get("noise_flag_range", sizeof(int) * (size_t)m);
         HIP_CHECK(hipMemsetAsync(range_flag, 0, sizeof(int) * (size_t)m, up));      // (in front of batch 0's rows: every batch waits for its rows' event)
+        if (beside_last) {
+            range_snap = (int *)ws.get("noise_flag_range_snap", sizeof(int) * (size_t)m);
+            if (!cx.pinned_small) {
+                HIP_CHECK(hipHostMalloc((void **)&cx.pinned_small, 64, hipHostMallocDefault));
+                HIP_CHECK(hipEventCreateWithFlags(&cx.flags_ev, hipEventDisableTiming));
+                HIP_CHECK(hipEventCreateWithFlags(&cx.pass_ev, hipEventDisableTiming));
+            }
+        }
     }
     auto upload_users = [&](int bi) {                                 // rows [cuts[bi], cuts[bi + 1]) into their places, on `up`
         const long long b0 = cuts[bi], b1 = cuts[bi + 1];
@@ -1356,7 +1438,7 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
         HIP_CHECK(hipEventRecord(cx.up_ev[bi & 1], up));
     };
     // RM_HOST_TRACE (timing studies only): host-side time stamps of the pipeline, printed at the end of the call
-    const bool trace = getenv("RM_HOST_TRACE") != nullptr;
+    const bool trace = g_sw.host_trace;
     std::vector<std::pair<const char *, double>> stamps;
     const auto t_start = std::chrono::steady_clock::now();
     auto stamp = [&](const char *what) { if (trace) stamps.emplace_back(what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count()); };
@@ -1366,6 +1448,7 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     stamp("batch 0 rows enqueued");
     // (`tail`: what the fp32 tie noise still has to look at once the batch is through, run_call; `copy_out`: the batch's device-to-host
     // copies, enqueued behind the batch and once more when the tail rewrote outputs)
+    long long users_copied = 0;                                       // users [0, users_copied) of the range have been handed over to the caller
     struct InFlight { bool on = false; long long b0 = 0; int mb = 0; size_t boff[10]; size_t bo = 0; int which = 0;
                       std::function<bool()> tail; std::function<void()> copy_out; } fl[2];
     auto finish = [&](int which) {                                    // wait for the batch in flight on context `which`, hand its outputs over
@@ -1380,6 +1463,7 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
             if (h.outs[i]) std::memcpy(h.outs[i] + ((size_t)u0 + f.b0) * w, hblocks[which] + f.boff[i], sizeof(T) * (size_t)f.mb * w);
         }
         stamp("outputs scattered");
+        users_copied = std::max<long long>(users_copied, f.b0 + f.mb);
         if (n_batches > 1) {                                          // more than one batch: add up the stage timings
             Ctx &c = *ctxs[which];
             float ta = 0, tb = 0, tc = 0, td = 0;
@@ -1387,6 +1471,105 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
             (void)hipEventElapsedTime(&tc, c.ev[2], c.ev[3]); (void)hipEventElapsedTime(&td, c.ev[0], c.ev[3]);
             cx.acc[0] += ta; cx.acc[1] += tb; cx.acc[2] += tc; cx.acc[3] += td;
             c.ev_recorded = false; cx.ev_recorded = false;
+        }
+    };
+    // ---- fp32 tie noise over the whole range (see `range_noise` above) ----
+    auto range_call = [&]() {                                         // every user of the range, outputs not set
+        Call<T> c{};
+        c.A = dA; c.lda = k; c.B = dB; c.ldb = k; c.m = m; c.n = n; c.k = k;
+        c.train_p = dtrp; c.train_i = dtri; c.nnz_train = nnz_tr;
+        c.test_p = dtep; c.test_i = dtei; c.test_v = dtev; c.nnz_test = nnz_te;
+        c.K = K; c.cumulative = h.cumulative; c.noise = true; c.cold = h.cold; c.min_items_pool = h.mip; c.min_pos_test = h.mpt;
+        c.items_tag = tag; c.seed = h.seed; c.user0 = (long long)u0;
+        c.csr_checked = true;                                         // (every batch has looked at its rows)
+        return c;
+    };
+    size_t x_off[10], x_bo = 0;                                       // layout of an exact pass's metric block: [metric][users of the range x width]
+    for (int i = 0; i < 10; i++) { x_off[i] = x_bo; if (h.outs[i]) x_bo += (size_t)m * (i >= 8 ? 1 : per); }
+    auto scatter_exact = [&](const T *hx, const int *hu, int count) {  // the flagged users' values -> the caller's arrays
+        for (int i = 0; i < 10; i++) {
+            if (!h.outs[i]) continue;
+            const size_t w = i >= 8 ? 1 : per;
+            for (int f = 0; f < count; f++)
+                std::memcpy(h.outs[i] + ((size_t)u0 + hu[f]) * w, hx + x_off[i] + (size_t)hu[f] * w, sizeof(T) * w);
+        }
+    };
+    struct Beside { bool ran = false; int count = 0; T *hx = nullptr; int *hu = nullptr; Ctx *pc = nullptr; std::unique_lock<std::mutex> lock; } bes;
+    // the exact pass beside the last batch's sweep, on the NOISE_SLOT context and its stream: flags as they stand once the last batch
+    // has scored its positives, noise rows for those users (from dense train rows built for them alone), the pipeline for them,
+    // and the copy of their metric block to page-locked memory -- all of it enqueued behind `flags_ev`, none of it waited for here
+    // except the count of the flagged users
+    auto beside_start = [&](long long b0_last, hipEvent_t other) {
+        if (!out_w) return;
+        Ctx &pc = peer_context(cx, NOISE_SLOT);
+        bes.lock = std::unique_lock<std::mutex>(pc.mu);
+        bes.pc = &pc;
+        if (!pc.own_stream) HIP_CHECK(hipStreamCreateWithFlags(&pc.own_stream, hipStreamNonBlocking));
+        hipStream_t ps = pc.own_stream;
+        Workspace &pw = pc.ws;
+        HIP_CHECK(hipStreamWaitEvent(ps, cx.flags_ev, 0));
+        if (other) HIP_CHECK(hipStreamWaitEvent(ps, other, 0));
+        // (the earlier batches' flags as they stand: a flag their k_finalize sets later is the sequential pass's, below)
+        if (b0_last > 0) HIP_CHECK(hipMemcpyAsync(range_snap, range_flag, sizeof(int) * (size_t)b0_last, hipMemcpyDeviceToDevice, ps));
+        int *noise_row = (int *)pw.get("noise_row", sizeof(int) * (size_t)m);
+        int *row_user = (int *)pw.get("noise_row_user", sizeof(int) * (size_t)m);
+        int *counter = (int *)pw.get("noise_counter", sizeof(int));
+        unsigned char *only = (unsigned char *)pw.get("noise_only", (size_t)m);
+        HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(int), ps));
+        hipLaunchKernelGGL(k_noise_assign_rows, dim3(cdiv(m, 256)), dim3(256), 0, ps, m, range_snap, (const int *)nullptr, noise_row, row_user, counter);
+        HIP_CHECK(hipMemcpyAsync(cx.pinned_small + 3, counter, sizeof(int), hipMemcpyDeviceToHost, ps));
+        HIP_CHECK(hipStreamSynchronize(ps));                          // (the last batch's positives are scored; its sweep has just been launched)
+        const int n_early = cx.pinned_small[3];
+        const NoiseGeom<T> g(pw, n);
+        if (n_early <= 0 || n_early > g.cap) return;                  // nobody, or more rows than the budget holds at once: the sequential pass
+        hipLaunchKernelGGL(k_noise_select, dim3(cdiv(m, 256)), dim3(256), 0, ps, m, noise_row, 0, n_early, only);
+        unsigned *D = (unsigned *)pw.get("noise_draws", sizeof(unsigned) * (size_t)n_early * (size_t)g.d_ld);
+        T *E = (T *)pw.get("noise_rows", sizeof(T) * (size_t)n_early * (size_t)g.e_ld);
+        Call<T> c = range_call();
+        const long long words = dense_row_words(n);
+        const bool fit = std::is_same<T, float>::value && dense_rows_fit(pw, m, n);
+        unsigned *bits = nullptr;
+        if (fit) {                                                    // rows of the flagged users alone, train items only
+            bits = (unsigned *)pw.get("train_bits", (size_t)m * (size_t)words * 4);
+            pc.bits_tag = 0; pc.bits_ptr = nullptr;
+            const unsigned blocks = (unsigned)std::min<long long>(((long long)m + TRAIN_BITS_WAVES - 1) / TRAIN_BITS_WAVES, 256 * 8);
+            hipLaunchKernelGGL(k_train_bits, dim3(blocks), dim3(TRAIN_BITS_WAVES * WAVE), sizeof(unsigned) * (size_t)TRAIN_BITS_WAVES * (size_t)words, ps,
+                               m, n, (int)words, dtrp, dtri, (const int *)nullptr, dtei, bits, (const Plan *)nullptr, only);
+            c.ext_bits = bits; c.ext_words = words; c.ext_masked = false;
+        }
+        c.dense_fit = fit ? 1 : 0;
+        noise_make_rows<T>(pc, c, g, row_user, n_early, dtrp, (long long)u0, D, E, ps, bits, words);
+        c.only_users = only; c.noise_row = noise_row; c.noise_row0 = 0; c.noise_E = E; c.noise_ld = g.e_ld; c.eval_users = n_early;
+        T *dx = (T *)pw.get("o_exact", sizeof(T) * std::max<size_t>(x_bo, 1));
+        for (int i = 0; i < 10; i++) c.out[i] = h.outs[i] ? dx + x_off[i] : nullptr;
+        try { run<T>(c, ps, pc); }
+        catch (...) {
+            (void)hipStreamSynchronize(ps);
+            if (pc.side_stream) (void)hipStreamSynchronize(pc.side_stream);
+            g_last_ctx = &cx;
+            throw;
+        }
+        g_last_ctx = &cx;
+        bes.hx = (T *)pc.pinned_get(sizeof(T) * x_bo + sizeof(int) * (size_t)n_early);
+        bes.hu = (int *)(bes.hx + x_bo);
+        HIP_CHECK(hipMemcpyAsync(bes.hx, dx, sizeof(T) * x_bo, hipMemcpyDeviceToHost, ps));
+        HIP_CHECK(hipMemcpyAsync(bes.hu, row_user, sizeof(int) * (size_t)n_early, hipMemcpyDeviceToHost, ps));
+        bes.ran = true; bes.count = n_early;
+    };
+    //  a call that stops between its first passes and the exact one -- interrupt, failure -- must not leave the first
+    // pass's un-noised values of the flagged users in the caller's arrays looking like results: they become NaN
+    auto nan_flagged = [&]() {
+        if (!range_noise || !out_w || users_copied <= 0) return;
+        std::vector<int> hf((size_t)users_copied);
+        if (hipMemcpy(hf.data(), range_flag, sizeof(int) * (size_t)users_copied, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return; }
+        const T nanv = std::numeric_limits<T>::quiet_NaN();
+        for (long long u = 0; u < users_copied; u++) {
+            if (!hf[(size_t)u]) continue;
+            for (int i = 0; i < 10; i++) {
+                if (!h.outs[i]) continue;
+                const size_t w = i >= 8 ? 1 : per;
+                for (size_t j = 0; j < w; j++) h.outs[i][((size_t)u0 + (size_t)u) * w + j] = nanv;
+            }
         }
     };
     try {
@@ -1414,6 +1597,8 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
         c.items_tag = tag;
         c.seed = h.seed; c.user0 = (long long)u0 + b0;
         if (range_noise) c.first_pass_flags = range_flag + b0;
+        const bool snap_here = beside_last && bi == n_batches - 1;
+        if (snap_here) { c.flag_snapshot = range_snap + b0; c.flag_count_host = cx.pinned_small; c.flags_event = cx.flags_ev; }
         // enqueued (one short plan read-back inside; with more than one batch the tie noise's last look at the batch is deferred to
         // finish(): the next batch is enqueued first)
         run_call<T>(c, bs, bc, n_batches > 1 ? &f.tail : nullptr);
@@ -1434,44 +1619,48 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
         // the next batch's rows travel while this batch's sweep runs (the copies below block the host, not the device)
         if (bi + 1 < n_batches && !g_interrupt) upload_users(bi + 1);
         stamp("next rows enqueued");
+        if (snap_here && !g_interrupt) {
+            // (the batch before this one runs on the other context's stream: its positives -- the early flags -- are in place once
+            // its own sweep has been launched, the event run() records as ev[1])
+            hipEvent_t other = (two_ctx && bi > 0) ? ctxs[(bi - 1) & 1]->ev[1] : nullptr;
+            beside_start(b0, other);
+            stamp("exact pass beside the last batch enqueued");
+        }
         if (!two_ctx) finish(which);
-    }
-    } catch (...) {
-        for (int i = 0; i < 2; i++) (void)hipStreamSynchronize(streams[i]);      // nothing may still write into staging that goes away
-        (void)hipStreamSynchronize(up);
-        throw;
     }
     finish(0); finish(1);
     g_last_ctx = &cx;
     if (range_noise && !g_interrupt && out_w) {
-        // the exact pass over the users of the range that the first passes flagged: into a metric block of its own, from which the
-        // host takes the flagged users' values
-        Call<T> c{};
-        c.A = dA; c.lda = k; c.B = dB; c.ldb = k; c.m = m; c.n = n; c.k = k;
-        c.train_p = dtrp; c.train_i = dtri; c.nnz_train = nnz_tr;
-        c.test_p = dtep; c.test_i = dtei; c.test_v = dtev; c.nnz_test = nnz_te;
-        c.K = K; c.cumulative = h.cumulative; c.noise = true; c.cold = h.cold; c.min_items_pool = h.mip; c.min_pos_test = h.mpt;
-        c.items_tag = tag; c.seed = h.seed; c.user0 = (long long)u0;
-        T *dx = (T *)ws.get("o_exact", sizeof(T) * out_w * (size_t)m);
-        size_t off[10], bo = 0;
-        for (int i = 0; i < 10; i++) { off[i] = bo; c.out[i] = h.outs[i] ? dx + bo : nullptr; if (h.outs[i]) bo += (size_t)m * (i >= 8 ? 1 : per); }
+        if (bes.ran) {                                                // (its results left the device while the last batch was sweeping)
+            HIP_CHECK(hipStreamSynchronize(bes.pc->own_stream));
+            scatter_exact(bes.hx, bes.hu, bes.count);
+            stamp("exact pass (beside) scattered");
+        }
+        // the exact pass over the users of the range that the first passes flagged and the pass beside the last batch has not seen
+        // (all of them without it): into a metric block of its own, from which the host takes the flagged users' values
+        Call<T> c = range_call();
+        T *dx = (T *)ws.get("o_exact", sizeof(T) * std::max<size_t>(x_bo, 1));
+        for (int i = 0; i < 10; i++) c.out[i] = h.outs[i] ? dx + x_off[i] : nullptr;
         const int *row_user = nullptr;
-        const int n_flagged = noise_exact_pass<T>(c, range_flag, nullptr, -1, stream, cx, &row_user);
+        const int n_flagged = noise_exact_pass<T>(c, range_flag, bes.ran ? (const int *)range_snap : (const int *)nullptr, -1, stream, cx, &row_user);
         stamp("exact pass enqueued");
         if (n_flagged > 0) {
-            T *hx = (T *)cx.pinned_get(sizeof(T) * bo + sizeof(int) * (size_t)n_flagged);
-            int *hu = (int *)(hx + bo);
-            HIP_CHECK(hipMemcpyAsync(hx, dx, sizeof(T) * bo, hipMemcpyDeviceToHost, stream));
+            T *hx = (T *)cx.pinned_get(sizeof(T) * x_bo + sizeof(int) * (size_t)n_flagged);
+            int *hu = (int *)(hx + x_bo);
+            HIP_CHECK(hipMemcpyAsync(hx, dx, sizeof(T) * x_bo, hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipMemcpyAsync(hu, row_user, sizeof(int) * (size_t)n_flagged, hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
-            for (int i = 0; i < 10; i++) {
-                if (!h.outs[i]) continue;
-                const size_t w = i >= 8 ? 1 : per;
-                for (int f = 0; f < n_flagged; f++)
-                    std::memcpy(h.outs[i] + ((size_t)u0 + hu[f]) * w, hx + off[i] + (size_t)hu[f] * w, sizeof(T) * w);
-            }
+            scatter_exact(hx, hu, n_flagged);
             stamp("exact pass scattered");
         }
+    } else if (bes.pc) (void)hipStreamSynchronize(bes.pc->own_stream);
+    if (g_interrupt) nan_flagged();
+    } catch (...) {
+        for (int i = 0; i < 2; i++) (void)hipStreamSynchronize(streams[i]);      // nothing may still write into staging that goes away
+        (void)hipStreamSynchronize(up);
+        if (bes.pc && bes.pc->own_stream) (void)hipStreamSynchronize(bes.pc->own_stream);
+        nan_flagged();
+        throw;
     }
     HIP_CHECK(hipStreamSynchronize(up));                              // `rb` and the caller's arrays go out of use (also after an interrupt)
     if (trace) {
@@ -1496,11 +1685,22 @@ void validate(const T *A, const T *B, int m, int n, int k, const int *trp, const
 // host-pointer entry: one device (the calling thread's current one), or the devices of rm_set_devices with contiguous user
 // ranges [m g / G, m (g + 1) / G), one host thread + stream + workspace per shard, no exchange between the shards
 template <class T>
-void run_host(const HostCall<T> &h)
+void run_host_once(const HostCall<T> &h)
 {
     if (h.m == 0) return;                                            // reference :428-437: no user, nothing written
     if (h.m < 0 || !h.tep) throw RmError{RM_ERR_INVALID, h.m < 0 ? "m, n, k must be positive" : "null input pointer"};
     validate(h.A, h.B, h.m, h.n, h.k, h.trp, h.tep, h.tei, (long long)h.tep[h.m], h.K, h.lda, h.ldb);
+    // the index pointers say how much of the caller's index arrays is read at all: they are looked at here, on the host (2 (m + 1)
+    // integers), before anything is sized or copied by them; the indices themselves are validated on the device (run())
+    for (const int *p : {h.trp, h.tep}) {
+        int bad = p[0] < 0;
+        for (int u = 0; u < h.m; u++) bad |= p[u + 1] < p[u];
+        if (bad) {
+            int u = 0;
+            while (u < h.m && !(p[u] < 0 || p[u + 1] < p[u])) u++;
+            throw RmError{RM_ERR_INVALID, std::string("CSR index pointers of row ") + std::to_string(u) + " are negative or decreasing (" + (p == h.trp ? "X_train" : "X_test") + ")"};
+        }
+    }
     if (h.trp[h.m] > 0 && !h.tri) throw RmError{RM_ERR_INVALID, "null train indices"};
     // (deviation D8: the reference's walk would use gain 0 for a null Xtest_csr, :620, but its normalisation dereferences
     // the pointer, :870-874 -- a crash there, an error here)
@@ -1551,8 +1751,63 @@ void run_host(const HostCall<T> &h)
     }
     for (auto &w : workers) w.join();
     g_last_ctx = first;
-    for (int g = 0; g < G; g++) if (errs[g].code != RM_OK) throw RmError{errs[g].code, "device " + std::to_string(devs[g]) + ": " + errs[g].msg};
+    for (int g = 0; g < G; g++) if (errs[g].code != RM_OK && errs[g].code != RM_INTERNAL_UNSORTED) throw RmError{errs[g].code, "device " + std::to_string(devs[g]) + ": " + errs[g].msg};
+    for (int g = 0; g < G; g++) if (errs[g].code == RM_INTERNAL_UNSORTED) throw errs[g];
     guard.check();
+}
+
+// The reference's callers hand over CSR rows with sorted column indices (recometrics/__init__.py:35-41 sorts them with SciPy, one
+// thread walking every entry: 26-33 ms at BASELINE C2); here the rows are uploaded as they come and validated on the device (run():
+// k_check_csr_*, ~40 us).  Only when some row turns out unsorted is a copy of the index / value arrays sorted on the host
+// (csrc/rm_csr.cpp, multi-threaded, stable like SciPy's) and the call run again on the copy -- the caller's arrays are const.
+template <class T>
+void run_host(const HostCall<T> &h)
+{
+    try { run_host_once<T>(h); return; }
+    catch (const RmError &e) { if (e.code != RM_INTERNAL_UNSORTED) throw; }
+    if (h.topk_idx) throw RmError{RM_ERR_INVALID, "rm_rank_*: the CSR rows must be sorted (pos_rank is indexed by the caller's entry order)"};
+    const size_t nnz_tr = (size_t)h.trp[h.m], nnz_te = (size_t)h.tep[h.m];
+    std::vector<int> tri(h.tri, h.tri + nnz_tr), tei(h.tei, h.tei + nnz_te);
+    std::vector<T> tev;
+    if (h.tev) tev.assign(h.tev, h.tev + nnz_te);
+    int rc = rm_csr_sort_rows(h.trp, tri.data(), nullptr, 0, h.m, 0);
+    if (rc == RM_OK) rc = rm_csr_sort_rows(h.tep, tei.data(), h.tev ? (void *)tev.data() : nullptr, h.tev ? (int32_t)sizeof(T) : 0, h.m, 0);
+    if (rc != RM_OK) throw RmError{rc, "sorting a copy of the CSR rows failed"};
+    HostCall<T> h2 = h;
+    h2.tri = tri.data(); h2.tei = tei.data(); h2.tev = h.tev ? tev.data() : nullptr;
+    try { run_host_once<T>(h2); }
+    catch (const RmError &e) { if (e.code != RM_INTERNAL_UNSORTED) throw; throw RmError{RM_ERR_INVALID, "CSR rows are not sorted"}; }
+}
+
+// device-pointer entry: the same fall-back through the host (the arrays are const device memory of the caller's: the sorted copies live in
+// the context's workspace)
+template <class T>
+void run_dev(Call<T> c, hipStream_t stream, Ctx &cx)
+{
+    try { run_call<T>(c, stream, cx); return; }
+    catch (const RmError &e) { if (e.code != RM_INTERNAL_UNSORTED) throw; }
+    const size_t m1 = (size_t)c.m + 1, nnz_tr = (size_t)std::max<long long>(c.nnz_train, 0), nnz_te = (size_t)std::max<long long>(c.nnz_test, 0);
+    std::vector<int> trp(m1), tep(m1), tri(std::max<size_t>(nnz_tr, 1)), tei(std::max<size_t>(nnz_te, 1));
+    std::vector<T> tev(c.test_v ? std::max<size_t>(nnz_te, 1) : 0);
+    HIP_CHECK(hipMemcpyAsync(trp.data(), c.train_p, sizeof(int) * m1, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(tep.data(), c.test_p, sizeof(int) * m1, hipMemcpyDeviceToHost, stream));
+    if (nnz_tr) HIP_CHECK(hipMemcpyAsync(tri.data(), c.train_i, sizeof(int) * nnz_tr, hipMemcpyDeviceToHost, stream));
+    if (nnz_te) HIP_CHECK(hipMemcpyAsync(tei.data(), c.test_i, sizeof(int) * nnz_te, hipMemcpyDeviceToHost, stream));
+    if (c.test_v && nnz_te) HIP_CHECK(hipMemcpyAsync(tev.data(), c.test_v, sizeof(T) * nnz_te, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    int rc = rm_csr_sort_rows(trp.data(), tri.data(), nullptr, 0, c.m, 0);
+    if (rc == RM_OK) rc = rm_csr_sort_rows(tep.data(), tei.data(), c.test_v ? (void *)tev.data() : nullptr, c.test_v ? (int32_t)sizeof(T) : 0, c.m, 0);
+    if (rc != RM_OK) throw RmError{rc, "sorting a copy of the CSR rows failed"};
+    int *dtri = (int *)cx.ws.get("sorted_tri", sizeof(int) * std::max<size_t>(nnz_tr, 1));
+    int *dtei = (int *)cx.ws.get("sorted_tei", sizeof(int) * std::max<size_t>(nnz_te, 1));
+    T *dtev = c.test_v ? (T *)cx.ws.get("sorted_tev", sizeof(T) * std::max<size_t>(nnz_te, 1)) : nullptr;
+    if (nnz_tr) HIP_CHECK(hipMemcpyAsync(dtri, tri.data(), sizeof(int) * nnz_tr, hipMemcpyHostToDevice, stream));
+    if (nnz_te) HIP_CHECK(hipMemcpyAsync(dtei, tei.data(), sizeof(int) * nnz_te, hipMemcpyHostToDevice, stream));
+    if (dtev && nnz_te) HIP_CHECK(hipMemcpyAsync(dtev, tev.data(), sizeof(T) * nnz_te, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));                         // (the vectors go out of scope below)
+    c.train_i = dtri; c.test_i = dtei; c.test_v = dtev;
+    try { run_call<T>(c, stream, cx); }
+    catch (const RmError &e) { if (e.code != RM_INTERNAL_UNSORTED) throw; throw RmError{RM_ERR_INVALID, "CSR rows are not sorted"}; }
 }
 
 template <class T>
@@ -1647,7 +1902,7 @@ extern "C" int rm_calc_metrics_dev_##SUFFIX(                                    
         std::lock_guard<std::mutex> lk(cx.mu);                                                                          \
         cx.acc[0] = cx.acc[1] = cx.acc[2] = cx.acc[3] = 0;                                                              \
         c.seed = seed; c.user0 = 0;                                                                                     \
-        run_call<T>(c, (hipStream_t)stream, cx);                                                                        \
+        run_dev<T>(c, (hipStream_t)stream, cx);                                                                         \
     });                                                                                                                 \
 }                                                                                                                       \
 extern "C" int rm_rank_##SUFFIX(                                                                                        \
@@ -1721,6 +1976,8 @@ extern "C" int rm_get_devices(int32_t *devices, int32_t cap)
 }
 
 extern "C" void rm_request_interrupt(void) { g_interrupt = 1; }
+
+extern "C" void rm_debug_reload_switches(void) { g_sw.load(); }
 
 extern "C" int rm_get_timings(double *out, int n)
 {

@@ -27,6 +27,45 @@ __device__ __forceinline__ int chunk_depth(int pc)      // smallest j with 2^j -
     return 32 - __clz(pc);
 }
 
+// ---- validation of the CSR inputs (first kernels of the plan) ----------------------------------------------------------
+// k_check_csr_ptr: index pointers of the m rows start at >= 0, never decrease and end within the index arrays.
+// k_check_csr_rows: every column index lies in [0, n) and every row ascends (equal neighbours allowed, as SciPy's
+// has_sorted_indices); 16 lanes per row, the row strided over them.  Both report through plan->csr_bad; every later kernel that
+// would index by what these arrays hold (k_assign_slots, k_block_rows, k_group_rows, k_train_bits) returns when INDPTR / INDEX is set.
+__global__ void k_check_csr_ptr(int m, const int *train_p, long long nnz_train, const int *test_p, long long nnz_test, Plan *plan)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= m) return;
+    const int a0 = train_p[u], a1 = train_p[u + 1], b0 = test_p[u], b1 = test_p[u + 1];
+    const bool bad = a0 < 0 || a1 < a0 || (long long)a1 > nnz_train || b0 < 0 || b1 < b0 || (long long)b1 > nnz_test;
+    if (bad) { atomicOr(&plan->csr_bad, CSR_BAD_INDPTR); plan->csr_where = u; }
+}
+constexpr int CHECK_ROW_LANES = 16;
+__global__ void k_check_csr_rows(int m, int n, const int *train_p, const int *train_i, const int *test_p, const int *test_i, Plan *plan,
+                                 const unsigned char *only)
+{
+    if (plan->csr_bad & CSR_BAD_INDPTR) return;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int sub = (int)(threadIdx.x % CHECK_ROW_LANES);
+    int bad = 0, where = 0;
+    for (long long u = t / CHECK_ROW_LANES; u < m; u += (long long)gridDim.x * blockDim.x / CHECK_ROW_LANES) {
+        if (only && !only[u]) continue;
+        #pragma unroll
+        for (int which = 0; which < 2; which++) {
+            const int *p = which ? test_p : train_p, *idx = which ? test_i : train_i;
+            const int e1 = p[u + 1];
+            for (int e = p[u] + sub; e < e1; e += CHECK_ROW_LANES) {
+                const int x = idx[e];
+                const int nx = e + 1 < e1 ? idx[e + 1] : 0x7fffffff;
+                int b = ((unsigned)x >= (unsigned)n) ? CSR_BAD_INDEX : 0;
+                if (x > nx) b |= which ? CSR_UNSORTED_TEST : CSR_UNSORTED_TRAIN;
+                if (b) { bad |= b; where = (int)u; }
+            }
+        }
+    }
+    if (bad) { atomicOr(&plan->csr_bad, bad); if (bad & CSR_BAD_INDEX) plan->csr_where = where; }
+}
+
 // users with more than POS_CHUNK test items (an upper bound of the streamed class: eligibility is not looked at), and the
 // decision whether their score rows fit the HBM budget (`cap` rows)
 __global__ void k_count_long(int m, const int *test_p, Plan *plan, const unsigned char *only)
@@ -186,6 +225,7 @@ constexpr int ASSIGN_THREADS = 1024;
 __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign_slots(AssignArgs a)
 {
     __shared__ int blk_count[N_CLASSES], blk_base[N_CLASSES];
+    if (a.plan->csr_bad & CSR_BAD_INDPTR) return;                 // (row lengths that cannot be trusted would index out of the slot arrays)
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     if (threadIdx.x < N_CLASSES) blk_count[threadIdx.x] = 0;
@@ -238,6 +278,7 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign_slots(AssignArgs a)
 __global__ void k_block_rows(const Plan *p, const unsigned char *slot_j, int *blk_j, int *blk_rows, int gu)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p->csr_bad & CSR_BAD_INDPTR) return;
     const int ng = p->n_groups, ns = p->n_slots;
     if (b * GROUPS_PER_BLOCK >= ng) return;
     const int glast = min(ng, (b + 1) * GROUPS_PER_BLOCK) - 1;
@@ -256,6 +297,7 @@ __global__ void k_block_rows(const Plan *p, const unsigned char *slot_j, int *bl
 __global__ void k_group_rows(Plan *p, const int *blk_j, const int *blk_base, const int *blk_total, int *gj, long long *grow)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p->csr_bad & CSR_BAD_INDPTR) return;
     if (g == 0) p->total_rows = *blk_total;
     if (g >= p->n_groups) return;
     const int b = g / GROUPS_PER_BLOCK, jb = blk_j[b];
@@ -354,13 +396,19 @@ constexpr int TRAIN_BITS_WAVES = 4;
 // With `test_p` the TEST items are marked as well (`bits`), and the sweep then never sees a user's own test items: they come
 // back in k_merge_positives (rm_finalize.hpp); the tie noise, which indexes its draws by the train items alone, clears the test
 // items' bits in its own LDS copy of a row (rm_noise.hpp k_noise_rows_bits).
+// `plan`: the CSR arrays are only walked when the plan's validation kernels found every index pointer and index in range (an item
+// beyond n would be an LDS write out of the row).  `only` (optional): rows of the users with a non-zero entry only -- the others'
+// are never read (a pass over a few flagged users of a large range).
 __global__ __launch_bounds__(TRAIN_BITS_WAVES * WAVE) void k_train_bits(int m, int n, int words, const int *train_p, const int *train_i,
-                                                                        const int *test_p, const int *test_i, unsigned *bits)
+                                                                        const int *test_p, const int *test_i, unsigned *bits,
+                                                                        const Plan *plan, const unsigned char *only)
 {
     extern __shared__ unsigned tb_lds[];                      // [TRAIN_BITS_WAVES][words]
+    if (plan && (plan->csr_bad & (CSR_BAD_INDPTR | CSR_BAD_INDEX))) return;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     unsigned *row = tb_lds + (size_t)wv * words;
     for (int u = blockIdx.x * TRAIN_BITS_WAVES + wv; u < m; u += gridDim.x * TRAIN_BITS_WAVES) {
+        if (only && !only[u]) continue;
         for (int w = lane; w < words; w += WAVE) row[w] = (w << 5) >= n ? 0xffffffffu : (((w << 5) + 32 > n) ? (0xffffffffu << (n & 31)) : 0u);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();

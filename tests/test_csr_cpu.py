@@ -83,3 +83,32 @@ def test_api_normalisation_matches_the_reference_recipe():
     coo = sp.coo_array((d, (np.repeat(np.arange(m), np.diff(ip)), ix)), shape=(m, n))
     got = _sorted_csr_int32(coo, 1)
     assert got.format == "csr" and got.has_sorted_indices and (got.toarray() == want.toarray()).all()
+
+
+def test_metric_call_normalisation_leaves_the_rows_alone():
+    """recometrics_amd._csr_int32 (what calc_reco_metrics hands to the library): int32 index arrays, rows in the caller's order,
+    the caller's matrix never modified -- the library validates the rows on the device and sorts a copy when it has to
+    (tests/test_hip_csr_validation.py)"""
+    from recometrics_amd import _csr_int32
+    m, n = 300, 70
+    ip, ix, d = _random_csr(m, n, 0.1, 9, np.float32)
+    for idx_dtype in (np.int32, np.int64):
+        X = sp.csr_array((d.copy(), ix.astype(idx_dtype), ip.astype(idx_dtype)), shape=(m, n))
+        before = (X.indices.copy(), X.data.copy(), X.indptr.copy())
+        got = _csr_int32(X)
+        assert got.indices.dtype == np.int32 and got.indptr.dtype == np.int32
+        assert (got.indices == ix).all() and (got.data == d).all() and (got.indptr == ip).all()      # unsorted as given
+        assert (X.indices == before[0]).all() and (X.data == before[1]).all() and (X.indptr == before[2]).all()
+        if idx_dtype == np.int32:
+            assert got is X
+    coo = sp.coo_array((d, (np.repeat(np.arange(m), np.diff(ip)), ix)), shape=(m, n))
+    assert _csr_int32(coo).format == "csr"
+
+
+def test_scipy_still_has_the_cached_sortedness_attribute():
+    """_sorted_csr_int32 (the split's normalisation) trusts SciPy's cached answer through the private attribute behind the public
+    `has_sorted_indices` property; if a SciPy release renames it the code stays correct but pays for a full check per call --
+    this test says so instead of letting it happen silently"""
+    X = sp.csr_array(np.array([[0, 2, 1], [3, 0, 0]], dtype=np.float64))
+    X.has_sorted_indices = True
+    assert getattr(X, "_has_sorted_indices", None) is True

@@ -237,7 +237,7 @@ def test_random_problem_vs_oracle_f64(hip, oracle, m, n, k, K, mean_c):
                                  {"RM_DEBUG_NSUB2": "1"}, {"RM_DEBUG_NSUB2": "1", "RM_DEBUG_NO_PENDING": "1"}])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_list_schemes_agree(hip, oracle, env, dtype, monkeypatch):
-    """the same problem through every top-K list scheme the sweep has (the library reads the switches per call), with the
+    """the same problem through every top-K list scheme the sweep has (the library reads the switches at load; conftest.py makes it read them again after every monkeypatch.setenv), with the
     CSR cursor instead of the dense train rows, without the seeded bounds, with another item split count, with a two-level
     grid ("S,tail user blocks,tail splits": the cheapest user blocks cut into more item ranges than the others):
     LDS lists without pending buffers, HBM replace-the-minimum lists with and without them, and (fp32, <= 64 factors,
@@ -691,6 +691,7 @@ prob = bench.DeviceProblem(torch, torch.device("cuda", 0), m, n, 16, 20, 4242, 1
 stream = torch.cuda.current_stream().cuda_stream
 def run(env):
     os.environ.update(env)
+    hip.reload_switches()                                  # (the library reads its switches at load: read them again)
     assert hip.load().rm_release_workspace() == 0
     free0 = torch.cuda.mem_get_info(0)[0]
     out = torch.empty_like(prob.out)
@@ -699,6 +700,7 @@ def run(env):
     used = free0 + out.numel() * out.element_size() - torch.cuda.mem_get_info(0)[0]
     for key in env:
         del os.environ[key]
+    hip.reload_switches()
     return out, used
 cursor, used_cursor = run({"RM_DEBUG_NO_TRAIN_BITS": "1"})
 dense, used_dense = run({})

@@ -27,7 +27,7 @@ def test_host_code_under_asan_and_ubsan():
                ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=1",
                UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
                RECOMETRICS_ORACLE_LIB=os.path.join(ROOT, "oracle", "_san", "librecometrics_oracle_san.so"),
-               RECOMETRICS_SPLIT_LIB=os.path.join(ROOT, "oracle", "_san", "librm_split_san.so"))
+               RECOMETRICS_SPLIT_LIB=os.path.join(ROOT, "recometrics_amd", "csrc", "_san", "librm_host_san.so"))
     res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider",
                           os.path.join(ROOT, "tests", "test_oracle_golden.py"), os.path.join(ROOT, "tests", "test_split_cpu.py"),
                           os.path.join(ROOT, "tests", "test_csr_cpu.py")],
