@@ -81,9 +81,9 @@ def host_problem(m, n, k, mean_c, seed, dtype=np.float32, shard=0):
 class DeviceProblem:
     """Synthetic workload resident in HBM (torch tensors are only the memory owner; the hot path gets raw pointers)."""
 
-    def __init__(self, torch, dev, m, n, k, mean_c, seed, K, dtype=np.float32, shard=0, cumulative=False):
+    def __init__(self, torch, dev, m, n, k, mean_c, seed, K, dtype=np.float32, shard=0, cumulative=False, host=None):
         self.m, self.n, self.k, self.K, self.dtype = m, n, k, K, dtype
-        self.host = host_problem(m, n, k, mean_c, seed, dtype, shard)
+        self.host = host if host is not None else host_problem(m, n, k, mean_c, seed, dtype, shard)
         A, B = self.host["A"], self.host["B"]
         (trp, tri), (tep, tei, tev) = self.host["train"], self.host["test"]
         t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
@@ -91,6 +91,7 @@ class DeviceProblem:
         self.trp, self.tri, self.tep, self.tei, self.tev = t(trp), t(tri if tri.size else np.zeros(1, np.int32)), t(tep), t(tei), t(tev)
         self.nnz_tr, self.nnz_te = int(tri.shape[0]), int(tei.shape[0])
         self.cumulative = bool(cumulative)
+        self.noise = False                                                   # break_ties_with_noise of step() unless it says otherwise
         tdt = torch.float32 if dtype == np.float32 else torch.float64
         if not self.cumulative:
             self.out = torch.empty((10, m), dtype=tdt, device=dev)           # per-user metric block
@@ -107,8 +108,9 @@ class DeviceProblem:
         K, m = self.K, self.m
         return o[i * K * m:(i + 1) * K * m].view(m, K) if i < 8 else o[8 * K * m + (i - 8) * m:8 * K * m + (i - 7) * m]
 
-    def step(self, binding, stream, out=None, noise=False):
+    def step(self, binding, stream, out=None, noise=None):
         o = self.out if out is None else out
+        noise = self.noise if noise is None else noise
         binding.calc_metrics_device(
             self.dtype, self.A.data_ptr(), self.k, self.B.data_ptr(), self.k, self.m, self.n, self.k,
             self.trp.data_ptr(), self.tri.data_ptr(), self.nnz_tr, self.tep.data_ptr(), self.tei.data_ptr(),
@@ -223,6 +225,31 @@ def parity_check(prob, out, n_users, noise=False, seed=1, cpu_seconds=15.0, bind
     else:
         info["tie_users"] = 0
     return dict(info, ok=True, max_abs_diff=worst)
+
+
+def default_build_check(prob, out, n_users, binding, cpu_seconds=10.0):
+    """SURVEY.md 8(c) contract item (4): the timed outputs against the reference's DEFAULT build -- vectorised, reassociated dot
+    products (oracle/_ref/librecometrics_ref_fast.so: -march=x86-64-v3, AVX2 + FMA) -- on the stratified sample: every metric
+    within 1e-5 except for users with a near tie, and every user beyond 1e-5 must be one (oracle/ties.py)."""
+    from oracle import oracle as orc
+    from oracle.ties import compare_with_default_build
+    if not orc.reference_available(fast=True):
+        return {"ok": None, "what": "oracle/_ref/librecometrics_ref_fast.so is not on this box"}
+    host = prob.host
+    n_users = int(max(16, min(n_users, cpu_seconds * 1.0e10 / (float(prob.n) * float(prob.k)))))
+    users = stratified_users(host, n_users)
+    A, B, tr, te = sub_problem(host, users)
+    A = np.ascontiguousarray(A)
+    nthreads = max(1, min(256, os.cpu_count() or 1, (2 ** 31 - 1) // int(B.shape[0])))
+    want = orc.Reference(fast=True).calc(A, B, tr, te, prob.K, nthreads=nthreads, noise=False, dtype=prob.dtype, cumulative=prob.cumulative)
+    uidx = torch_index(out, users)
+    got = {orc.NAMES[name]: prob.metric(out, i)[uidx].cpu().numpy() for i, name in enumerate(orc.METRICS)}
+    amax = float(np.abs(A).max() * np.abs(B).max())
+    rec = compare_with_default_build(got, want, lambda who: binding.debug_scores(np.ascontiguousarray(A[who]), B), tr, te, prob.K, prob.dtype,
+                                     prob.k, amax)
+    rec["checker"] = "reference, default-style build (-march=x86-64-v3: vectorised dot products)"
+    rec["sample"] = "stratified"
+    return rec
 
 
 def torch_index(out, users):
@@ -344,10 +371,10 @@ def sharded_child_main(args):
                       "what": "rm_calc_metrics_* (host pointers) with rm_set_devices(%s) against rm_set_devices([0]); second call of each" % devices}))
 
 
-def run_child(args, m, extra, timeout=900):
+def run_child(args, m, extra, timeout=900, workload=None):
     """Runs a leg as a child process (started from this one, which keeps running: never an exec)."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--users", str(m)] + extra
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload or args.workload, "--users", str(m)] + extra
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     if res.returncode != 0 or not lines:
@@ -565,6 +592,13 @@ def main():
         line["parity_checked"] = pc["users"] if pc["ok"] else 0
         line["parity"] = pc
         failed = not pc["ok"]
+        if world == 1 and not args.no_extra:
+            try:
+                line["parity_vs_default_build"] = default_build_check(prob, prob.out, args.parity_users, binding)
+                failed = failed or line["parity_vs_default_build"].get("ok") is False
+            except Exception as e:      # noqa: BLE001
+                line["parity_vs_default_build"] = {"ok": False, "what": repr(e)}
+                failed = True
     if rank == 0 and world == 1 and not args.no_e2e:
         try:
             child = run_child(args, m, ["--e2e-child"])
@@ -623,6 +657,45 @@ def main():
             del p2
         except Exception as e:      # noqa: BLE001
             line["north_star_shape"] = {"error": repr(e)}
+
+    if rank == 0 and world == 1 and not args.no_extra and args.workload != "TUT":
+        # the only realistic workload the reference documents (examples/recometrics_example.ipynb cells 3, 5, 9, 11; BASELINE.md
+        # section 1): 10,000 users x 160,112 items x 50 factors, k = 5, all metrics, API defaults -- tie noise ON.  The small-m
+        # regime (79 user blocks for 256 CUs: the grid is filled by item ranges) and a factor count that is not a multiple of 8
+        # (50 -> 56: seven factor groups, one half empty).  Device-resident step, then the call a user types (SciPy in, dict out).
+        try:
+            mt, nt, kt, dtt, Kt, ct, st = CONFIGS["TUT"]
+            if "prob" in locals() and hasattr(prob, "A"):
+                del prob.A, prob.B
+            torch.cuda.empty_cache()
+            pt = DeviceProblem(torch, dev, mt, nt, kt, ct, st, Kt, dtt)
+            pt.noise = True
+            t_steps, t_warm = 10, 2
+            dtt_, swt, prt, fit, _ = measure(torch, dist, binding, pt, t_steps, t_warm, 1, None)
+            tmt = binding.timings()
+            # (with the noise on, rm_get_timings reports the main pass -- every user on the plain scores; the exact pass of the
+            # flagged users runs beside it)
+            tft = 2.0 * nt * kt * mt / (swt * 1e-3) / 1e12
+            line["tutorial"] = {
+                "workload": "TUT: %d users x %d items, %d factors fp32, k=%d, all metrics, break_ties_with_noise=True (the notebook's call)" % (mt, nt, kt, Kt),
+                "users_per_s": mt * t_steps / dtt_, "steps": t_steps, "warmup": t_warm, "ms_per_step": dtt_ / t_steps * 1e3,
+                "sweep_ms": swt, "prep_ms": prt, "finalize_ms": fit, "item_splits": tmt.get("item_splits"), "sweep_blocks": tmt.get("sweep_blocks"),
+                "mfma_TFLOPs": tft, "mfma_frac": tft / PEAK_FP32_MFMA_TFLOPS,
+                "mfma_frac_padded_factors": tft / PEAK_FP32_MFMA_TFLOPS * (((kt + 7) // 8 * 8) / kt)}
+            if args.parity_users > 0:
+                line["tutorial"]["parity"] = parity_check(pt, pt.out, min(args.parity_users, 1024), noise=True, seed=1, cpu_seconds=8.0, binding=binding)
+                failed = failed or not line["tutorial"]["parity"]["ok"]
+            del pt
+            binding.load().rm_release_workspace()
+            torch.cuda.empty_cache()
+            if not args.no_e2e:
+                child = run_child(args, mt, ["--e2e-child"], workload="TUT")
+                api = child.get("api_default", {})
+                line["tutorial"]["api_ms"] = api.get("ms")
+                line["tutorial"]["api_users_per_s"] = api.get("users_per_s")
+                line["tutorial"]["host_entry_ms"] = child.get("e2e_host", {}).get("steady_ms")
+        except Exception as e:      # noqa: BLE001
+            line["tutorial"] = {"error": repr(e)}
 
     if rank == 0 and world == 1 and not args.no_extra and not args.no_other:
         # every other BASELINE config in the same driver-run line, as compact legs: 3 timed steps after 1 warm-up, the sweep's

@@ -404,6 +404,40 @@ inline void set_spec(Sweep64Args &sa) { sa.spec = (sa.check_nan || sa.noise_E ||
 inline void set_ext_bits(SweepArgs &sa, const unsigned *bits, int words) { sa.train_bits = bits; sa.train_words = words; }
 inline void set_ext_bits(Sweep64Args &, const unsigned *, int) {}
 
+// what the plan's validation kernels found wrong with the caller's CSR arrays -> the error the entry points see
+template <class T>
+void throw_csr_defects(const Plan &hp, const Call<T> &c, Ctx &cx)
+{
+    if (!hp.csr_bad) return;
+    cx.bits_tag = 0; cx.bits_ptr = nullptr;                        // (dense train rows launched beside the plan were not built)
+    if (hp.csr_bad & CSR_BAD_INDPTR)
+        throw RmError{RM_ERR_INVALID, "CSR index pointers of row " + std::to_string((long long)c.user0 + hp.csr_where) + " are negative, decreasing or beyond the index array"};
+    if (hp.csr_bad & CSR_BAD_INDEX)
+        throw RmError{RM_ERR_INVALID, "CSR column index out of range [0, " + std::to_string(c.n) + ") in row " + std::to_string((long long)c.user0 + hp.csr_where)};
+    throw RmError{RM_INTERNAL_UNSORTED, "CSR rows are not sorted"};
+}
+inline void launch_csr_checks(int m, int n, const int *train_p, const int *train_i, long long nnz_train, const int *test_p, const int *test_i, long long nnz_test,
+                              Plan *plan, const unsigned char *only, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_check_csr_ptr, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, train_p, nnz_train, test_p, nnz_test, plan);
+    hipLaunchKernelGGL(k_check_csr_rows, dim3((unsigned)std::min<long long>(((long long)m * CHECK_ROW_LANES + 255) / 256, 256 * 16)), dim3(256), 0, stream,
+                       m, n, train_p, train_i, test_p, test_i, plan, only);
+}
+// the validation alone, with its own wait: for the callers that index by the CSR arrays BEFORE the pipeline runs (the fp64 tie noise
+// builds its noise rows -- candidate index = item - train items below it -- in front of run())
+template <class T>
+void check_csr_now(const Call<T> &c, hipStream_t stream, Ctx &cx)
+{
+    Plan *plan = (Plan *)cx.ws.get("plan", sizeof(Plan));
+    if (cx.ev_valid) HIP_CHECK(hipStreamWaitEvent(stream, cx.done, 0));
+    HIP_CHECK(hipMemsetAsync(plan, 0, sizeof(Plan), stream));
+    launch_csr_checks(c.m, c.n, c.train_p, c.train_i, c.nnz_train, c.test_p, c.test_i, c.nnz_test, plan, c.only_users, stream);
+    Plan hp;
+    HIP_CHECK(hipMemcpyAsync(&hp, plan, sizeof(Plan), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    throw_csr_defects(hp, c, cx);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // device pipeline (T = float: v_mfma_f32_32x32x2_f32 sweep; T = double: v_mfma_f64_16x16x4_f64 sweep)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -465,11 +499,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     ca.only = c.only_users;
     // the caller's CSR arrays are validated here, in front of everything that indexes by them (an out-of-range column index in
     // k_train_bits would be a memory fault; on the CPU reference it is a segfault): 80 MB of indices at BASELINE C2, ~40 us
-    if (!c.csr_checked) {
-        hipLaunchKernelGGL(k_check_csr_ptr, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, c.train_p, c.nnz_train, c.test_p, c.nnz_test, plan);
-        hipLaunchKernelGGL(k_check_csr_rows, dim3((unsigned)std::min<long long>(((long long)m * CHECK_ROW_LANES + 255) / 256, 256 * 16)), dim3(256), 0, stream,
-                           m, n, c.train_p, c.train_i, c.test_p, c.test_i, plan, c.only_users);
-    }
+    if (!c.csr_checked) launch_csr_checks(m, n, c.train_p, c.train_i, c.nnz_train, c.test_p, c.test_i, c.nnz_test, plan, c.only_users, stream);
     // Users with more than POS_CHUNK test items are "streamed" (rm_device.hpp STREAM_CLASS) when a score row for each of
     // them fits the HBM budget: a third of the free memory unless RM_STREAM_BUDGET_MB says otherwise (0 = never; such
     // users then take one sweep slot per chunk of their test row -- same results, the contraction repeated per chunk).
@@ -558,13 +588,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     Plan hp;
     HIP_CHECK(hipMemcpyAsync(&hp, plan, sizeof(Plan), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-    if (hp.csr_bad) { cx.bits_tag = 0; cx.bits_ptr = nullptr; }          // (dense train rows launched beside the plan were not built)
-    if (hp.csr_bad & CSR_BAD_INDPTR)
-        throw RmError{RM_ERR_INVALID, "CSR index pointers of row " + std::to_string((long long)c.user0 + hp.csr_where) + " are negative, decreasing or beyond the index array"};
-    if (hp.csr_bad & CSR_BAD_INDEX)
-        throw RmError{RM_ERR_INVALID, "CSR column index out of range [0, " + std::to_string(n) + ") in row " + std::to_string((long long)c.user0 + hp.csr_where)};
-    if (hp.csr_bad & (CSR_UNSORTED_TRAIN | CSR_UNSORTED_TEST))
-        throw RmError{RM_INTERNAL_UNSORTED, "CSR rows are not sorted"};
+    throw_csr_defects(hp, c, cx);
 
     const int n_slots = hp.n_slots, n_groups = hp.n_groups;
     const int jmax = want_auc ? hp.jmax : 0;
@@ -1062,6 +1086,7 @@ void run_call(const Call<T> &c_in, hipStream_t stream, Ctx &cx, std::function<bo
         make_rows_into(row_user, rows, train_p, user0, D, E, stream);
     };
     if (sizeof(T) == 8) {
+        if (!c0.csr_checked) { check_csr_now<T>(c0, stream, cx); c0.csr_checked = true; }     // (the noise rows below index by the CSR arrays)
         const long long width = c0.cumulative ? c0.K : 1;
         for (long long b0 = 0; b0 < m; b0 += cap) {
             const int mb = (int)std::min<long long>(cap, m - b0);
@@ -1494,21 +1519,26 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
                 std::memcpy(h.outs[i] + ((size_t)u0 + hu[f]) * w, hx + x_off[i] + (size_t)hu[f] * w, sizeof(T) * w);
         }
     };
-    struct Beside { bool ran = false; int count = 0; T *hx = nullptr; int *hu = nullptr; Ctx *pc = nullptr; std::unique_lock<std::mutex> lock; } bes;
+    struct Beside { bool ran = false; int count = 0; T *hx = nullptr; int *hu = nullptr; Ctx *pc = nullptr; hipStream_t stream = nullptr; std::unique_lock<std::mutex> lock; } bes;
     // the exact pass beside the last batch's sweep, on the NOISE_SLOT context and its stream: flags as they stand once the last batch
     // has scored its positives, noise rows for those users (from dense train rows built for them alone), the pipeline for them,
     // and the copy of their metric block to page-locked memory -- all of it enqueued behind `flags_ev`, none of it waited for here
     // except the count of the flagged users
-    auto beside_start = [&](long long b0_last, hipEvent_t other) {
+    auto beside_start = [&](long long b0_last, hipStream_t other_stream) {
         if (!out_w) return;
         Ctx &pc = peer_context(cx, NOISE_SLOT);
         bes.lock = std::unique_lock<std::mutex>(pc.mu);
         bes.pc = &pc;
         if (!pc.own_stream) HIP_CHECK(hipStreamCreateWithFlags(&pc.own_stream, hipStreamNonBlocking));
-        hipStream_t ps = pc.own_stream;
+        // The pass goes onto the stream of the batch BEFORE the last one (the other batch context's), behind that batch: the two batch
+        // streams are known to run side by side -- the pipeline lives on it -- whereas one more stream may share a hardware queue
+        // with the last batch's (the runtime multiplexes streams onto four queues) and then waits for its whole sweep: measured,
+        // the pass started when the last batch ended.  One batch context only: the NOISE_SLOT context's own stream.
+        hipStream_t ps = other_stream ? other_stream : pc.own_stream;
+        bes.stream = ps;
         Workspace &pw = pc.ws;
+        if (pc.ev_valid) HIP_CHECK(hipStreamWaitEvent(ps, pc.done, 0));    // (an earlier call's pass on this context, on another stream)
         HIP_CHECK(hipStreamWaitEvent(ps, cx.flags_ev, 0));
-        if (other) HIP_CHECK(hipStreamWaitEvent(ps, other, 0));
         // (the earlier batches' flags as they stand: a flag their k_finalize sets later is the sequential pass's, below)
         if (b0_last > 0) HIP_CHECK(hipMemcpyAsync(range_snap, range_flag, sizeof(int) * (size_t)b0_last, hipMemcpyDeviceToDevice, ps));
         int *noise_row = (int *)pw.get("noise_row", sizeof(int) * (size_t)m);
@@ -1620,10 +1650,8 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
         if (bi + 1 < n_batches && !g_interrupt) upload_users(bi + 1);
         stamp("next rows enqueued");
         if (snap_here && !g_interrupt) {
-            // (the batch before this one runs on the other context's stream: its positives -- the early flags -- are in place once
-            // its own sweep has been launched, the event run() records as ev[1])
-            hipEvent_t other = (two_ctx && bi > 0) ? ctxs[(bi - 1) & 1]->ev[1] : nullptr;
-            beside_start(b0, other);
+            // (behind the batch before this one, on that batch's stream: its flags are final there)
+            beside_start(b0, (two_ctx && bi > 0) ? streams[(bi - 1) & 1] : (hipStream_t)nullptr);
             stamp("exact pass beside the last batch enqueued");
         }
         if (!two_ctx) finish(which);
@@ -1632,7 +1660,7 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     g_last_ctx = &cx;
     if (range_noise && !g_interrupt && out_w) {
         if (bes.ran) {                                                // (its results left the device while the last batch was sweeping)
-            HIP_CHECK(hipStreamSynchronize(bes.pc->own_stream));
+            HIP_CHECK(hipStreamSynchronize(bes.stream));
             scatter_exact(bes.hx, bes.hu, bes.count);
             stamp("exact pass (beside) scattered");
         }
@@ -1653,12 +1681,12 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
             scatter_exact(hx, hu, n_flagged);
             stamp("exact pass scattered");
         }
-    } else if (bes.pc) (void)hipStreamSynchronize(bes.pc->own_stream);
+    } else if (bes.pc) (void)hipStreamSynchronize(bes.stream);
     if (g_interrupt) nan_flagged();
     } catch (...) {
         for (int i = 0; i < 2; i++) (void)hipStreamSynchronize(streams[i]);      // nothing may still write into staging that goes away
         (void)hipStreamSynchronize(up);
-        if (bes.pc && bes.pc->own_stream) (void)hipStreamSynchronize(bes.pc->own_stream);
+        if (bes.pc) (void)hipStreamSynchronize(bes.stream);
         nan_flagged();
         throw;
     }

@@ -41,4 +41,5 @@ for _ in range(5):
 pr.disable()
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(18); print(s.getvalue()[:3500])
 os.environ["RM_HOST_TRACE"] = "1"
+binding.reload_switches()
 host_call(False); host_call(True)

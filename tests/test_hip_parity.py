@@ -803,3 +803,105 @@ def test_repeated_test_columns_fill_the_top_k(hip, oracle, dtype):
         assert (got["topk_idx"][got["status"] == 0] >= 0).all(), "incomplete top-K list"
         assert (got["topk_idx"] == want["topk_idx"]).all()
         assert_same_bits(got["topk_score"], want["topk_score"], "top-K scores")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE C3 and C5 at their full USER counts, one device call each (the m-driven machinery -- grids of thousands of sweep blocks
+# in many rounds, the two-level tail, plan scans over a million users, metric blocks of hundreds of MB -- at the size the configs
+# are quoted on; the item-count side is covered above).  Inputs live in torch tensors: a process of its own.
+_FULL_M_SCRIPT = r"""
+import json, os, sys, time, numpy as np
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import torch
+import bench
+from recometrics_amd import _binding as hip
+from recometrics_amd.synth import CONFIGS, make_interactions_fast
+from _util import same_bits
+torch.cuda.set_device(0); hip.load(); hip.set_device(0)
+dev = torch.device("cuda", 0)
+name, cumulative = %(name)r, %(cumulative)r
+m, n, k, dtype, K, mean_c, seed = CONFIGS[name]
+t0 = time.time()
+rng = np.random.default_rng(seed)
+sc = np.float32(1.0 / np.sqrt(k))
+def factors(rows):
+    X = np.empty((rows, k), dtype=dtype)
+    for r0 in range(0, rows, 1 << 18):
+        r1 = min(rows, r0 + (1 << 18))
+        X[r0:r1] = rng.standard_normal((r1 - r0, k), dtype=np.float32) * sc
+    return X
+A, B = factors(m), factors(n)
+trp, tri, tep, tei, tev = make_interactions_fast(m, n, mean_c, dtype, seed)
+host = dict(A=A, B=B, train=(trp, tri), test=(tep, tei, tev))
+t_gen = time.time() - t0
+prob = bench.DeviceProblem(torch, dev, m, n, k, mean_c, seed, K, dtype, cumulative=cumulative, host=host)
+stream = torch.cuda.current_stream().cuda_stream
+prob.step(hip, stream); torch.cuda.synchronize()
+t1 = time.time(); prob.step(hip, stream); torch.cuda.synchronize(); t_call = time.time() - t1
+tm = hip.timings()
+res = {"users": m, "gen_s": t_gen, "call_ms": t_call * 1e3, "sweep_ms": tm["sweep_ms"], "sweep_blocks": tm["sweep_blocks"], "item_splits": tm["item_splits"],
+       "mfma_frac": 2.0 * n * k * m / (tm["sweep_ms"] * 1e-3) / 1e12 / (157.3 if dtype == np.float32 else 78.6)}
+# properties that do not depend on the size
+ntest = np.diff(tep)
+roc = prob.metric(prob.out, 8).cpu().numpy()
+res["roc_mean"] = float(np.nanmean(roc)); res["roc_nan"] = int(np.isnan(roc).sum()); res["users_without_test"] = int((ntest == 0).sum())
+res["roc_in_range"] = bool(np.nanmin(roc) >= 0 and np.nanmax(roc) <= 1)
+p_at = prob.metric(prob.out, 0).cpu().numpy(); r_at = prob.metric(prob.out, 2).cpu().numpy(); hit = prob.metric(prob.out, 6).cpu().numpy()
+if cumulative:
+    res["recall_monotone"] = bool((np.diff(r_at, axis=1) >= 0).all()); res["hit_monotone"] = bool((np.diff(hit, axis=1) >= 0).all())
+    pk, hk = p_at[:, -1], hit[:, -1]
+else:
+    res["recall_monotone"] = res["hit_monotone"] = True
+    pk, hk = p_at, hit
+res["hit_is_p_positive"] = bool(((pk > 0) == (hk > 0)).all())
+pkk = np.nan_to_num(pk.astype(np.float64) * K)
+res["p_grid"] = bool(np.allclose(pkk, np.rint(pkk), atol=1e-4))                  # P@K = hits / K
+# users are independent: the first 512 users of the big call == a call over those 512 users alone, bit for bit
+sub = 512
+hs = dict(A=A[:sub], B=B, train=(trp[:sub + 1], tri[:max(int(trp[sub]), 1)]), test=(tep[:sub + 1], tei[:int(tep[sub])], tev[:int(tep[sub])]))
+small = bench.DeviceProblem(torch, dev, sub, n, k, mean_c, seed, K, dtype, cumulative=cumulative, host=hs)
+small.step(hip, stream); torch.cuda.synchronize()
+ok = True
+for i in range(10):
+    ok &= bool(same_bits(prob.metric(prob.out, i)[:sub].cpu().numpy(), small.metric(small.out, i).cpu().numpy()).all())
+res["first_users_equal_their_own_call"] = ok
+# a stratified sample (heaviest rows, streamed users, cold users, first and last block) against the compiled reference
+res["parity"] = bench.parity_check(prob, prob.out, %(sample)d, cpu_seconds=%(cpu_s)f, binding=hip)
+print(json.dumps(res))
+"""
+
+
+def _full_m_run(name, cumulative, sample, cpu_s):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", _FULL_M_SCRIPT % {"root": root, "name": name, "cumulative": cumulative, "sample": sample, "cpu_s": cpu_s}],
+                         capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    got = json.loads(res.stdout.strip().splitlines()[-1])
+    print(name, "at its full user count:", {k: v for k, v in got.items() if k != "parity"}, got["parity"])
+    return got
+
+
+def _full_m_asserts(got, m):
+    from oracle.oracle import reference_available
+    assert got["users"] == m
+    assert got["roc_in_range"] and abs(got["roc_mean"] - 0.5) < 0.005 and got["roc_nan"] == got["users_without_test"], got
+    assert got["recall_monotone"] and got["hit_monotone"] and got["hit_is_p_positive"] and got["p_grid"], got
+    assert got["first_users_equal_their_own_call"], "the first users of the big call differ from a call over them alone"
+    assert got["parity"]["ok"] and (got["parity"]["checker"] == "reference") == reference_available(), got["parity"]
+
+
+def test_baseline_c3_at_its_full_user_count(hip):
+    """C3 as BASELINE quotes it before sharding: 1,000,000 users x 380,000 items x 128 factors fp32, cumulative K = 1..20, all ten
+    metrics, ONE device call (7,813 user blocks; 162 values per user = 648 MB of outputs)"""
+    got = _full_m_run("C3", True, 600, 8.0)
+    _full_m_asserts(got, 1_000_000)
+
+
+def test_baseline_c5_at_its_full_user_count(hip):
+    """C5: 200,000 users x 500,000 items x 256 factors fp64, K = 50, all ten metrics, ONE device call"""
+    got = _full_m_run("C5", False, 160, 8.0)
+    _full_m_asserts(got, 200_000)
