@@ -75,6 +75,13 @@ struct Plan {                                     // produced on device, read ba
     unsigned long long amax_a, amax_b;  // bit patterns of max|A|, max|B| as doubles (non-negative doubles order like u64)
     int csr_bad;                        // CSR_* bits: what k_check_csr_ptr / k_check_csr_rows found wrong with the caller's CSR arrays
     int csr_where;                      // a user (row) that shows the defect, for the message
+    // sortedness, counted: descents (idx[e] > idx[e + 1]) over the whole index array, and those that sit on a row boundary --
+    // the rows are sorted exactly when the two agree ([0] train, [1] test; k_check_csr_flat / k_check_csr_starts)
+    // (a cache line of their own: atomics on one line serialise in L2, and the validation kernels run BESIDE the plan chain, whose
+    // kernels bump the counters above)
+    alignas(128) unsigned long long csr_desc_all[2];
+    unsigned long long csr_desc_legit[2];
+    unsigned long long csr_pad[12];
 };
 // Validation of the caller's CSR arrays on the device (the reference's callers guarantee sorted rows, recometrics/__init__.py:35-41,
 // :553-558, and nobody range-checks: on the CPU a bad index is a segfault).  INDPTR / INDEX defects end the call with RM_ERR_INVALID;

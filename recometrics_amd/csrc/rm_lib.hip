@@ -131,7 +131,7 @@ struct Ctx {
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false, ev_recorded = false;
     hipStream_t side_stream = nullptr;      // second sweep launch of a depth-split call runs beside the first
-    hipEvent_t side_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t side_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t done = nullptr;               // end of the device work of the most recent call on this context
     hipStream_t own_stream = nullptr;        // stream of a shard worker (multi-device calls)
     hipStream_t up_stream = nullptr;         // host-pointer calls: uploads of the NEXT user batch run beside the current batch's kernels
@@ -156,8 +156,25 @@ struct Ctx {
     unsigned long long bits_tag = 0; const int *bits_train_p = nullptr;             // ... by which call (Call::items_tag) and for which rows
     bool bits_masked = false;                                                       // ... with the test items marked too
     bool bits_partial = false;                                                      // ... for a subset of the users only (Call::only_users)
+    bool high_priority = false;          // streams of this context are created with the highest priority (the exact passes of the tie noise)
+    Plan *pinned_plan = nullptr;                                                    // page-locked landing place of the plan read-back
+    const void *log2_ptr = nullptr; int log2_K = 0;                                 // the DCG discount table the workspace holds (run())
     unsigned long long packed_amax_b = 0; int packed_nonfinite_b = 0;
 };
+// A stream of a context.  The NOISE_SLOT contexts ask for the highest priority the device offers: their work -- the exact pass of the
+// tie noise over a few thousand users -- is enqueued BESIDE a sweep that fills every compute unit, and at normal priority its kernels
+// are only served when that sweep has no more blocks to place (measured: the pass started when the sweep ended); at high priority its
+// workgroups go first whenever a compute unit frees up.
+inline hipError_t create_stream(hipStream_t *st, bool high_priority)
+{
+    if (high_priority) {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+            return hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest);
+        (void)hipGetLastError();
+    }
+    return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
 std::mutex g_ctx_mu;
 std::map<std::pair<int, int>, std::unique_ptr<Ctx>> g_ctx;
 thread_local Ctx *g_last_ctx = nullptr;      // context of the most recent call on this thread (rm_get_timings)
@@ -180,7 +197,7 @@ Ctx &peer_context(const Ctx &cx, int offset = PEER_SLOT)
 {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     auto &p = g_ctx[std::make_pair(cx.device, cx.slot + offset)];
-    if (!p) { p.reset(new Ctx()); p->device = cx.device; p->slot = cx.slot + offset; }
+    if (!p) { p.reset(new Ctx()); p->device = cx.device; p->slot = cx.slot + offset; p->high_priority = offset == NOISE_SLOT; }
     return *p;
 }
 
@@ -408,7 +425,8 @@ inline void set_ext_bits(Sweep64Args &, const unsigned *, int) {}
 template <class T>
 void throw_csr_defects(const Plan &hp, const Call<T> &c, Ctx &cx)
 {
-    if (!hp.csr_bad) return;
+    const bool unsorted = hp.csr_desc_all[0] != hp.csr_desc_legit[0] || hp.csr_desc_all[1] != hp.csr_desc_legit[1];
+    if (!hp.csr_bad && !unsorted) return;
     cx.bits_tag = 0; cx.bits_ptr = nullptr;                        // (dense train rows launched beside the plan were not built)
     if (hp.csr_bad & CSR_BAD_INDPTR)
         throw RmError{RM_ERR_INVALID, "CSR index pointers of row " + std::to_string((long long)c.user0 + hp.csr_where) + " are negative, decreasing or beyond the index array"};
@@ -416,12 +434,21 @@ void throw_csr_defects(const Plan &hp, const Call<T> &c, Ctx &cx)
         throw RmError{RM_ERR_INVALID, "CSR column index out of range [0, " + std::to_string(c.n) + ") in row " + std::to_string((long long)c.user0 + hp.csr_where)};
     throw RmError{RM_INTERNAL_UNSORTED, "CSR rows are not sorted"};
 }
+// the validation of the index ARRAYS (the index pointers are k_classify's / k_check_csr_ptr's): `nnz_*` bound the grids -- the
+// kernels look up the entry range of this call's rows themselves
+inline void launch_csr_index_checks(int m, int n, const int *train_p, const int *train_i, long long nnz_train, const int *test_p, const int *test_i, long long nnz_test,
+                                    Plan *plan, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_check_csr_starts, dim3(cdiv(m, 1024)), dim3(1024), 0, stream, m, train_p, train_i, test_p, test_i, plan);
+    auto blocks = [](long long nnz) { return dim3((unsigned)std::min<long long>((nnz / 4 + 2 + CHECK_FLAT_THREADS - 1) / CHECK_FLAT_THREADS, CHECK_FLAT_BLOCKS)); };
+    if (nnz_train > 0) hipLaunchKernelGGL(k_check_csr_flat, blocks(nnz_train), dim3(CHECK_FLAT_THREADS), 0, stream, m, n, train_p, train_i, plan, 0);
+    if (nnz_test > 0) hipLaunchKernelGGL(k_check_csr_flat, blocks(nnz_test), dim3(CHECK_FLAT_THREADS), 0, stream, m, n, test_p, test_i, plan, 1);
+}
 inline void launch_csr_checks(int m, int n, const int *train_p, const int *train_i, long long nnz_train, const int *test_p, const int *test_i, long long nnz_test,
-                              Plan *plan, const unsigned char *only, hipStream_t stream)
+                              Plan *plan, const unsigned char *, hipStream_t stream)
 {
     hipLaunchKernelGGL(k_check_csr_ptr, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, train_p, nnz_train, test_p, nnz_test, plan);
-    hipLaunchKernelGGL(k_check_csr_rows, dim3((unsigned)std::min<long long>(((long long)m * CHECK_ROW_LANES + 255) / 256, 256 * 16)), dim3(256), 0, stream,
-                       m, n, train_p, train_i, test_p, test_i, plan, only);
+    launch_csr_index_checks(m, n, train_p, train_i, nnz_train, test_p, test_i, nnz_test, plan, stream);
 }
 // the validation alone, with its own wait: for the callers that index by the CSR arrays BEFORE the pipeline runs (the fp64 tie noise
 // builds its noise rows -- candidate index = item - train items below it -- in front of run())
@@ -473,8 +500,8 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     // the positives, the streamed users' ranks beside the rest of the finalisation; a depth-split call's second sweep launch)
     auto side_stream = [&]() -> hipStream_t {
         if (!cx.side_stream) {
-            HIP_CHECK(hipStreamCreateWithFlags(&cx.side_stream, hipStreamNonBlocking));
-            for (int i = 0; i < 5; i++) HIP_CHECK(hipEventCreateWithFlags(&cx.side_ev[i], hipEventDisableTiming));
+            HIP_CHECK(create_stream(&cx.side_stream, cx.high_priority));
+            for (int i = 0; i < 6; i++) HIP_CHECK(hipEventCreateWithFlags(&cx.side_ev[i], hipEventDisableTiming));
         }
         return cx.side_stream;
     };
@@ -492,46 +519,34 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     int *user_nslots = (int *)ws.get("user_nslots", sizeof(int) * (size_t)m);
     int *uslot_base = (int *)ws.get("uslot_base", sizeof(int) * (size_t)m);
     Plan *plan = (Plan *)ws.get("plan", sizeof(Plan));
-    HIP_CHECK(hipMemsetAsync(plan, 0, sizeof(Plan), stream));
     int *heavy_users = (int *)ws.get("heavy_users", sizeof(int) * (size_t)m);
     ClassifyArgs ca{m, n, K, c.train_p, c.test_p, req, c.cold ? 1 : 0, min_items_pool, min_pos_test, want_auc ? 1 : 0,
                     flags, user_nslots, heavy_users, plan};
     ca.only = c.only_users;
-    // the caller's CSR arrays are validated here, in front of everything that indexes by them (an out-of-range column index in
-    // k_train_bits would be a memory fault; on the CPU reference it is a segfault): 80 MB of indices at BASELINE C2, ~40 us
-    if (!c.csr_checked) launch_csr_checks(m, n, c.train_p, c.train_i, c.nnz_train, c.test_p, c.test_i, c.nnz_test, plan, c.only_users, stream);
+    // the caller's CSR arrays are validated in front of everything that indexes by them (an out-of-range column index in
+    // k_train_bits would be a memory fault; on the CPU reference it is a segfault): the index pointers by k_classify itself, the
+    // 80 MB of indices of BASELINE C2 by k_check_csr_rows beside the plan chain (~40 us)
+    ca.check_ptr = c.csr_checked ? 0 : 1; ca.nnz_train = c.nnz_train; ca.nnz_test = c.nnz_test;
     // Users with more than POS_CHUNK test items are "streamed" (rm_device.hpp STREAM_CLASS) when a score row for each of
     // them fits the HBM budget: a third of the free memory unless RM_STREAM_BUDGET_MB says otherwise (0 = never; such
     // users then take one sweep slot per chunk of their test row -- same results, the contraction repeated per chunk).
+    // The plan assumes they fit; the host looks at their number in the read-back and, should the rows not fit, plans once more
+    // without streaming (what used to be two launches in front of k_classify -- count, decide -- on every call).
     const long long stream_ld_max = ((long long)n + 191) / 192 * 192;             // row stride for either tile size (64 / 96 items)
     // k_metrics beyond the sweep's lists (append buffers + wave compaction reach 256): every user is streamed and
     // k_select_topk picks its top-K from the stored row -- any k_metrics <= n, at one score row of HBM per user
     const bool ext_topk = K > 256 || g_sw.ext_topk;
+    long long stream_cap = 0;
     if (want_auc || ext_topk) {
-        const long long cap = stream_budget_bytes(ws) / (stream_ld_max * (long long)sizeof(T));
+        stream_cap = stream_budget_bytes(ws) / (stream_ld_max * (long long)sizeof(T));
         // (a pass over a subset of the users -- the exact second pass of the fp32 tie noise -- stores rows for that subset only)
         const long long m_rows = c.eval_users >= 0 ? std::min<long long>(c.eval_users, m) : m;
         if (ext_topk) {
-            if (m_rows > cap) throw RmError{RM_ERR_NOMEM, "k_metrics > 256 keeps one score row (" + std::to_string(stream_ld_max * (long long)sizeof(T)) +
-                                       " B) per user in device memory: " + std::to_string(m_rows) + " users do not fit, at most " + std::to_string(cap) + " per call"};
+            if (m_rows > stream_cap) throw RmError{RM_ERR_NOMEM, "k_metrics > 256 keeps one score row (" + std::to_string(stream_ld_max * (long long)sizeof(T)) +
+                                       " B) per user in device memory: " + std::to_string(m_rows) + " users do not fit, at most " + std::to_string(stream_cap) + " per call"};
             ca.force_stream = 1;
-        } else if (cap > 0) {
-            hipLaunchKernelGGL(k_count_long, dim3(cdiv(m, 1024)), dim3(1024), 0, stream, m, c.test_p, plan, c.only_users);
-            hipLaunchKernelGGL(k_decide_stream, dim3(1), dim3(1), 0, stream, plan, cap);
-        }
+        } else if (stream_cap > 0) ca.allow_stream = 1;
     }
-    hipLaunchKernelGGL(k_classify, dim3(cdiv(m, 1024)), dim3(1024), 0, stream, ca);
-    if (m > 8192) {                                          // one block walking the whole array costs ~0.5 us per 1024 entries
-        const int n_tiles = (int)cdiv(m, 1024);
-        int *tile_total = (int *)ws.get("scan_tile_total", sizeof(int) * (size_t)n_tiles);
-        int *tile_offset = (int *)ws.get("scan_tile_offset", sizeof(int) * (size_t)n_tiles);
-        hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(1024), 0, stream, user_nslots, uslot_base, m, tile_total);
-        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, tile_total, tile_offset, n_tiles, &plan->n_slots);
-        hipLaunchKernelGGL(k_scan_add_offsets, dim3(cdiv(m, 256)), dim3(256), 0, stream, uslot_base, m, tile_offset);
-    } else {
-        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, user_nslots, uslot_base, m, &plan->n_slots);
-    }
-    hipLaunchKernelGGL(k_plan_classes, dim3(1), dim3(1), 0, stream, plan, GU);
     const long long slot_bound = (long long)m + c.nnz_test / POS_CHUNK + 1;
     const long long group_bound = slot_bound / GU + 2;
     int *slot_user = (int *)ws.get("slot_user", sizeof(int) * (size_t)slot_bound);
@@ -542,52 +557,84 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     long long *grow = (long long *)ws.get("grow", sizeof(long long) * (size_t)group_bound);
     int *sc_user = (int *)ws.get("sc_user", sizeof(int) * (size_t)slot_bound);
     int *sc_chunk = (int *)ws.get("sc_chunk", sizeof(int) * (size_t)slot_bound);
-    AssignArgs aa{m, c.test_p, flags, user_nslots, uslot_base, want_auc ? 1 : 0, plan, slot_user, slot_chunk, slot_index, slot_j, sc_user, sc_chunk,
-                  ext_topk ? 1 : 0};
-    hipLaunchKernelGGL(k_assign_slots, dim3(cdiv(m, ASSIGN_THREADS)), dim3(ASSIGN_THREADS), 0, stream, aa);
-    const long long block_bound = group_bound / GROUPS_PER_BLOCK + 2;
-    int *blk_j = (int *)ws.get("blk_j", sizeof(int) * (size_t)block_bound);
-    int *blk_rows = (int *)ws.get("blk_rows", sizeof(int) * (size_t)block_bound);
-    int *blk_base = (int *)ws.get("blk_base", sizeof(int) * (size_t)(block_bound + 1));
-    HIP_CHECK(hipMemsetAsync(blk_rows, 0, sizeof(int) * (size_t)block_bound, stream));
-    hipLaunchKernelGGL(k_block_rows, dim3(cdiv(block_bound, 256)), dim3(256), 0, stream, plan, slot_j, blk_j, blk_rows, GU);
-    hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, blk_rows, blk_base, (int)block_bound, blk_base + block_bound);
-    hipLaunchKernelGGL(k_group_rows, dim3(cdiv(group_bound, 256)), dim3(256), 0, stream, plan, blk_j, blk_base, blk_base + block_bound, gj, grow);
-    hipLaunchKernelGGL(k_absmax<T>, dim3(512), dim3(256), 0, stream, c.A, c.lda, (long long)m, k, &plan->amax_a, &plan->nonfinite);
+    int *tile_total = nullptr, *tile_offset = nullptr;
+    const int n_tiles = (int)cdiv(m, 1024);
+    if (m > 8192) {                                          // one block walking the whole array costs ~0.5 us per 1024 entries
+        tile_total = (int *)ws.get("scan_tile_total", sizeof(int) * (size_t)n_tiles);
+        tile_offset = (int *)ws.get("scan_tile_offset", sizeof(int) * (size_t)n_tiles);
+    }
     const bool items_known = c.items_tag != 0 && c.items_tag == cx.packed_tag;       // a later batch of the same host call
-    if (!items_known) hipLaunchKernelGGL(k_absmax<T>, dim3(1024), dim3(256), 0, stream, c.B, c.ldb, (long long)n, k, &plan->amax_b, &plan->nonfinite_b);
-    // log2(i + 2) for the DCG discounts, from the host's libm like the reference's (:620,:902, int -> double log2); staged
-    // here so that the one synchronisation of the call (the plan read-back below) also covers this stack-owned buffer
-    std::vector<double> lt((size_t)K);
-    for (int i = 0; i < K; i++) lt[i] = std::log2(i + 2);
+    // log2(i + 2) for the DCG discounts, from the host's libm like the reference's (:620,:902, int -> double log2).  The table
+    // depends on K alone: it stays in the workspace, and only a longer one (or a moved buffer) is uploaded again -- the copy
+    // comes from pageable memory, which blocks the host and waits for the stream
     double *log2tab = (double *)ws.get("log2tab", sizeof(double) * (size_t)K);
-    HIP_CHECK(hipMemcpyAsync(log2tab, lt.data(), sizeof(double) * (size_t)K, hipMemcpyHostToDevice, stream));
-    // Dense train rows (fp32, small item counts; set_train_bits) depend on the CSR inputs alone: they are launched on the side stream
-    // behind the plan kernels, so that they run during the plan read-back -- the host's one wait of the call, otherwise an idle
-    // device -- and beside the packing kernels (0.17 ms of preparation at BASELINE C2 that used to sit behind the read-back; in
-    // front of the plan kernels they slowed those down by as much as they saved).  Whether the rows also mark the test items
-    // (`mask_test`) is only decided behind the read-back; the guess here is the usual answer, and a wrong guess costs one more
-    // launch of the kernel behind it.
-    bool bits_early = false, bits_early_masked = false;
+    if (cx.log2_ptr != (const void *)log2tab || cx.log2_K < K) {
+        std::vector<double> lt((size_t)K);
+        for (int i = 0; i < K; i++) lt[i] = std::log2(i + 2);
+        HIP_CHECK(hipMemcpy(log2tab, lt.data(), sizeof(double) * (size_t)K, hipMemcpyHostToDevice));       // (synchronous: `lt` is on the stack)
+        cx.log2_ptr = (const void *)log2tab; cx.log2_K = K;
+    }
+    if (!cx.pinned_plan) HIP_CHECK(hipHostMalloc((void **)&cx.pinned_plan, sizeof(Plan), hipHostMallocDefault));
     // (one answer per call: a later pass -- the exact passes of the tie noise, on this or on a peer context with less free memory --
     // carries the first pass's answer; rows handed over by another pass are proof that they fit)
     const bool dense_ok = std::is_same<T, float>::value && (c.ext_bits ? true : c.dense_fit >= 0 ? c.dense_fit != 0 : dense_rows_fit(ws, m, n));
-    if (std::is_same<T, float>::value && use_side && !c.ext_bits && dense_ok && !g_sw.no_early_bits) {
-        SweepArgs probe{};
-        const bool guess = want_auc && !ext_topk && !g_sw.no_test_mask;
-        const unsigned *had = (const unsigned *)cx.bits_ptr;
-        const bool reuse = c.same_train_rows && had && !cx.bits_partial && cx.bits_words == dense_row_words(n) && cx.bits_m == m && cx.bits_masked == guess &&
-                           had == (const unsigned *)ws.get("train_bits", (size_t)m * (size_t)dense_row_words(n) * 4);
-        if (!reuse) {
-            hipStream_t sd = fork_side();
-            set_train_bits(probe, cx, c, m, n, dense_ok, sd, guess);
-            HIP_CHECK(hipEventRecord(cx.side_ev[4], sd));
-            bits_early = true; bits_early_masked = guess;
-        }
-    }
+    bool bits_early = false, bits_early_masked = false;
     Plan hp;
-    HIP_CHECK(hipMemcpyAsync(&hp, plan, sizeof(Plan), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
+    for (int attempt = 0; ; attempt++) {
+        // ---- the plan chain: five launches that depend on one another, on the call's stream (index pointers only) ----
+        HIP_CHECK(hipMemsetAsync(plan, 0, sizeof(Plan), stream));
+        hipLaunchKernelGGL(k_classify, dim3(cdiv(m, 1024)), dim3(1024), 0, stream, ca);
+        // ---- beside it, on the side stream: everything that reads the index arrays and the factors ----
+        // the CSR rows' validation (gated on the index pointers k_classify has just checked), max |A| and max |B|, and the dense
+        // train rows (fp32, small item counts; set_train_bits), which depend on the CSR inputs alone: they run during the plan chain
+        // and the plan read-back -- the host's one wait of the call, otherwise an idle device -- and beside the packing kernels.
+        // Whether the rows also mark the test items (`mask_test`) is only decided behind the read-back; the guess here is the usual
+        // answer, and a wrong guess costs one more launch of the kernel behind it.
+        hipStream_t aux = use_side ? fork_side() : stream;
+        if (!c.csr_checked) launch_csr_index_checks(m, n, c.train_p, c.train_i, c.nnz_train, c.test_p, c.test_i, c.nnz_test, plan, aux);
+        hipLaunchKernelGGL(k_absmax<T>, dim3(512), dim3(256), 0, aux, c.A, c.lda, (long long)m, k, &plan->amax_a, &plan->nonfinite);
+        if (!items_known) hipLaunchKernelGGL(k_absmax<T>, dim3(1024), dim3(256), 0, aux, c.B, c.ldb, (long long)n, k, &plan->amax_b, &plan->nonfinite_b);
+        if (use_side) HIP_CHECK(hipEventRecord(cx.side_ev[2], aux));                  // the plan read-back waits for this much of the side stream
+        if (tile_total) {
+            hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(1024), 0, stream, user_nslots, uslot_base, m, tile_total);
+            hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, tile_total, tile_offset, n_tiles, &plan->n_slots, plan, GU);
+        } else {
+            hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, user_nslots, uslot_base, m, &plan->n_slots, plan, GU);
+        }
+        AssignArgs aa{m, c.test_p, flags, user_nslots, uslot_base, want_auc ? 1 : 0, plan, slot_user, slot_chunk, slot_index, slot_j, sc_user, sc_chunk,
+                      ext_topk ? 1 : 0, tile_offset};
+        hipLaunchKernelGGL(k_assign_slots, dim3(cdiv(m, ASSIGN_THREADS)), dim3(ASSIGN_THREADS), 0, stream, aa);
+        hipLaunchKernelGGL(k_block_tables, dim3(1), dim3(1024), 0, stream, plan, slot_j, gj, grow, GU);
+        if (use_side) HIP_CHECK(hipStreamWaitEvent(stream, cx.side_ev[2], 0));
+        HIP_CHECK(hipMemcpyAsync(cx.pinned_plan, plan, sizeof(Plan), hipMemcpyDeviceToHost, stream));
+        // (the dense train rows are 463 MB of writes at BASELINE C2: launched BEHIND the read-back's copy -- in front of it they
+        // kept the copy, and with it the host, waiting for 0.1 ms)
+        if (use_side) { HIP_CHECK(hipEventRecord(cx.side_ev[5], stream)); HIP_CHECK(hipStreamWaitEvent(aux, cx.side_ev[5], 0)); }
+        if (attempt == 0 && std::is_same<T, float>::value && use_side && !c.ext_bits && dense_ok && !g_sw.no_early_bits) {
+            SweepArgs probe{};
+            const bool guess = want_auc && !ext_topk && !g_sw.no_test_mask;
+            const unsigned *had = (const unsigned *)cx.bits_ptr;
+            const bool reuse = c.same_train_rows && had && !cx.bits_partial && cx.bits_words == dense_row_words(n) && cx.bits_m == m && cx.bits_masked == guess &&
+                               had == (const unsigned *)ws.get("train_bits", (size_t)m * (size_t)dense_row_words(n) * 4);
+            if (!reuse) {
+                set_train_bits(probe, cx, c, m, n, dense_ok, aux, guess);
+                HIP_CHECK(hipEventRecord(cx.side_ev[4], aux));
+                bits_early = true; bits_early_masked = guess;
+            }
+        }
+        HIP_CHECK(hipStreamSynchronize(stream));
+        // (the stream has waited for side_ev[2]: only the dense train rows of the first attempt may still be running over there)
+        if (use_side && !(attempt == 0 && bits_early)) side_guard.pending--;
+        hp = *cx.pinned_plan;
+        throw_csr_defects(hp, c, cx);
+        // the streamed users' score rows must fit the budget; if not (memory pressure), plan again with those users in chunks
+        if (ca.allow_stream && !ca.force_stream && hp.class_count[STREAM_CLASS] > stream_cap && attempt == 0) {
+            ca.allow_stream = 0; ca.check_ptr = 0;
+            if (use_side) { HIP_CHECK(hipStreamSynchronize(cx.side_stream)); side_guard.pending = bits_early ? 1 : 0; }
+            continue;
+        }
+        break;
+    }
     throw_csr_defects(hp, c, cx);
 
     const int n_slots = hp.n_slots, n_groups = hp.n_groups;
@@ -754,9 +801,12 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         // ---- dense train rows (fp32, small item counts) ----
         // (measured: on the side stream beside the positives' kernels they gain nothing -- both are bound by memory; r3_ab_c2.txt)
         typename P::Args sa{};
-        if (bits_early) {                                             // (launched beside the plan kernels: the sweep is behind them)
+        // (rows launched beside the plan read-back that turn out not to be the ones wanted -- a wrong guess of `mask_test`, rows handed over
+        // by another pass -- are waited for here, before anything is launched over them; the usual case waits in front of the sweep)
+        bool bits_wait = bits_early;
+        if (bits_early && (bits_early_masked != mask_test || (use_ext_bits && dense_ok))) {
             HIP_CHECK(hipStreamWaitEvent(stream, cx.side_ev[4], 0));
-            side_guard.pending--;
+            side_guard.pending--; bits_wait = false;
         }
         if (use_ext_bits && dense_ok) set_ext_bits(sa, c.ext_bits, (int)c.ext_words);
         else set_train_bits(sa, cx, c, m, n, dense_ok, stream, mask_test, bits_early, bits_early_masked);
@@ -769,8 +819,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             hist = (unsigned *)ws.get("hist", sizeof(unsigned) * (size_t)(rows + 1) * GU);
             T *pos_tmp = (T *)ws.get("pos_tmp", sizeof(T) * (size_t)std::max<long long>(c.nnz_test, 1));
             pos_order = (int *)ws.get("pos_order", sizeof(int) * (size_t)std::max<long long>(c.nnz_test, 1));
-            hipLaunchKernelGGL(k_fill<T>, dim3(cdiv(rows * GU, 256)), dim3(256), 0, stream, pos_score, (T)INFINITY, rows * GU);
-            HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(unsigned) * (size_t)rows * GU, stream));
+            hipLaunchKernelGGL(k_init_tables<T>, dim3(cdiv(rows * GU, 256)), dim3(256), 0, stream, pos_score, hist, rows * GU);
             PosArgs<T> pa{m, n, k, c.A, c.lda, c.B, c.ldb, c.train_p, c.train_i, c.test_p, c.test_i,
                           flags, user_nslots, uslot_base, slot_index, grow, pos_tmp, pos_order, pos_score, pos_item, GU};
             pa.noise_row = c.noise_row; pa.noise_row0 = c.noise_row0; pa.noise_E = c.noise_E; pa.noise_ld = c.noise_ld;
@@ -787,9 +836,8 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
                 spos_item = (int *)ws.get("spos_item", sizeof(int) * nz);
                 shist = (unsigned *)ws.get("shist", sizeof(unsigned) * nz);
                 if (pos_beside) ps = fork_side();
-                HIP_CHECK(hipMemsetAsync(shist, 0, sizeof(unsigned) * nz, ps));
                 // (+inf in every rank: entries that repeat an item -- a non-canonical CSR row -- share a rank and leave one unused)
-                hipLaunchKernelGGL(k_fill<T>, dim3(cdiv((long long)nz, 256)), dim3(256), 0, ps, spos_score, (T)INFINITY, (long long)nz);
+                hipLaunchKernelGGL(k_init_tables<T>, dim3(cdiv((long long)nz, 256)), dim3(256), 0, ps, spos_score, shist, (long long)nz);
                 PosArgs<T> pb = pa;
                 pb.stream = 1; pb.spos_score = spos_score; pb.spos_item = spos_item;
                 const int nsc = hp.n_stream_chunks;
@@ -814,10 +862,10 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
 
         typedef typename std::remove_pointer<decltype(typename P::Args{}.thr_shared)>::type ThrT;
         ThrT *thr_shared = (ThrT *)ws.get("thr_shared", sizeof(ThrT) * (size_t)n_slots);
-        HIP_CHECK(hipMemsetAsync(thr_shared, 0, sizeof(ThrT) * (size_t)n_slots, stream));
         if (want_auc && !ext_topk && !g_sw.no_seed)
             hipLaunchKernelGGL((k_seed_thresholds<T, ThrT>), dim3(cdiv(n_slots, 256)), dim3(256), 0, stream, n_slots, stream_slot0, K, GU, slot_user, slot_chunk,
                                user_nslots, flags, c.test_p, grow, pos_score, spos_score, thr_shared);
+        else HIP_CHECK(hipMemsetAsync(thr_shared, 0, sizeof(ThrT) * (size_t)n_slots, stream));
         sa.thr_shared = thr_shared;
         sa.n = n; sa.K = K; sa.ngt = NG; sa.n_slots = n_slots; sa.n_groups = n_groups; sa.n_ublocks = n_ublocks;
         sa.n_splits = n_splits; sa.tail_ublocks = tail_ublocks; sa.tail_splits = tail_splits; sa.part_splits = part_splits; sa.tiles_total = tiles_total; sa.jmax = jmax; sa.check_nan = check_nan ? 1 : 0; sa.buffered_lists = (K > 32 || ext_topk) ? 1 : 0; sa.ext_topk = ext_topk ? 1 : 0;
@@ -831,6 +879,12 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         sa.noise_row = c.noise_row; sa.noise_row0 = c.noise_row0; sa.noise_E = c.noise_E; sa.noise_ld = c.noise_ld;
         set_spec(sa);
 
+        // the dense train rows, launched beside the plan read-back: the sweep reads them, and so do the passes that start at
+        // `flags_event` (their noise rows, their own sweeps) -- nothing in front of this point does
+        if (bits_wait) {
+            HIP_CHECK(hipStreamWaitEvent(stream, cx.side_ev[4], 0));
+            side_guard.pending--;
+        }
         if (c.flag_snapshot) {
             HIP_CHECK(hipMemcpyAsync(c.flag_snapshot, c.noise_flag, sizeof(int) * (size_t)m, hipMemcpyDeviceToDevice, stream));
             HIP_CHECK(hipMemcpyAsync(c.flag_count_host, &plan->n_noise_flagged, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -1119,17 +1173,21 @@ void run_call(const Call<T> &c_in, hipStream_t stream, Ctx &cx, std::function<bo
         *cx.pinned_small = 0;
         c1.flag_snapshot = snap; c1.flag_count_host = cx.pinned_small; c1.flags_event = cx.flags_ev;
     }
-    run<T>(c1, stream, cx);
+    // The exact pass beside the first sweep: enqueued right behind the first pass, on the NOISE_SLOT context's HIGH-PRIORITY streams
+    // (create_stream) -- at normal priority its kernels would only be served when the sweep, which fills every compute unit, drains.
+    // (Measured and dropped: enqueueing it from inside the first pass's run(), in front of the sweep's dispatch:
+    // the host-side chain of the pass, two waits, keeps the sweep off the device for 0.8 ms.)
     Plan *plan = (Plan *)ws.get("plan", sizeof(Plan));
     int n_beside = 0;
     std::unique_lock<std::mutex> peer_lock;
-    if (beside) {
+    ScatterArgs<T> sc_keep{};
+    auto beside_pass = [&]() {
         HIP_CHECK(hipEventSynchronize(cx.flags_ev));                 // (early: the sweep has only just been launched)
         const int n_early = *cx.pinned_small;
         if (n_early > 0 && n_early <= cap) {
             Ctx &pc = peer_context(cx, NOISE_SLOT);
             peer_lock = std::unique_lock<std::mutex>(pc.mu);
-            if (!pc.own_stream) HIP_CHECK(hipStreamCreateWithFlags(&pc.own_stream, hipStreamNonBlocking));
+            if (!pc.own_stream) HIP_CHECK(create_stream(&pc.own_stream, pc.high_priority));
             hipStream_t ps = pc.own_stream;
             Workspace &pw = pc.ws;
             HIP_CHECK(hipStreamWaitEvent(ps, cx.flags_ev, 0));       // flags, their snapshot and the dense train rows are in place
@@ -1170,11 +1228,16 @@ void run_call(const Call<T> &c_in, hipStream_t stream, Ctx &cx, std::function<bo
             }
             g_last_ctx = &cx;                                        // rm_get_timings reports the main pass, not the small exact one
             HIP_CHECK(hipEventRecord(cx.pass_ev, ps));
-            HIP_CHECK(hipStreamWaitEvent(stream, cx.pass_ev, 0));    // behind the first pass (stream order) AND the exact one
-            hipLaunchKernelGGL(k_noise_scatter<T>, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, snap, sc);
-            HIP_CHECK(hipEventRecord(cx.done, stream));              // (the context's "last work" now ends with the scatter)
+            sc_keep = sc;
             n_beside = n_early;
         }
+    };
+    run<T>(c1, stream, cx);
+    if (beside) beside_pass();
+    if (n_beside > 0) {
+        HIP_CHECK(hipStreamWaitEvent(stream, cx.pass_ev, 0));        // behind the first pass (stream order) AND the exact one
+        hipLaunchKernelGGL(k_noise_scatter<T>, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, snap, sc_keep);
+        HIP_CHECK(hipEventRecord(cx.done, stream));                  // (the context's "last work" now ends with the scatter)
     }
     int *n_flagged_host = cx.pinned_small + 1;
     HIP_CHECK(hipMemcpyAsync(n_flagged_host, &plan->n_noise_flagged, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -1474,7 +1537,8 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     // (`tail`: what the fp32 tie noise still has to look at once the batch is through, run_call; `copy_out`: the batch's device-to-host
     // copies, enqueued behind the batch and once more when the tail rewrote outputs)
     long long users_copied = 0;                                       // users [0, users_copied) of the range have been handed over to the caller
-    struct InFlight { bool on = false; long long b0 = 0; int mb = 0; size_t boff[10]; size_t bo = 0; int which = 0;
+    long long flagged_total = 0;                                      // fp32 tie noise over the range: users the batches' first passes flagged
+    struct InFlight { bool on = false; bool counts_flags = false; long long b0 = 0; int mb = 0; size_t boff[10]; size_t bo = 0; int which = 0;
                       std::function<bool()> tail; std::function<void()> copy_out; } fl[2];
     auto finish = [&](int which) {                                    // wait for the batch in flight on context `which`, hand its outputs over
         InFlight &f = fl[which];
@@ -1489,6 +1553,7 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
         }
         stamp("outputs scattered");
         users_copied = std::max<long long>(users_copied, f.b0 + f.mb);
+        if (f.counts_flags) flagged_total += ctxs[which]->pinned_small[5];
         if (n_batches > 1) {                                          // more than one batch: add up the stage timings
             Ctx &c = *ctxs[which];
             float ta = 0, tb = 0, tc = 0, td = 0;
@@ -1511,12 +1576,28 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     };
     size_t x_off[10], x_bo = 0;                                       // layout of an exact pass's metric block: [metric][users of the range x width]
     for (int i = 0; i < 10; i++) { x_off[i] = x_bo; if (h.outs[i]) x_bo += (size_t)m * (i >= 8 ? 1 : per); }
-    auto scatter_exact = [&](const T *hx, const int *hu, int count) {  // the flagged users' values -> the caller's arrays
-        for (int i = 0; i < 10; i++) {
-            if (!h.outs[i]) continue;
-            const size_t w = i >= 8 ? 1 : per;
-            for (int f = 0; f < count; f++)
-                std::memcpy(h.outs[i] + ((size_t)u0 + hu[f]) * w, hx + x_off[i] + (size_t)hu[f] * w, sizeof(T) * w);
+    // an exact pass's results leave the device packed: one record of `out_w` values per evaluated user (k_noise_gather)
+    size_t rec_off[10], rec_w = 0;
+    for (int i = 0; i < 10; i++) { rec_off[i] = rec_w; if (h.outs[i]) rec_w += i >= 8 ? 1 : per; }
+    auto gather_exact = [&](Ctx &gc, const T *dx, const int *row_user, int count, hipStream_t st, T *&hx, int *&hu) {
+        GatherArgs<T> ga{};
+        for (int i = 0; i < 10; i++) { ga.src[i] = h.outs[i] ? dx + x_off[i] : nullptr; ga.width[i] = i >= 8 ? 1 : (int)per; ga.off[i] = (int)rec_off[i]; }
+        ga.out_w = (int)rec_w;
+        T *dg = (T *)gc.ws.get("o_exact_packed", sizeof(T) * rec_w * (size_t)count);
+        hipLaunchKernelGGL(k_noise_gather<T>, dim3(cdiv(count, 256)), dim3(256), 0, st, count, row_user, ga, dg);
+        hx = (T *)gc.pinned_get(sizeof(T) * rec_w * (size_t)count + sizeof(int) * (size_t)count);
+        hu = (int *)(hx + rec_w * (size_t)count);
+        HIP_CHECK(hipMemcpyAsync(hx, dg, sizeof(T) * rec_w * (size_t)count, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(hu, row_user, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost, st));
+    };
+    auto scatter_exact = [&](const T *hx, const int *hu, int count) {  // the flagged users' records -> the caller's arrays
+        for (int f = 0; f < count; f++) {
+            const T *rec = hx + (size_t)f * rec_w;
+            for (int i = 0; i < 10; i++) {
+                if (!h.outs[i]) continue;
+                const size_t w = i >= 8 ? 1 : per;
+                std::memcpy(h.outs[i] + ((size_t)u0 + hu[f]) * w, rec + rec_off[i], sizeof(T) * w);
+            }
         }
     };
     struct Beside { bool ran = false; int count = 0; T *hx = nullptr; int *hu = nullptr; Ctx *pc = nullptr; hipStream_t stream = nullptr; std::unique_lock<std::mutex> lock; } bes;
@@ -1524,21 +1605,22 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     // has scored its positives, noise rows for those users (from dense train rows built for them alone), the pipeline for them,
     // and the copy of their metric block to page-locked memory -- all of it enqueued behind `flags_ev`, none of it waited for here
     // except the count of the flagged users
-    auto beside_start = [&](long long b0_last, hipStream_t other_stream) {
+    // It runs on the NOISE_SLOT context's high-priority streams (create_stream): at normal priority, kernels that reach the device after
+    // a sweep which fills every compute unit only start when it drains -- the pass began when the last batch ended and cost its full
+    // 0.9 ms (profiles/r5_host_entry.txt).
+    auto beside_start = [&](long long b0_last, hipEvent_t other) {
         if (!out_w) return;
         Ctx &pc = peer_context(cx, NOISE_SLOT);
         bes.lock = std::unique_lock<std::mutex>(pc.mu);
         bes.pc = &pc;
-        if (!pc.own_stream) HIP_CHECK(hipStreamCreateWithFlags(&pc.own_stream, hipStreamNonBlocking));
-        // The pass goes onto the stream of the batch BEFORE the last one (the other batch context's), behind that batch: the two batch
-        // streams are known to run side by side -- the pipeline lives on it -- whereas one more stream may share a hardware queue
-        // with the last batch's (the runtime multiplexes streams onto four queues) and then waits for its whole sweep: measured,
-        // the pass started when the last batch ended.  One batch context only: the NOISE_SLOT context's own stream.
-        hipStream_t ps = other_stream ? other_stream : pc.own_stream;
+        if (!pc.own_stream) HIP_CHECK(create_stream(&pc.own_stream, pc.high_priority));
+        hipStream_t ps = pc.own_stream;
         bes.stream = ps;
         Workspace &pw = pc.ws;
-        if (pc.ev_valid) HIP_CHECK(hipStreamWaitEvent(ps, pc.done, 0));    // (an earlier call's pass on this context, on another stream)
         HIP_CHECK(hipStreamWaitEvent(ps, cx.flags_ev, 0));
+        // (the batch before the last runs on the other context's stream: its positives -- the early flags -- are in place once its
+        // own sweep has been launched, the event run() records as ev[1]; what its k_finalize flags later is the late pass's)
+        if (other) HIP_CHECK(hipStreamWaitEvent(ps, other, 0));
         // (the earlier batches' flags as they stand: a flag their k_finalize sets later is the sequential pass's, below)
         if (b0_last > 0) HIP_CHECK(hipMemcpyAsync(range_snap, range_flag, sizeof(int) * (size_t)b0_last, hipMemcpyDeviceToDevice, ps));
         int *noise_row = (int *)pw.get("noise_row", sizeof(int) * (size_t)m);
@@ -1580,10 +1662,7 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
             throw;
         }
         g_last_ctx = &cx;
-        bes.hx = (T *)pc.pinned_get(sizeof(T) * x_bo + sizeof(int) * (size_t)n_early);
-        bes.hu = (int *)(bes.hx + x_bo);
-        HIP_CHECK(hipMemcpyAsync(bes.hx, dx, sizeof(T) * x_bo, hipMemcpyDeviceToHost, ps));
-        HIP_CHECK(hipMemcpyAsync(bes.hu, row_user, sizeof(int) * (size_t)n_early, hipMemcpyDeviceToHost, ps));
+        gather_exact(pc, dx, row_user, n_early, ps, bes.hx, bes.hu);
         bes.ran = true; bes.count = n_early;
     };
     //  a call that stops between its first passes and the exact one -- interrupt, failure -- must not leave the first
@@ -1628,7 +1707,9 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
         c.seed = h.seed; c.user0 = (long long)u0 + b0;
         if (range_noise) c.first_pass_flags = range_flag + b0;
         const bool snap_here = beside_last && bi == n_batches - 1;
-        if (snap_here) { c.flag_snapshot = range_snap + b0; c.flag_count_host = cx.pinned_small; c.flags_event = cx.flags_ev; }
+        if (snap_here) {
+            c.flag_snapshot = range_snap + b0; c.flag_count_host = cx.pinned_small; c.flags_event = cx.flags_ev;
+        }
         // enqueued (one short plan read-back inside; with more than one batch the tie noise's last look at the batch is deferred to
         // finish(): the next batch is enqueued first)
         run_call<T>(c, bs, bc, n_batches > 1 ? &f.tail : nullptr);
@@ -1636,7 +1717,11 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
         stamp("batch enqueued");
         const size_t bo = f.bo;
         const long long e0 = tep[b0], e1 = tep[b1];                 // this batch's test entries (range-relative)
+        Plan *batch_plan = (Plan *)bc.ws.get("plan", sizeof(Plan));
+        int *flagged_here = (range_noise && bc.pinned_small) ? bc.pinned_small + 5 : nullptr;
+        f.counts_flags = flagged_here != nullptr;
         f.copy_out = [=, &h]() {
+            if (flagged_here) HIP_CHECK(hipMemcpyAsync(flagged_here, &batch_plan->n_noise_flagged, sizeof(int), hipMemcpyDeviceToHost, bs));
             if (bo) HIP_CHECK(hipMemcpyAsync(hblocks[which], dblocks[which], sizeof(T) * bo, hipMemcpyDeviceToHost, bs));
             if (h.topk_idx) {
                 HIP_CHECK(hipMemcpyAsync(h.topk_idx + ((size_t)u0 + b0) * K, c.topk_idx, sizeof(int) * (size_t)mb * K, hipMemcpyDeviceToHost, bs));
@@ -1650,13 +1735,13 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
         if (bi + 1 < n_batches && !g_interrupt) upload_users(bi + 1);
         stamp("next rows enqueued");
         if (snap_here && !g_interrupt) {
-            // (behind the batch before this one, on that batch's stream: its flags are final there)
-            beside_start(b0, (two_ctx && bi > 0) ? streams[(bi - 1) & 1] : (hipStream_t)nullptr);
+            beside_start(b0, (two_ctx && bi > 0) ? ctxs[(bi - 1) & 1]->ev[1] : (hipEvent_t)nullptr);
             stamp("exact pass beside the last batch enqueued");
         }
         if (!two_ctx) finish(which);
     }
-    finish(0); finish(1);
+    // (the batch before the last one first: its outputs are copied to the caller while the last batch is still on the device)
+    { const int older = two_ctx ? ((n_batches - 2) & 1) : 0; finish(older); finish(older ^ 1); }
     g_last_ctx = &cx;
     if (range_noise && !g_interrupt && out_w) {
         if (bes.ran) {                                                // (its results left the device while the last batch was sweeping)
@@ -1669,17 +1754,20 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
         Call<T> c = range_call();
         T *dx = (T *)ws.get("o_exact", sizeof(T) * std::max<size_t>(x_bo, 1));
         for (int i = 0; i < 10; i++) c.out[i] = h.outs[i] ? dx + x_off[i] : nullptr;
-        const int *row_user = nullptr;
-        const int n_flagged = noise_exact_pass<T>(c, range_flag, bes.ran ? (const int *)range_snap : (const int *)nullptr, -1, stream, cx, &row_user);
-        stamp("exact pass enqueued");
-        if (n_flagged > 0) {
-            T *hx = (T *)cx.pinned_get(sizeof(T) * x_bo + sizeof(int) * (size_t)n_flagged);
-            int *hu = (int *)(hx + x_bo);
-            HIP_CHECK(hipMemcpyAsync(hx, dx, sizeof(T) * x_bo, hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipMemcpyAsync(hu, row_user, sizeof(int) * (size_t)n_flagged, hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
-            scatter_exact(hx, hu, n_flagged);
-            stamp("exact pass scattered");
+        // (every batch reports how many users its first pass flagged: when the pass beside the last batch has seen them all --
+        // the usual case -- nothing is left to look for)
+        const long long late = flagged_total - (bes.ran ? bes.count : 0);
+        if (late > 0) {
+            const int *row_user = nullptr;
+            const int n_flagged = noise_exact_pass<T>(c, range_flag, bes.ran ? (const int *)range_snap : (const int *)nullptr, -1, stream, cx, &row_user);
+            stamp("exact pass enqueued");
+            if (n_flagged > 0) {
+                T *hx = nullptr; int *hu = nullptr;
+                gather_exact(cx, dx, row_user, n_flagged, stream, hx, hu);
+                HIP_CHECK(hipStreamSynchronize(stream));
+                scatter_exact(hx, hu, n_flagged);
+                stamp("exact pass scattered");
+            }
         }
     } else if (bes.pc) (void)hipStreamSynchronize(bes.stream);
     if (g_interrupt) nan_flagged();

@@ -207,6 +207,22 @@ __global__ void k_noise_scatter(int m, const int *picked, ScatterArgs<T> a)
         for (int j = 0; j < a.width[i]; j++) a.dst[i][o + j] = a.src[i][o + j];
     }
 }
+// the metric values of the users an exact pass evaluated, packed: out[f][...] for the f-th user of `row_user` (the host copies
+// `count` short records instead of a metric block over every user of the range)
+template <class T> struct GatherArgs { const T *src[10]; int width[10]; int off[10]; int out_w; };
+template <class T>
+__global__ void k_noise_gather(int count, const int *row_user, GatherArgs<T> a, T *out)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= count) return;
+    const size_t u = (size_t)row_user[f];
+    T *o = out + (size_t)f * a.out_w;
+    #pragma unroll
+    for (int i = 0; i < 10; i++) {
+        if (!a.src[i]) continue;
+        for (int j = 0; j < a.width[i]; j++) o[a.off[i] + j] = a.src[i][u * a.width[i] + j];
+    }
+}
 __global__ void k_noise_select(int m, const int *noise_row, int r0, int r1, unsigned char *only)
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;

@@ -20,6 +20,10 @@ struct ClassifyArgs {
     Plan *plan;
     const unsigned char *only;   // optional [m]: evaluate only the users with a non-zero entry (the others: UF_SKIP)
     int force_stream;            // 1 = every evaluated user is streamed (top-K picked from its stored scores: k_metrics > 256)
+    int allow_stream;            // 1 = users with more than POS_CHUNK test items are streamed (the host has a budget for score rows; it
+                                 //     looks at the count afterwards and plans again without when the rows do not fit)
+    int check_ptr;               // 1 = validate the index pointers of every row here (first pass of a call over these users)
+    long long nnz_train, nnz_test;
 };
 
 __device__ __forceinline__ int chunk_depth(int pc)      // smallest j with 2^j - 1 >= pc   (pc in 1..63)
@@ -28,77 +32,103 @@ __device__ __forceinline__ int chunk_depth(int pc)      // smallest j with 2^j -
 }
 
 // ---- validation of the CSR inputs (first kernels of the plan) ----------------------------------------------------------
-// k_check_csr_ptr: index pointers of the m rows start at >= 0, never decrease and end within the index arrays.
-// k_check_csr_rows: every column index lies in [0, n) and every row ascends (equal neighbours allowed, as SciPy's
-// has_sorted_indices); 16 lanes per row, the row strided over them.  Both report through plan->csr_bad; every later kernel that
-// would index by what these arrays hold (k_assign_slots, k_block_rows, k_group_rows, k_train_bits) returns when INDPTR / INDEX is set.
+// k_classify (ClassifyArgs::check_ptr): index pointers of the m rows start at >= 0, never decrease and end within the index arrays.
+// k_check_csr_flat / k_check_csr_starts: every column index lies in [0, n) and every row ascends (equal neighbours allowed, as
+// SciPy's has_sorted_indices).  They report through plan->csr_bad and the descent counters; every later kernel that
+// would index by what these arrays hold (k_assign_slots, k_block_tables, k_train_bits) returns when INDPTR / INDEX is set.
+// (the index pointers alone, for check_csr_now: the validation in front of the fp64 tie noise, which indexes by the rows before the plan runs)
 __global__ void k_check_csr_ptr(int m, const int *train_p, long long nnz_train, const int *test_p, long long nnz_test, Plan *plan)
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= m) return;
     const int a0 = train_p[u], a1 = train_p[u + 1], b0 = test_p[u], b1 = test_p[u + 1];
-    const bool bad = a0 < 0 || a1 < a0 || (long long)a1 > nnz_train || b0 < 0 || b1 < b0 || (long long)b1 > nnz_test;
-    if (bad) { atomicOr(&plan->csr_bad, CSR_BAD_INDPTR); plan->csr_where = u; }
+    if (a0 < 0 || a1 < a0 || (long long)a1 > nnz_train || b0 < 0 || b1 < b0 || (long long)b1 > nnz_test) { atomicOr(&plan->csr_bad, CSR_BAD_INDPTR); plan->csr_where = u; }
 }
-constexpr int CHECK_ROW_LANES = 16;
-__global__ void k_check_csr_rows(int m, int n, const int *train_p, const int *train_i, const int *test_p, const int *test_i, Plan *plan,
-                                 const unsigned char *only)
+// The indices themselves, FLAT: one thread per four entries of the index array (16-byte loads, fully coalesced: the 80 MB of
+// BASELINE C2 in ~25 us; a walk row by row -- 16 lanes per row, two dependent loads per step -- took 177 us).  Range: every
+// entry in [0, n).  Order: every DESCENT idx[e] > idx[e + 1] of the flat array is counted; a descent is legitimate exactly when
+// e + 1 starts a row, and k_check_csr_starts counts those per row boundary -- the rows are sorted iff the two counts agree
+// (the host compares them in the plan read-back).  Entries [p[0], p[m]) of this call's rows only.
+constexpr int CHECK_FLAT_THREADS = 256, CHECK_FLAT_BLOCKS = 1024;      // (a grid of at most that many blocks: one atomic per block at the end)
+__global__ __launch_bounds__(CHECK_FLAT_THREADS) void k_check_csr_flat(int m, int n, const int *indptr, const int *idx, Plan *plan, int which)
 {
     if (plan->csr_bad & CSR_BAD_INDPTR) return;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int sub = (int)(threadIdx.x % CHECK_ROW_LANES);
-    int bad = 0, where = 0;
-    for (long long u = t / CHECK_ROW_LANES; u < m; u += (long long)gridDim.x * blockDim.x / CHECK_ROW_LANES) {
-        if (only && !only[u]) continue;
-        #pragma unroll
-        for (int which = 0; which < 2; which++) {
-            const int *p = which ? test_p : train_p, *idx = which ? test_i : train_i;
-            const int e1 = p[u + 1];
-            for (int e = p[u] + sub; e < e1; e += CHECK_ROW_LANES) {
-                const int x = idx[e];
-                const int nx = e + 1 < e1 ? idx[e + 1] : 0x7fffffff;
-                int b = ((unsigned)x >= (unsigned)n) ? CSR_BAD_INDEX : 0;
-                if (x > nx) b |= which ? CSR_UNSORTED_TEST : CSR_UNSORTED_TRAIN;
-                if (b) { bad |= b; where = (int)u; }
+    const long long e0 = indptr[0], e1 = indptr[m];
+    const bool aligned = (((size_t)idx) & 15) == 0;
+    unsigned desc = 0; bool bad = false; long long bad_at = 0;
+    // (aligned groups of four entries of the ARRAY, so that the 16-byte loads are aligned whatever e0 is)
+    for (long long g = (e0 >> 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; (g << 2) < e1; g += (long long)gridDim.x * blockDim.x) {
+        const long long e = g << 2;
+        if (e >= e0 && e + 4 < e1 && aligned) {
+            const int4 q = *(const int4 *)(idx + e);
+            const int x4 = idx[e + 4];
+            const int x[5] = {q.x, q.y, q.z, q.w, x4};
+            #pragma unroll
+            for (int i = 0; i < 4; i++) { if ((unsigned)x[i] >= (unsigned)n) { bad = true; bad_at = e + i; } desc += x[i] > x[i + 1]; }
+        } else {
+            for (int i = 0; i < 4; i++) {
+                const long long f = e + i;
+                if (f < e0 || f >= e1) continue;
+                const int v = idx[f];
+                if ((unsigned)v >= (unsigned)n) { bad = true; bad_at = f; }
+                if (f + 1 < e1) desc += v > idx[f + 1];
             }
         }
     }
-    if (bad) { atomicOr(&plan->csr_bad, bad); if (bad & CSR_BAD_INDEX) plan->csr_where = where; }
+    if (bad) {                                                    // rare: name the row (the last row that starts at or before the entry)
+        int lo = 0, hi = m;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((long long)indptr[mid] <= bad_at) lo = mid; else hi = mid - 1; }
+        atomicOr(&plan->csr_bad, CSR_BAD_INDEX); plan->csr_where = lo;
+    }
+    #pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) desc += __shfl_xor(desc, d);
+    __shared__ unsigned blk;
+    if (threadIdx.x == 0) blk = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && desc) atomicAdd(&blk, desc);
+    __syncthreads();
+    if (threadIdx.x == 0 && blk) atomicAdd(&plan->csr_desc_all[which], (unsigned long long)blk);
 }
-
-// users with more than POS_CHUNK test items (an upper bound of the streamed class: eligibility is not looked at), and the
-// decision whether their score rows fit the HBM budget (`cap` rows)
-__global__ void k_count_long(int m, const int *test_p, Plan *plan, const unsigned char *only)
+// the legitimate descents: one thread per row boundary (the smallest u with p[u] = s names each distinct start s once)
+__global__ __launch_bounds__(1024) void k_check_csr_starts(int m, const int *train_p, const int *train_i, const int *test_p, const int *test_i, Plan *plan)
 {
-    // (one atomic pair per BLOCK: atomics of thousands of waves on the same two words serialise -- 30 us at BASELINE C2 with one
-    // pair per wave)
-    __shared__ int blk_cnt, blk_max;
-    if (threadIdx.x == 0) { blk_cnt = 0; blk_max = 0; }
+    if (plan->csr_bad & CSR_BAD_INDPTR) return;
+    __shared__ unsigned blk[2];
+    if (threadIdx.x < 2) blk[threadIdx.x] = 0;
     __syncthreads();
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    const int npos = (u < m && !(only && !only[u])) ? test_p[u + 1] - test_p[u] : 0;
-    const bool lng = npos > POS_CHUNK;
-    const unsigned long long mk = __ballot(lng);
-    if (mk) {
-        int mx = lng ? npos : 0;
-        #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
-        if ((threadIdx.x & 63) == __ffsll((long long)mk) - 1) { atomicAdd(&blk_cnt, __popcll(mk)); atomicMax(&blk_max, mx); }
+    unsigned d0 = 0, d1 = 0;
+    if (u >= 1 && u < m) {
+        const int s = train_p[u], e1 = train_p[m], e0 = train_p[0];
+        if (train_p[u - 1] < s && s > e0 && s < e1) d0 = train_i[s - 1] > train_i[s];
+        const int t = test_p[u], f1 = test_p[m], f0 = test_p[0];
+        if (test_p[u - 1] < t && t > f0 && t < f1) d1 = test_i[t - 1] > test_i[t];
+    }
+    const unsigned long long b0 = __ballot(d0), b1 = __ballot(d1);
+    if ((threadIdx.x & 63) == 0) {
+        if (b0) atomicAdd(&blk[0], (unsigned)__popcll(b0));
+        if (b1) atomicAdd(&blk[1], (unsigned)__popcll(b1));
     }
     __syncthreads();
-    if (threadIdx.x == 0 && blk_cnt) { atomicAdd(&plan->n_long, blk_cnt); atomicMax(&plan->max_npos, blk_max); }
+    if (threadIdx.x < 2 && blk[threadIdx.x]) atomicAdd(&plan->csr_desc_legit[threadIdx.x], (unsigned long long)blk[threadIdx.x]);
 }
-__global__ void k_decide_stream(Plan *plan, long long cap) { plan->stream_enable = plan->n_long > 0 && plan->n_long <= cap; }
 
 // reference recometrics.hpp:439-448, :479-486  (one thread per user)
+// Also, in the same pass over the index pointers: their validation (check_ptr), the number of users with more than POS_CHUNK test
+// items and the longest such row (plan->n_long, max_npos: eligibility is not looked at, as an upper bound of the streamed class).
 __global__ void k_classify(ClassifyArgs a)
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     const bool skip = u < a.m && a.only && !a.only[u];
-    const bool live = u < a.m && !skip;
+    bool live = u < a.m && !skip;
     if (skip) { a.flags[u] = UF_SKIP; a.user_nslots[u] = 0; }
-    const int ntr = live ? a.train_p[u + 1] - a.train_p[u] : 0;
-    const int npos = live ? a.test_p[u + 1] - a.test_p[u] : 0;
+    int ntr = 0, npos = 0;
+    if (live) {
+        const int a0 = a.train_p[u], a1 = a.train_p[u + 1], b0 = a.test_p[u], b1 = a.test_p[u + 1];
+        if (a.check_ptr && (a0 < 0 || a1 < a0 || (long long)a1 > a.nnz_train || b0 < 0 || b1 < b0 || (long long)b1 > a.nnz_test)) {
+            atomicOr(&a.plan->csr_bad, CSR_BAD_INDPTR); a.plan->csr_where = u;
+        } else { ntr = a1 - a0; npos = b1 - b0; }
+    }
     const int cand = a.n - ntr;
     bool isnan_user = !live || npos <= 0 || (ntr + npos >= a.n && !(a.req & RQ_NDCG)) || cand < a.min_items_pool ||
                       (!a.cold && ntr == 0) || npos < a.min_pos_test;
@@ -109,7 +139,7 @@ __global__ void k_classify(ClassifyArgs a)
     if (isnan_user) f = UF_NAN;
     else {
         f = UF_ACTIVE | (only_ndcg ? UF_ONLY_NDCG : 0) | (kleqn ? UF_KLEQN : 0);
-        if (a.force_stream || (a.want_auc && !only_ndcg && npos > POS_CHUNK && a.plan->stream_enable)) {
+        if (a.force_stream || (a.want_auc && !only_ndcg && npos > POS_CHUNK && a.allow_stream)) {
             nsl = 1;                                            // streamed user: one slot, ranks from its stored score row
             myclass = STREAM_CLASS;
         } else if (a.want_auc && !only_ndcg) {
@@ -123,8 +153,8 @@ __global__ void k_classify(ClassifyArgs a)
         }
     }
     // counts are aggregated per block in LDS, then one global atomic per block and class (the counters share a line)
-    __shared__ int blk_count[N_CLASSES + 1];                      // [N_CLASSES] = evaluated users
-    if (threadIdx.x <= N_CLASSES) blk_count[threadIdx.x] = 0;
+    __shared__ int blk_count[N_CLASSES + 3];                      // [N_CLASSES] = evaluated users, [+1] long rows, [+2] the longest of them
+    if (threadIdx.x < N_CLASSES + 3) blk_count[threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const unsigned long long act = __ballot(!isnan_user);
@@ -134,16 +164,25 @@ __global__ void k_classify(ClassifyArgs a)
         if (mk && lane == __ffsll((long long)mk) - 1) atomicAdd(&blk_count[j], __popcll(mk));
     }
     if (nfull) atomicAdd(&blk_count[MAX_J], nfull);
+    const bool lng = live && npos > POS_CHUNK;
+    const unsigned long long lm = __ballot(lng);
+    if (lm) {
+        int mx = lng ? npos : 0;
+        #pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+        if (lane == __ffsll((long long)lm) - 1) { atomicAdd(&blk_count[N_CLASSES + 1], __popcll(lm)); atomicMax(&blk_count[N_CLASSES + 2], mx); }
+    }
     if (live) { a.flags[u] = f; a.user_nslots[u] = nsl; }
     if (live && !isnan_user && npos > HEAVY_NPOS) a.heavy_users[atomicAdd(&a.plan->n_heavy, 1)] = u;      // rare
     if (live && !isnan_user && only_ndcg) atomicAdd(&a.plan->n_only_ndcg, 1);                              // rarer
     __syncthreads();
     if (threadIdx.x < N_CLASSES && blk_count[threadIdx.x]) atomicAdd(&a.plan->class_count[threadIdx.x], blk_count[threadIdx.x]);
     if (threadIdx.x == N_CLASSES && blk_count[N_CLASSES]) atomicAdd(&a.plan->n_active, blk_count[N_CLASSES]);
+    if (threadIdx.x == N_CLASSES + 1 && blk_count[N_CLASSES + 1]) { atomicAdd(&a.plan->n_long, blk_count[N_CLASSES + 1]); atomicMax(&a.plan->max_npos, blk_count[N_CLASSES + 2]); }
 }
 
-// Long arrays are scanned in three launches: k_scan_tiles (every block scans its own 1024 entries and reports its total),
-// k_scan_exclusive over the block totals, k_scan_add_offsets.
+// Long arrays are scanned in two launches: k_scan_tiles (every block scans its own 1024 entries and reports its total) and
+// k_scan_exclusive over the block totals; the consumer (k_assign_slots) adds its tile's offset itself.
 __global__ __launch_bounds__(1024) void k_scan_tiles(const int *in, int *out, int count, int *tile_total)
 {
     __shared__ int wsum[16];
@@ -160,14 +199,23 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const int *in, int *out, in
     if (i < count) out[i] = woff + x - v;
     if (tid == 1023) tile_total[blockIdx.x] = woff + x;
 }
-__global__ void k_scan_add_offsets(int *out, int count, const int *tile_offset)
+// exclusive scan of int array by ONE block of 1024 threads (m <= 2^31; a few hundred iterations at m = 1M)
+__device__ inline void plan_classes(Plan *p, int gu, int n_slots)      // one thread; gu = users per group (32 fp32, 16 fp64)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) out[i] += tile_offset[i >> 10];
+    int off = 0, jmax = 0;
+    for (int j = 0; j < N_CLASSES; j++) {
+        p->class_offset[j] = off;
+        off += p->class_count[j];
+        if (p->class_count[j] && j <= MAX_J) jmax = j;         // deepest TABLE: streamed users have none
+        p->class_cursor[j] = 0;
+    }
+    p->class_offset[N_CLASSES] = off;
+    p->n_groups = (n_slots + gu - 1) / gu;
+    p->jmax = jmax;
 }
 
-// exclusive scan of int array by ONE block of 1024 threads (m <= 2^31; a few hundred iterations at m = 1M)
-__global__ void k_scan_exclusive(const int *in, int *out, int count, int *total_out)
+// (`classes`, optional: the thread that holds the total also lays out the depth classes -- what used to be a launch of one thread)
+__global__ void k_scan_exclusive(const int *in, int *out, int count, int *total_out, Plan *classes, int gu)
 {
     __shared__ int wsum[16];
     __shared__ int carry_s;
@@ -191,20 +239,7 @@ __global__ void k_scan_exclusive(const int *in, int *out, int count, int *total_
         __syncthreads();
     }
     if (tid == 0 && total_out) *total_out = carry_s;
-}
-
-__global__ void k_plan_classes(Plan *p, int gu)      // one thread; gu = users per group (32 fp32, 16 fp64)
-{
-    int off = 0, jmax = 0;
-    for (int j = 0; j < N_CLASSES; j++) {
-        p->class_offset[j] = off;
-        off += p->class_count[j];
-        if (p->class_count[j] && j <= MAX_J) jmax = j;         // deepest TABLE: streamed users have none
-        p->class_cursor[j] = 0;
-    }
-    p->class_offset[N_CLASSES] = off;
-    p->n_groups = (p->n_slots + gu - 1) / gu;
-    p->jmax = jmax;
+    if (tid == 0 && classes) plan_classes(classes, gu, carry_s);
 }
 
 struct AssignArgs {
@@ -216,6 +251,7 @@ struct AssignArgs {
     unsigned char *slot_j;
     int *sc_user, *sc_chunk;     // work list of the streamed users' chunks of POS_CHUNK test entries (plan->n_stream_chunks of them)
     int force_stream;
+    const int *tile_offset;      // optional: uslot_base holds scans of tiles of 1024 users (k_scan_tiles); tile t starts at tile_offset[t]
 };
 
 // scatter every (user, chunk) into its depth class; order inside a class is arbitrary (results do not depend on it).
@@ -224,14 +260,20 @@ struct AssignArgs {
 constexpr int ASSIGN_THREADS = 1024;
 __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign_slots(AssignArgs a)
 {
-    __shared__ int blk_count[N_CLASSES], blk_base[N_CLASSES];
+    __shared__ int blk_count[N_CLASSES], blk_base[N_CLASSES], blk_chunks, blk_chunk_base;
     if (a.plan->csr_bad & CSR_BAD_INDPTR) return;                 // (row lengths that cannot be trusted would index out of the slot arrays)
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     if (threadIdx.x < N_CLASSES) blk_count[threadIdx.x] = 0;
+    if (threadIdx.x == N_CLASSES) blk_chunks = 0;
     __syncthreads();
     const int nsl = u < a.m ? a.user_nslots[u] : 0;
     const int npos = nsl ? a.test_p[u + 1] - a.test_p[u] : 0;
+    int ubase = 0;
+    if (u < a.m) {                                                // the scan's last step, in place: every later reader sees final values
+        ubase = a.uslot_base[u] + (a.tile_offset ? a.tile_offset[u >> 10] : 0);
+        if (a.tile_offset) ((int *)a.uslot_base)[u] = ubase;
+    }
     const bool auc_user = nsl && a.want_auc && !(a.flags[u] & UF_ONLY_NDCG);
     // last (or only) chunk of every user: position inside the block's share of its class
     int jlast = -1, in_blk = 0;
@@ -249,12 +291,17 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign_slots(AssignArgs a)
     // the full 63-positive chunks of heavy users (rare): nsl - 1 consecutive positions each in the deepest class
     int full_at = 0;
     if (nsl > 1) full_at = atomicAdd(&blk_count[MAX_J], nsl - 1);
+    // the streamed users' work list of chunks: places inside the block's share by an LDS atomic, ONE global atomic per block (a
+    // fifth of BASELINE C2's users are streamed: one returning global atomic each, all on one word, was most of this kernel's 30 us)
+    const int nch = (streamed && auc_user) ? (npos + POS_CHUNK - 1) / POS_CHUNK : 0;
+    int ch_at = 0;
+    if (nch) ch_at = atomicAdd(&blk_chunks, nch);
     __syncthreads();
     if (threadIdx.x < N_CLASSES && blk_count[threadIdx.x]) blk_base[threadIdx.x] = atomicAdd(&a.plan->class_cursor[threadIdx.x], blk_count[threadIdx.x]);
+    if (threadIdx.x == N_CLASSES && blk_chunks) blk_chunk_base = atomicAdd(&a.plan->n_stream_chunks, blk_chunks);
     __syncthreads();
-    if (streamed && auc_user) {                                  // rare: the order of the work list does not matter
-        const int nch = (npos + POS_CHUNK - 1) / POS_CHUNK;
-        const int at = atomicAdd(&a.plan->n_stream_chunks, nch);
+    if (nch) {                                                   // the order of the work list does not matter
+        const int at = blk_chunk_base + ch_at;
         for (int c = 0; c < nch; c++) { a.sc_user[at + c] = u; a.sc_chunk[at + c] = c; }
     }
     if (nsl) {
@@ -262,47 +309,66 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign_slots(AssignArgs a)
         a.slot_user[pos] = u;
         a.slot_chunk[pos] = nsl - 1;
         a.slot_j[pos] = (unsigned char)jlast;
-        a.slot_index[a.uslot_base[u] + nsl - 1] = pos;
+        a.slot_index[ubase + nsl - 1] = pos;
     }
     for (int c = 0; c < nsl - 1; c++) {
         const int pos = a.plan->class_offset[MAX_J] + blk_base[MAX_J] + full_at + c;
         a.slot_user[pos] = u;
         a.slot_chunk[pos] = c;
         a.slot_j[pos] = (unsigned char)MAX_J;
-        a.slot_index[a.uslot_base[u] + c] = pos;
+        a.slot_index[ubase + c] = pos;
     }
 }
 
-// per sweep block (4 groups): uniform tree depth jb = depth of its last slot (slots are sorted by depth); the block's
-// positive tables take 2^jb - 1 rows per group.  k_block_rows -> k_scan_exclusive -> k_group_rows.
-__global__ void k_block_rows(const Plan *p, const unsigned char *slot_j, int *blk_j, int *blk_rows, int gu)
+// per sweep block (4 groups): uniform tree depth jb = depth of its last slot (slots are sorted by depth); the block's positive
+// tables take 2^jb - 1 rows per group.  ONE block of 1024 threads walks the sweep blocks 1024 at a time: depth and rows of each,
+// their running sum, and from it gj / grow of the block's groups (what used to be k_block_rows -> a scan -> k_group_rows).
+__global__ __launch_bounds__(1024) void k_block_tables(Plan *p, const unsigned char *slot_j, int *gj, long long *grow, int gu)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int wsum[16];
+    __shared__ long long carry_s;
     if (p->csr_bad & CSR_BAD_INDPTR) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ng = p->n_groups, ns = p->n_slots;
-    if (b * GROUPS_PER_BLOCK >= ng) return;
-    const int glast = min(ng, (b + 1) * GROUPS_PER_BLOCK) - 1;
-    const int slast = min(ns, (glast + 1) * gu) - 1;
-    int jb = slot_j[slast];
-    if (jb == STREAM_CLASS) {
-        // streamed slots are the last class: a block of nothing else has no tables at all, the one block that straddles
-        // the boundary sizes its tables for the deepest of its other slots
-        const int first_stream = p->class_offset[STREAM_CLASS];
-        jb = first_stream > b * GROUPS_PER_BLOCK * gu ? slot_j[first_stream - 1] : 0;
+    const int nb = (ng + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int b = base + tid;
+        int jb = 0, ngb = 0;
+        if (b < nb) {
+            const int glast = min(ng, (b + 1) * GROUPS_PER_BLOCK) - 1;
+            const int slast = min(ns, (glast + 1) * gu) - 1;
+            jb = slot_j[slast];
+            if (jb == STREAM_CLASS) {
+                // streamed slots are the last class: a block of nothing else has no tables at all, the one block that straddles
+                // the boundary sizes its tables for the deepest of its other slots
+                const int first_stream = p->class_offset[STREAM_CLASS];
+                jb = first_stream > b * GROUPS_PER_BLOCK * gu ? slot_j[first_stream - 1] : 0;
+            }
+            ngb = glast - b * GROUPS_PER_BLOCK + 1;
+        }
+        const int per_group = (1 << jb) - 1;
+        const int v = ngb * per_group;
+        int x = v;
+        #pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        const long long carry = carry_s;
+        const long long mine = carry + woff + x - v;               // rows in front of this block's tables
+        for (int q = 0; q < ngb; q++) {
+            const int g = b * GROUPS_PER_BLOCK + q;
+            gj[g] = jb;
+            grow[g] = mine + (long long)q * per_group;
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + x;
+        __syncthreads();
     }
-    blk_j[b] = jb;
-    blk_rows[b] = (glast - b * GROUPS_PER_BLOCK + 1) * ((1 << jb) - 1);
-}
-
-__global__ void k_group_rows(Plan *p, const int *blk_j, const int *blk_base, const int *blk_total, int *gj, long long *grow)
-{
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p->csr_bad & CSR_BAD_INDPTR) return;
-    if (g == 0) p->total_rows = *blk_total;
-    if (g >= p->n_groups) return;
-    const int b = g / GROUPS_PER_BLOCK, jb = blk_j[b];
-    gj[g] = jb;
-    grow[g] = (long long)blk_base[b] + (long long)(g % GROUPS_PER_BLOCK) * ((1 << jb) - 1);
+    if (tid == 0) p->total_rows = carry_s;
 }
 
 // max |x| over a row-major matrix (rows x k, leading dimension ld) + a non-finite flag: lets the host prove that no
@@ -358,21 +424,19 @@ __global__ void k_absmax(const T *X, size_t ld, long long rows, int k, unsigned 
 // test items high this removes most of the warm-up inserts; with random factors about a fifth.  Users whose positives span
 // several slots are left alone (their best positives are not in the primary slot's table).
 template <class T, class KeyT>
-__global__ void k_seed_thresholds(int n_slots, int stream_slot0, int K, int gu, const int *slot_user, const int *slot_chunk, const int *user_nslots,
-                                  const int *flags, const int *test_p, const long long *grow, const T *pos_score, const T *spos_score, KeyT *thr_shared)
+__device__ __forceinline__ KeyT seed_of_slot(int slot, int stream_slot0, int K, int gu, const int *slot_user, const int *slot_chunk, const int *user_nslots,
+                                             const int *flags, const int *test_p, const long long *grow, const T *pos_score, const T *spos_score)
 {
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= n_slots) return;
     const int u = slot_user[slot];
-    if (slot_chunk[slot] != 0 || user_nslots[u] != 1 || (flags[u] & UF_ONLY_NDCG)) return;
+    if (slot_chunk[slot] != 0 || user_nslots[u] != 1 || (flags[u] & UF_ONLY_NDCG)) return (KeyT)0;
     const int te0 = test_p[u], P = test_p[u + 1] - te0;
-    if (P < K) return;
+    if (P < K) return (KeyT)0;
     const T *tab; long long stride;
     if (slot >= stream_slot0) { tab = spos_score + te0; stride = 1; }
     else { const int g = slot / gu; tab = pos_score + (grow[g] + g) * gu + (slot % gu); stride = gu; }
     int nvalid = P;                                               // positives masked by the train row sort to the top as +inf
     while (nvalid > 0) { const T x = tab[(long long)(nvalid - 1) * stride]; if (isinf(x) && x > 0) nvalid--; else break; }
-    if (nvalid < K) return;
+    if (nvalid < K) return (KeyT)0;
     // the K-th best DISTINCT score of the test row: a non-canonical CSR row may list an item twice (the reference only sorts
     // the rows, recometrics/__init__.py:478-486), and K entries are then fewer than K candidates -- entries with equal scores
     // count once, which can only lower the bound
@@ -384,8 +448,24 @@ __global__ void k_seed_thresholds(int n_slots, int stream_slot0, int K, int gu, 
         const T x = tab[(long long)(--i) * stride];
         if (x != kth && !(isinf(x) && x > 0)) { kth = x; distinct++; }
     }
-    if (distinct < K) return;
-    if (kth == kth) thr_shared[slot] = ord_key(kth);
+    if (distinct < K) return (KeyT)0;
+    return kth == kth ? (KeyT)ord_key(kth) : (KeyT)0;
+}
+// (every slot's bound is WRITTEN -- 0 = "nothing yet" where there is no seed -- so the array needs no memset in front of the kernel)
+template <class T, class KeyT>
+__global__ void k_seed_thresholds(int n_slots, int stream_slot0, int K, int gu, const int *slot_user, const int *slot_chunk, const int *user_nslots,
+                                  const int *flags, const int *test_p, const long long *grow, const T *pos_score, const T *spos_score, KeyT *thr_shared)
+{
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_slots) return;
+    thr_shared[slot] = seed_of_slot<T, KeyT>(slot, stream_slot0, K, gu, slot_user, slot_chunk, user_nslots, flags, test_p, grow, pos_score, spos_score);
+}
+
+// the tables of sorted positives start as +inf everywhere, their rank histograms as zero: one launch for both arrays
+template <class T> __global__ void k_init_tables(T *scores, unsigned *hist, long long count)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) { scores[i] = (T)__int_as_float(0x7f800000); hist[i] = 0u; }
 }
 
 // dense train rows for the sweep (SweepArgs::train_bits): one wavefront per user builds the row in LDS (coalesced reads of the

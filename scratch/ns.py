@@ -14,7 +14,9 @@ K = int(os.environ.get('NS_K', K))
 k = int(os.environ.get('NS_FACTORS', k))
 if os.environ.get('NS_DTYPE'): dtype = {'f32': np.float32, 'f64': np.float64}[os.environ['NS_DTYPE']]
 torch.cuda.set_device(0); binding.load(); binding.set_device(0)
-p = DeviceProblem(torch, torch.device("cuda", 0), m, n, k, mean_c, seed, K, dtype)
+cumulative = wl == "C3" or bool(os.environ.get("NS_CUMULATIVE"))          # C3 is quoted with K = 1..20 (cumulative)
+p = DeviceProblem(torch, torch.device("cuda", 0), m, n, k, mean_c, seed, K, dtype, cumulative=cumulative)
+p.noise = bool(os.environ.get("NS_NOISE"))
 dt, sw, pr, fi, tm = measure(torch, dist, binding, p, steps, 1, 1, None)
 tf = 2.0 * n * k * m / (sw * 1e-3) / 1e12
 peak = 157.3 if dtype == np.float32 else 78.6
