@@ -122,7 +122,7 @@ def load_traffic(workload, users):
     """HBM bytes per sweep launch from the committed PMC run (scratch/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in
     separate rocprofv3 passes, FETCH_SIZE doubled per the gfx950 correction) and the file it was read from -- a constant of
     that profile, not a counter of this run; (None, None) when no matching profile exists."""
-    for rnd in ("r4", "r3", "r2"):                            # the newest committed profile of this workload and user count
+    for rnd in ("r5", "r4", "r3", "r2"):                      # the newest committed profile of this workload and user count
         rel = os.path.join("profiles", "%s_traffic_%s.json" % (rnd, workload))
         try:
             d = json.load(open(os.path.join(ROOT, rel)))
@@ -651,6 +651,11 @@ def main():
                 "main_launch_share_of_users": sh2,
                 "hbm_equiv_GBs": n2 * k2 * 4.0 * m2 * sh2 / (sw2 * 1e-3) / 1e9,
                 "hbm_equiv_frac": n2 * k2 * 4.0 * m2 * sh2 / (sw2 * 1e-3) / 1e9 / PEAK_HBM_GBS}
+            tr_b, tr_src = load_traffic("NS", m2)
+            if tr_b:
+                td = json.load(open(os.path.join(ROOT, tr_src)))
+                line["north_star_shape"].update({"traffic": tr_b, "traffic_source": tr_src, "hbm_read_GBs": td["hbm_read_bytes"] / (sw2 * 1e-3) / 1e9,
+                                                 "hbm_read_frac_of_peak": td["hbm_read_bytes"] / (sw2 * 1e-3) / 1e9 / PEAK_HBM_GBS})
             if args.parity_users > 0:
                 line["north_star_shape"]["parity"] = parity_check(p2, p2.out, min(args.parity_users, 512), binding=binding)
                 failed = failed or not line["north_star_shape"]["parity"]["ok"]
@@ -725,6 +730,14 @@ def main():
                                  "mfma_TFLOPs": tfo, "mfma_peak_TFLOPs": pk, "mfma_frac": tfo / pk,
                                  # (three steps: one slow step -- seen once at C5, 108 ms among 86 ms ones -- moves the mean by 8 %)
                                  "sweep_ms_per_step": per_step, "mfma_frac_best_step": tfo / pk * swo / min(per_step)}
+                # HBM traffic of this config's sweep launch from its own committed PMC profile (B is larger than the 256 MiB
+                # Infinity Cache at C4 and C5: the read rate against the 8 TB/s peak, next to the MFMA fraction)
+                tr_b, tr_src = load_traffic(wname, mo)
+                if tr_b:
+                    td = json.load(open(os.path.join(ROOT, tr_src)))
+                    others[wname].update({"traffic": tr_b, "traffic_source": tr_src,
+                                          "hbm_read_GBs": td["hbm_read_bytes"] / (swo * 1e-3) / 1e9,
+                                          "hbm_read_frac_of_peak": td["hbm_read_bytes"] / (swo * 1e-3) / 1e9 / PEAK_HBM_GBS})
                 if args.parity_users > 0:
                     others[wname]["parity"] = parity_check(po, po.out, min(args.parity_users, 512), cpu_seconds=5.0, binding=binding)
                     failed = failed or not others[wname]["parity"]["ok"]

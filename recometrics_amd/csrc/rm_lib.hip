@@ -664,6 +664,8 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     auto lds_need_n = [&](bool with_lists, int ns) { return lds_need_j(with_lists, ns, jmax); };
     if (!ext_topk && P::max_nsub >= 3 && NG <= 8 && lds_need_n(true, 3) + SYNC_BYTES <= LDS_LIMIT && !g_sw.hbm_lists && !g_sw.nsub2)
         nsub = 3;
+    // (four sub-tiles -- sixteen waves, four per SIMD, 128 registers each -- were built in round 5, passed the parity tests and were
+    // 1.9 % SLOWER at BASELINE C2: profiles/r5_ab_c2.txt r5a; the patches are scratch/dropped/r5_nsub4*)
     const int tile_items = 32 * nsub, n_waves = 4 * nsub;
     const int tiles_total = (n + tile_items - 1) / tile_items;
     // LDS admits one block per CU, so the grid runs in rounds of 256 blocks, and a block costs its tiles plus a fixed part:

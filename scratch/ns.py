@@ -12,6 +12,7 @@ m, n, k, dtype, K, mean_c, seed = CONFIGS[wl]
 m = users
 K = int(os.environ.get('NS_K', K))
 k = int(os.environ.get('NS_FACTORS', k))
+n = int(os.environ.get('NS_ITEMS', n))
 if os.environ.get('NS_DTYPE'): dtype = {'f32': np.float32, 'f64': np.float64}[os.environ['NS_DTYPE']]
 torch.cuda.set_device(0); binding.load(); binding.set_device(0)
 cumulative = wl == "C3" or bool(os.environ.get("NS_CUMULATIVE"))          # C3 is quoted with K = 1..20 (cumulative)
