@@ -57,7 +57,7 @@ struct RmError { int code; std::string msg; };
 struct Switches {
     bool no_train_bits, no_spec, no_side, ext_topk, no_early_bits, no_test_mask, hbm_lists, nsub2, no_pending, no_pos_keys, no_pos_beside,
          no_seed, no_depth_split, rank_generic, no_fused_auc, no_defer_auc, noise_sequential, no_ext_bits, one_context, noise_per_batch,
-         host_trace, no_noise_beside_last;
+         host_trace, no_noise_beside_last, no_pack_beside;
     long long free_mb, stream_budget_mb, dense_always_mb, noise_budget_mb;      // -1 = not set
     double batch_users;                                                        // 0 = not set
     int ramp;                                                                  // 0 = not set
@@ -73,7 +73,7 @@ struct Switches {
         no_depth_split = on("RM_DEBUG_NO_DEPTH_SPLIT"); rank_generic = on("RM_DEBUG_RANK_GENERIC"); no_fused_auc = on("RM_DEBUG_NO_FUSED_AUC");
         no_defer_auc = on("RM_DEBUG_NO_DEFER_AUC"); noise_sequential = on("RM_DEBUG_NOISE_SEQUENTIAL"); no_ext_bits = on("RM_DEBUG_NO_EXT_BITS");
         one_context = on("RM_DEBUG_ONE_CONTEXT"); noise_per_batch = on("RM_DEBUG_NOISE_PER_BATCH"); host_trace = on("RM_HOST_TRACE");
-        no_noise_beside_last = on("RM_DEBUG_NO_NOISE_BESIDE_LAST");
+        no_noise_beside_last = on("RM_DEBUG_NO_NOISE_BESIDE_LAST"); no_pack_beside = on("RM_DEBUG_NO_PACK_BESIDE");
         free_mb = num("RM_DEBUG_FREE_MB"); stream_budget_mb = num("RM_STREAM_BUDGET_MB"); dense_always_mb = num("RM_DEBUG_DENSE_ALWAYS_MB");
         noise_budget_mb = num("RM_NOISE_BUDGET_MB");
         const char *b = getenv("RM_BATCH_USERS"); batch_users = b ? atof(b) : 0.0;
@@ -131,6 +131,7 @@ struct Ctx {
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false, ev_recorded = false;
     hipStream_t side_stream = nullptr;      // second sweep launch of a depth-split call runs beside the first
+    hipStream_t pos_stream = nullptr; hipEvent_t pos_ev[2] = {nullptr, nullptr};      // the streamed users' positives beside the table users' (run())
     hipEvent_t side_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t done = nullptr;               // end of the device work of the most recent call on this context
     hipStream_t own_stream = nullptr;        // stream of a shard worker (multi-device calls)
@@ -797,7 +798,14 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         typename P::PackT *Ap = (typename P::PackT *)ws.get("Ap", 16 * (size_t)ap_units);
         // the packed item image survives between the batches of one host call (same B, same geometry)
         const bool items_packed = items_known && cx.packed_tile == tile_items && cx.packed_ng == NG && cx.packed_ptr == (const void *)Bp;
-        pack_operands(c.A, c.lda, c.B, c.ldb, n, k, NG, tile_items, slot_user, n_slots, Ap, ap_units, Bp, bp_units, stream, !items_packed);
+        // Only the sweep reads the packed images: with a side stream they are made there, behind the dense train rows and beside the
+        // positives' kernels (120 us of BASELINE C2's preparation that sat in front of k_pos_scores); the sweep's launch waits for both.
+        const bool packs_side = use_side && want_auc && cx.side_stream != nullptr && !g_sw.no_pack_beside;
+        pack_operands(c.A, c.lda, c.B, c.ldb, n, k, NG, tile_items, slot_user, n_slots, Ap, ap_units, Bp, bp_units, packs_side ? cx.side_stream : stream, !items_packed);
+        if (packs_side) {
+            HIP_CHECK(hipEventRecord(cx.side_ev[4], cx.side_stream));   // (behind the rows, when they were launched: one event for both)
+            if (!bits_early) side_guard.pending++;
+        }
         cx.packed_tag = c.items_tag; cx.packed_tile = tile_items; cx.packed_ng = NG; cx.packed_ptr = (const void *)Bp;
 
         // ---- dense train rows (fp32, small item counts) ----
@@ -805,7 +813,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         typename P::Args sa{};
         // (rows launched beside the plan read-back that turn out not to be the ones wanted -- a wrong guess of `mask_test`, rows handed over
         // by another pass -- are waited for here, before anything is launched over them; the usual case waits in front of the sweep)
-        bool bits_wait = bits_early;
+        bool bits_wait = bits_early || packs_side;
         if (bits_early && (bits_early_masked != mask_test || (use_ext_bits && dense_ok))) {
             HIP_CHECK(hipStreamWaitEvent(stream, cx.side_ev[4], 0));
             side_guard.pending--; bits_wait = false;
@@ -831,13 +839,25 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             // The streamed users' positives (scores, then the all-pairs rank of long test rows: vector work) run on the side stream
             // beside the table users' (whose scoring is an L2 gather): two chains of two kernels each instead of four kernels in a row
             hipStream_t ps = stream;
+            struct PosGuard { hipStream_t st = nullptr; ~PosGuard() { if (st) (void)hipStreamSynchronize(st); } } pos_guard;     // (an error between fork and join)
             const bool pos_beside = use_side && n_stream > 0 && stream_slot0 > 0 && !g_sw.no_pos_beside;
             if (n_stream > 0) {
                 const size_t nz = (size_t)std::max<long long>(c.nnz_test, 1);
                 spos_score = (T *)ws.get("spos_score", sizeof(T) * nz);
                 spos_item = (int *)ws.get("spos_item", sizeof(int) * nz);
                 shist = (unsigned *)ws.get("shist", sizeof(unsigned) * nz);
-                if (pos_beside) ps = fork_side();
+                if (pos_beside) {
+                    // (a stream of their own, not the side stream: that one carries the dense train rows and the operand packing, 0.3 ms the
+                    // streamed users' chain used to queue behind)
+                    if (!cx.pos_stream) {
+                        HIP_CHECK(create_stream(&cx.pos_stream, cx.high_priority));
+                        for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&cx.pos_ev[i], hipEventDisableTiming));
+                    }
+                    ps = cx.pos_stream;
+                    HIP_CHECK(hipEventRecord(cx.pos_ev[0], stream));
+                    HIP_CHECK(hipStreamWaitEvent(ps, cx.pos_ev[0], 0));
+                    pos_guard.st = ps;
+                }
                 // (+inf in every rank: entries that repeat an item -- a non-canonical CSR row -- share a rank and leave one unused)
                 hipLaunchKernelGGL(k_init_tables<T>, dim3(cdiv((long long)nz, 256)), dim3(256), 0, ps, spos_score, shist, (long long)nz);
                 PosArgs<T> pb = pa;
@@ -850,7 +870,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
                 hipLaunchKernelGGL(k_pos_scores<T>, dim3(cdiv(stream_slot0, POSS_WAVES)), dim3(POSS_WAVES * WAVE), 0, stream, pa, slot_user, slot_chunk, stream_slot0);
                 hipLaunchKernelGGL(k_pos_place<T>, dim3(cdiv((long long)stream_slot0 * WAVE, 256)), dim3(256), 0, stream, pa, slot_user, slot_chunk, stream_slot0);
             }
-            if (pos_beside) { join_side(); topv_pending = false; }       // (the join also covers k_top_values, launched there earlier)
+            if (pos_beside) { HIP_CHECK(hipEventRecord(cx.pos_ev[1], ps)); HIP_CHECK(hipStreamWaitEvent(stream, cx.pos_ev[1], 0)); pos_guard.st = nullptr; }
         }
 
         if (n_stream > 0) stream_scores = (T *)ws.get("stream_scores", sizeof(T) * (size_t)n_stream * (size_t)stream_ld);
