@@ -483,6 +483,25 @@ def main():
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(args)
+    # The host-pointer legs (`e2e_host`, `api_default`, the tutorial's API call) run FIRST, each in a torch-free child process, while
+    # THIS process has not touched the GPU yet: with the parent's HIP context alive beside it (torch's streams and queues, idle but
+    # mapped) the same child measured 0.5-0.8 ms more per call than alone (profiles/r5_host_entry.txt against the round's first bench
+    # lines) -- two processes' hardware queues are time-sliced.  A wrapper's process is alone on its GPU; so is the child here.
+    early = {}
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and not args.no_e2e:
+        from recometrics_amd.synth import CONFIGS as _CFG
+        m0 = _CFG[args.workload][0] // (8 if args.workload == "C3" else 1)
+        if args.users:
+            m0 = args.users
+        try:
+            early["main"] = run_child(args, m0, ["--e2e-child"])
+        except Exception as e:      # noqa: BLE001
+            early["main"] = {"error": repr(e)}
+        if not args.no_extra and args.workload != "TUT":
+            try:
+                early["TUT"] = run_child(args, _CFG["TUT"][0], ["--e2e-child"], workload="TUT")
+            except Exception as e:      # noqa: BLE001
+                early["TUT"] = {"error": repr(e)}
     import torch
     import torch.distributed as dist
     from recometrics_amd import _binding as binding
@@ -600,12 +619,9 @@ def main():
                 line["parity_vs_default_build"] = {"ok": False, "what": repr(e)}
                 failed = True
     if rank == 0 and world == 1 and not args.no_e2e:
-        try:
-            child = run_child(args, m, ["--e2e-child"])
-            line["e2e_host"] = child.get("e2e_host", child)
-            line["api_default"] = child.get("api_default", {"error": "no result"})
-        except Exception as e:      # noqa: BLE001
-            line["e2e_host"] = {"error": repr(e)}
+        child = early.get("main", {"error": "not run"})
+        line["e2e_host"] = child.get("e2e_host", child)
+        line["api_default"] = child.get("api_default", {"error": "no result"})
 
     if rank == 0 and world == 1 and not args.no_extra:
         # the API's default, break_ties_with_noise=True (exact mt19937 noise: a second pass over the users it can touch);
@@ -694,7 +710,7 @@ def main():
             binding.load().rm_release_workspace()
             torch.cuda.empty_cache()
             if not args.no_e2e:
-                child = run_child(args, mt, ["--e2e-child"], workload="TUT")
+                child = early.get("TUT", {})
                 api = child.get("api_default", {})
                 line["tutorial"]["api_ms"] = api.get("ms")
                 line["tutorial"]["api_users_per_s"] = api.get("users_per_s")

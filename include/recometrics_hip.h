@@ -14,7 +14,14 @@
  * Ownership (same as the reference, src/recometrics.hpp:193-358): the caller owns every buffer; outputs are
  * pre-allocated by the binding ([m] or row-major [m x k_metrics] when `cumulative`); a NULL output pointer means
  * "metric not requested"; inputs are never modified; users that cannot be evaluated get NaN in every requested
- * output, so outputs need no initialisation.  CSR is 0-based int32 with sorted, unique indices inside a row.
+ * output, so outputs need no initialisation.  CSR is 0-based int32.  The reference's callers sort the column indices of every row
+ * first (recometrics/__init__.py:35-41, R/recometrics.R) and nobody checks them; here the arrays are VALIDATED on the device
+ * before anything indexes by them: index pointers that are negative, decreasing or beyond the index array, and column indices
+ * outside [0, n), are RM_ERR_INVALID with a message that names the row (on the CPU: a segfault); rows that are merely unsorted
+ * are sorted by the library -- a copy, the caller's arrays are const -- and give the outputs of the sorted matrix (rm_rank_*
+ * excepted: its pos_rank is indexed by the caller's entry order, unsorted rows are RM_ERR_INVALID there).  An item listed twice
+ * in a row is tolerated as the reference tolerates it.
+ * On a status other than RM_OK the contents of the output arrays are undefined, with one exception: RM_ERR_INTERRUPTED (below).
  * `nthreads` is accepted for signature compatibility (the device path has no host thread pool).  `seed` is USED:
  * with `break_ties_with_noise` the reference's tie-breaking noise -- std::mt19937(seed + user) through libstdc++'s
  * uniform_real_distribution, reference :528-534 -- is reproduced bit for bit (rm_noise.hpp; DESIGN.md, "tie noise"),
@@ -43,7 +50,9 @@ extern "C" {
 #define RM_ERR_UNSUPPORTED 4 /* shape outside what the kernels are built for (message says which) */
 #define RM_ERR_INTERRUPTED 5 /* SIGINT (or rm_request_interrupt) during a host-pointer call: "Error: procedure was interrupted."
                               * -- the std::runtime_error of src/recometrics.hpp:171.  Users of finished batches have their
-                              * results; the rest of the output arrays is untouched, as in the reference (:488-489) */
+                              * results; the rest of the output arrays is untouched, as in the reference (:488-489).  With
+                              * break_ties_with_noise in fp32, users of finished batches whose exact (noise) evaluation had not
+                              * run yet are set to NaN rather than left with their un-noised first-pass values */
 
 /* replaces calc_metrics_float  (src/recometrics_signatures.hpp:74-98).  ALL pointers are HOST pointers. */
 int rm_calc_metrics_f32(
