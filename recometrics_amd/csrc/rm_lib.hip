@@ -277,7 +277,7 @@ template <> struct Prec<float> {
     static constexpr int GU = GROUP_USERS;               // users per group
     typedef float4 PackT;  typedef u32x2 ListT;  typedef SweepArgs Args;
     // factor groups of 8: the instantiated counts up to 512 factors, beyond that whole 128-factor chunks (run-time count)
-    static int supported_ng(int k) { const int ng = (k + 7) / 8; for (int o : {2, 4, 8, 16, 32, 64}) if (ng <= o) return o; return (ng + 15) / 16 * 16; }
+    static int supported_ng(int k) { const int ng = (k + 7) / 8; for (int o : {2, 3, 4, 5, 6, 7, 8, 10, 12, 13, 16, 32, 64}) if (ng <= o) return o; return (ng + 15) / 16 * 16; }
     static const char *limit() { return "unsupported factor count"; }
     static size_t lds_b(int NG, int tile = TILE_ITEMS) { return 2ull * std::min(NG, 16) * 2 * tile * 16; }
     static long long items_units(int tiles, int NG, int tile = TILE_ITEMS) { return (long long)tiles * NG * 2 * tile; }

@@ -511,7 +511,7 @@ void k_sweep(SweepArgs a)
     // ---- MFMA: 32 items (registers) x 32 users (lanes), k in index order ----
     // EARLY ARRIVAL (kernels with resident user factors: one unit per tile): see do_mfma
 #if !defined(RM_FULL_BARRIER) && !defined(RM_ABL_NO_BARRIER)
-    constexpr bool EARLY_ARRIVE = AF_RESIDENT && NG >= 4;
+    constexpr bool EARLY_ARRIVE = AF_RESIDENT && NG >= 4 && NG % 2 == 0;      // (an odd group count arrives behind its last matrix instruction)
 #else
     constexpr bool EARLY_ARRIVE = false;
 #endif

@@ -16,6 +16,11 @@ import pytest
 from _util import assert_same_bits
 
 pytestmark = pytest.mark.gpu
+
+
+def _same(x, y):
+    from _util import same_bits
+    return same_bits(x, y)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ALL = {name: True for name in ("p", "tp", "r", "ap", "tap", "ndcg", "hit", "rr", "roc", "pr")}
 
@@ -28,11 +33,11 @@ def hip():
     return _binding
 
 
-def _calc(hip, pr, K, cumulative=False, dtype=np.float32, outs=None):
+def _calc(hip, pr, K, cumulative=False, dtype=np.float32, outs=None, noise=False):
     trp, tri = pr["train"]
     tep, tei, tev = pr["test"]
     return hip.calc_metrics(np.ascontiguousarray(pr["A"], dtype), pr["A"].shape[1], np.ascontiguousarray(pr["B"], dtype), pr["B"].shape[1],
-                            trp, tri, tep, tei, tev.astype(dtype), K, ALL, cumulative, False, True, 2, 1, 1, 1, outs=outs)
+                            trp, tri, tep, tei, tev.astype(dtype), K, ALL, cumulative, noise, True, 2, 1, 1, 1, outs=outs)
 
 
 @pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], [0]])
@@ -116,6 +121,43 @@ def test_interrupt_between_batches(hip, monkeypatch):
     again = _calc(hip, pr, 10)
     for name, g, w in zip(hip.METRIC_ORDER, again, full):
         assert_same_bits(g, w, name + " after an interrupted call")
+
+
+def test_interrupt_with_tie_noise_never_leaves_un_noised_values(hip, monkeypatch):
+    """fp32 + break_ties_with_noise over user batches: every batch first evaluates on the plain scores and flags the users the noise
+    can touch; their exact evaluation follows the last batch.  A call interrupted in between must not hand out the first pass's
+    values of flagged users as results: every user of a finished batch either carries its final (noise-on) value, bit for bit, or
+    NaN; users behind the interrupt are untouched.  (Cold items -- zero factors -- put many test scores into the noise zone.)"""
+    pr = _interruptible_problem()
+    pr = dict(pr, B=pr["B"].copy())
+    pr["B"][::5] = 0                                         # every fifth item scores exactly 0 for everybody
+    m = pr["A"].shape[0]
+    full = _calc(hip, pr, 10, noise=True)
+    plain = _calc(hip, pr, 10, noise=False)
+    changed = np.zeros(m, bool)
+    for g, w in zip(plain, full):
+        changed |= ~(_same(g, w))
+    assert changed.sum() > 100, "the problem must have users whose metrics the noise changes (%d)" % changed.sum()
+    monkeypatch.setenv("RM_BATCH_USERS", "1024")
+    outs = [np.full(m, -7.0, np.float32) for _ in range(10)]
+    t = threading.Timer(0.03, hip.request_interrupt)
+    t.start()
+    with pytest.raises(RuntimeError, match="procedure was interrupted"):
+        _calc(hip, pr, 10, outs=outs, noise=True)
+    t.join()
+    touched = np.zeros(m, bool)
+    for g in outs:
+        touched |= ~(g == -7.0)
+    done = int(touched.nonzero()[0].max()) + 1 if touched.any() else 0
+    assert 1024 <= done < m, "finished users: %d of %d" % (done, m)
+    for name, g, w in zip(hip.METRIC_ORDER, outs, full):
+        ok = _same(g[:done], w[:done]) | np.isnan(g[:done])
+        assert ok.all(), "%s: %d finished users carry neither their final value nor NaN" % (name, (~ok).sum())
+        assert (g[done:] == -7.0).all(), name + ": users after the interrupt must be untouched"
+    # a user whose first-pass value differs from its final one must be NaN (its exact evaluation never ran)
+    for name, g, w, pl in zip(hip.METRIC_ORDER, outs, full, plain):
+        differs = ~_same(pl[:done], w[:done])
+        assert (np.isnan(g[:done][differs]) | _same(g[:done][differs], w[:done][differs])).all(), name
 
 
 def test_sigint_during_a_call_becomes_keyboard_interrupt(hip, monkeypatch):

@@ -41,7 +41,7 @@ def hip_calc(hip, A, B, train, test, k, metrics=("p", "tp", "r", "ap", "tap", "n
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("k", [1, 8, 24, 50, 64, 100, 128, 129, 200, 256, 300, 512, 520, 1000, 1024, 1500])
+@pytest.mark.parametrize("k", [1, 8, 24, 33, 41, 50, 64, 80, 96, 100, 128, 129, 200, 256, 300, 512, 520, 1000, 1024, 1500])
 def test_mfma_scores_are_the_k_ordered_fma_chain(hip, oracle, k):
     """The sweep's v_mfma_f32_32x32x2_f32 contraction == strict index-order fmaf chain (reference dot1), bit for bit."""
     rng = np.random.default_rng(k)
@@ -228,6 +228,22 @@ def test_random_problem_vs_oracle_f64(hip, oracle, m, n, k, K, mean_c):
     from recometrics_amd.synth import make_problem
     pr = make_problem(m, n, k, np.float64, mean_c=mean_c, seed=m + n + 1)
     _check_against_oracle(hip, oracle, pr, K, dtype=np.float64)
+
+
+@pytest.mark.parametrize("k", [17, 24, 33, 40, 48, 50, 56, 72, 80, 96, 100, 104])
+@pytest.mark.parametrize("env", [{}, {"RM_DEBUG_HBM_LISTS": "1"}, {"RM_DEBUG_NSUB2": "1"}])
+def test_every_factor_group_count_has_its_kernel(hip, oracle, k, env, monkeypatch):
+    """factor counts between the powers of two run on kernels of their own group count -- 3, 5, 6, 7 groups of 8 factors up to 64
+    factors (three or two sub-tiles, LDS or HBM lists), 10, 12, 13 up to 128 -- instead of being padded to the next power of two
+    (50 factors, the reference notebook's model: 56, not 64; 100: 104, not 128): the whole pipeline against the oracle, K = 10 and
+    K = 40 (append-buffer lists)"""
+    from recometrics_amd.synth import make_problem
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    pr = make_problem(300, 5000 + k, k, np.float32, mean_c=50, seed=1000 + k)
+    _check_against_oracle(hip, oracle, pr, 10)
+    if not env:
+        _check_against_oracle(hip, oracle, pr, 40)
 
 
 @pytest.mark.parametrize("env", [{"RM_DEBUG_NO_PENDING": "1"}, {"RM_DEBUG_HBM_LISTS": "1"}, {"RM_DEBUG_EXT_TOPK": "1"},
