@@ -295,7 +295,7 @@ template <> struct Prec<float> {
 template <> struct Prec<double> {
     static constexpr int GU = GROUP_USERS64;
     typedef double2 PackT;  typedef u32x4 ListT;  typedef Sweep64Args Args;
-    static int supported_ng(int k) { const int ng = (k + 7) / 8; for (int o : {2, 4, 8, 16, 32, 64}) if (ng <= o) return o; return (ng + 7) / 8 * 8; }
+    static int supported_ng(int k) { const int ng = (k + 7) / 8; for (int o : {2, 3, 4, 5, 6, 7, 8, 16, 32, 64}) if (ng <= o) return o; return (ng + 7) / 8 * 8; }
     static const char *limit() { return "unsupported factor count"; }
     static size_t lds_b(int NG, int = TILE_ITEMS) { return 2ull * std::min(NG, 8) * 4 * TILE_ITEMS * 16; }
     static long long items_units(int tiles, int NG, int = TILE_ITEMS) { return (long long)tiles * NG * 4 * TILE_ITEMS; }

@@ -244,6 +244,9 @@ def test_every_factor_group_count_has_its_kernel(hip, oracle, k, env, monkeypatc
     _check_against_oracle(hip, oracle, pr, 10)
     if not env:
         _check_against_oracle(hip, oracle, pr, 40)
+    if k <= 64 and k % 16 and not env.get("RM_DEBUG_NSUB2"):         # fp64 has the group counts up to 8 as well
+        pr64 = make_problem(200, 4000 + k, k, np.float64, mean_c=50, seed=2000 + k)
+        _check_against_oracle(hip, oracle, pr64, 10 if not env else 40, dtype=np.float64)
 
 
 @pytest.mark.parametrize("env", [{"RM_DEBUG_NO_PENDING": "1"}, {"RM_DEBUG_HBM_LISTS": "1"}, {"RM_DEBUG_EXT_TOPK": "1"},
