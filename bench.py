@@ -389,8 +389,11 @@ def cpu_baseline(host, K, n_users_total, budget_s, dtype=np.float32):
     # the reference addresses its per-thread scratch as `buffer + omp_get_thread_num() * n` in int32
     # (src/recometrics.hpp:499): more than (2^31 - 1) / n threads overflow it (214 at n = 10M)
     ncores = max(1, min(ncores, (2 ** 31 - 1) // int(host["B"].shape[0])))
-    if orc.reference_available(fast=True):
-        impl, kind = orc.Reference(fast=True), "reference"
+    march = None
+    if orc.reference_available(v4=True) and orc.host_has_avx512():
+        impl, kind, march = orc.Reference(v4=True), "reference", "x86-64-v4 (AVX-512: what the reference's default -march=native gives on this host)"
+    elif orc.reference_available(fast=True):
+        impl, kind, march = orc.Reference(fast=True), "reference", "x86-64-v3 (its default user build is -march=native)"
     else:
         impl, kind = orc.Oracle(), "port"
     A, B = host["A"], host["B"]
@@ -414,7 +417,7 @@ def cpu_baseline(host, K, n_users_total, budget_s, dtype=np.float32):
     if t < 0.6 * budget_s and nu < n_users_total:          # the small probe overestimates the per-user cost (thread start-up): once more
         nu = int(min(n_users_total, nu * budget_s / max(t, 1e-6)))
         t = run(nu)
-    how = "the reference built by oracle/Makefile with -march=x86-64-v3 (its default user build is -march=native)" if kind == "reference" else "oracle/ restatement"
+    how = ("the reference built by oracle/Makefile with -march=" + march) if kind == "reference" else "oracle/ restatement"
     return {"value": nu / t, "unit": "users/s", "cores": ncores, "kind": kind,
             "sample": "%d of %d users of the same workload, all metrics, K=%d, %d threads, %.1f s; %s" % (nu, n_users_total, K, ncores, t, how)}
 

@@ -145,8 +145,8 @@ class Oracle(_Lib):
 class Reference(_Lib):
     """The real reference (C++-linkage symbols called through their mangled names)."""
 
-    def __init__(self, fast=False):
-        name = "librecometrics_ref_fast.so" if fast else "librecometrics_ref.so"
+    def __init__(self, fast=False, v4=False):
+        name = "librecometrics_ref_v4.so" if v4 else ("librecometrics_ref_fast.so" if fast else "librecometrics_ref.so")
         path = os.path.join(_HERE, "_ref", name)
         if not os.path.exists(path) and os.path.exists("/root/reference/src/recometrics.hpp"):
             build()
@@ -159,6 +159,19 @@ class Reference(_Lib):
                           min_items_pool, min_pos_test, nthreads, seed, dtype)
 
 
-def reference_available(fast=False):
-    name = "librecometrics_ref_fast.so" if fast else "librecometrics_ref.so"
+def reference_available(fast=False, v4=False):
+    name = "librecometrics_ref_v4.so" if v4 else ("librecometrics_ref_fast.so" if fast else "librecometrics_ref.so")
     return os.path.exists(os.path.join(_HERE, "_ref", name))
+
+
+def host_has_avx512():
+    """the x86-64-v4 build needs AVX-512 F / BW / CD / DQ / VL: only run it on a host whose CPU lists them"""
+    try:
+        flags = set()
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                flags = set(line.split(":", 1)[1].split())
+                break
+        return {"avx512f", "avx512bw", "avx512cd", "avx512dq", "avx512vl"} <= flags
+    except OSError:
+        return False
