@@ -294,20 +294,22 @@ def api_default_measure(host, k, K, dtype, reps=5):
     def fresh():
         return (sp.csr_array((ones, tri, trp), shape=(m, n), copy=False), sp.csr_array((tev, tei, tep), shape=(m, n), copy=False))
 
-    def call(mats):
+    def call(mats, as_df=False):
         t0 = time.perf_counter()
-        out = recometrics_amd.calc_reco_metrics(mats[0], mats[1], host["A"], host["B"], k=K, all_metrics=True, as_df=False)
+        out = recometrics_amd.calc_reco_metrics(mats[0], mats[1], host["A"], host["B"], k=K, all_metrics=True, as_df=as_df)
         return (time.perf_counter() - t0) * 1e3, out
     first, _ = call(fresh())
     times = sorted(call(fresh())[0] for _ in range(reps))
     mats = fresh()
     call(mats)
     same = sorted(call(mats)[0] for _ in range(reps))          # the same objects again: SciPy's flag is set, no check at all
+    call(fresh(), True)
+    frame = sorted(call(fresh(), True)[0] for _ in range(reps))  # the literal default: as_df=True (a pandas DataFrame over the outputs' own storage)
     t0 = time.perf_counter()
     xs = fresh()
     xs[0].sort_indices(); xs[1].sort_indices()
     scipy_ms = (time.perf_counter() - t0) * 1e3
-    return {"first_call_ms": first, "ms": times[len(times) // 2], "same_objects_ms": same[len(same) // 2],
+    return {"first_call_ms": first, "ms": times[len(times) // 2], "same_objects_ms": same[len(same) // 2], "as_df_ms": frame[len(frame) // 2],
             "users_per_s": m / (times[len(times) // 2] * 1e-3), "scipy_sort_indices_ms": scipy_ms,
             "what": "recometrics_amd.calc_reco_metrics(X_train, X_test, A, B, k=%d, all_metrics=True, as_df=False): noise on, SciPy CSR in, "
                     "fresh matrix objects per call (sortedness unknown to SciPy), torch-free process; `scipy_sort_indices_ms` = what "

@@ -252,11 +252,27 @@ def calc_reco_metrics(
     B, ldb = _row_major_with_ld(B.astype(dtype, copy=False))
     c = np.ascontiguousarray
 
+    want = {short: requested[name] for name, short, _ in _METRICS}
+    outs = block = None
+    if as_df and not cumulative:
+        # the DataFrame's storage is allocated up front: one column-major [users, metrics] block whose columns ARE the output
+        # arrays of the call -- pandas wraps it without a copy (building the frame from ten separate arrays consolidates them into
+        # such a block: 0.9 ms for BASELINE C2's 138k users, 8 % of the call)
+        keys = [key for (name, _, key) in _METRICS if requested[name]]
+        block = np.empty((n_users, len(keys)), dtype=dtype, order="F")
+        cols = iter(range(len(keys)))
+        outs = [block[:, next(cols)] if requested[name] else np.empty(0, dtype=dtype) for name, _, _ in _METRICS]
+
     arrays = _binding.calc_metrics(
         A, lda, B, ldb, c(X_train.indptr), c(X_train.indices), c(X_test.indptr), c(X_test.indices), c(test_values),
-        k, {short: requested[name] for name, short, _ in _METRICS}, bool(cumulative), bool(break_ties_with_noise),
-        bool(consider_cold_start), min_items_pool, min_pos_test, nthreads, seed)
+        k, want, bool(cumulative), bool(break_ties_with_noise),
+        bool(consider_cold_start), min_items_pool, min_pos_test, nthreads, seed, outs=outs)
 
+    if block is not None:
+        import pandas as pd
+        if rename_k:
+            keys = [key[:-1] + str(k) if key.endswith("@K") else key for key in keys]
+        return pd.DataFrame(block, columns=keys, copy=False)
     out = {key: arr for (_, _, key), arr in zip(_METRICS, arrays) if arr.shape[0]}
     if not as_df:
         out["K"] = k
