@@ -57,7 +57,7 @@ struct RmError { int code; std::string msg; };
 struct Switches {
     bool no_train_bits, no_spec, no_side, ext_topk, no_early_bits, no_test_mask, hbm_lists, nsub2, no_pending, no_pos_keys, no_pos_beside,
          no_seed, no_depth_split, rank_generic, no_fused_auc, no_defer_auc, noise_sequential, no_ext_bits, one_context, noise_per_batch,
-         host_trace, no_noise_beside_last, no_pack_beside;
+         host_trace, no_noise_beside_last, no_pack_beside, no_pos_flat;
     long long free_mb, stream_budget_mb, dense_always_mb, noise_budget_mb;      // -1 = not set
     double batch_users;                                                        // 0 = not set
     int ramp;                                                                  // 0 = not set
@@ -74,6 +74,7 @@ struct Switches {
         no_defer_auc = on("RM_DEBUG_NO_DEFER_AUC"); noise_sequential = on("RM_DEBUG_NOISE_SEQUENTIAL"); no_ext_bits = on("RM_DEBUG_NO_EXT_BITS");
         one_context = on("RM_DEBUG_ONE_CONTEXT"); noise_per_batch = on("RM_DEBUG_NOISE_PER_BATCH"); host_trace = on("RM_HOST_TRACE");
         no_noise_beside_last = on("RM_DEBUG_NO_NOISE_BESIDE_LAST"); no_pack_beside = on("RM_DEBUG_NO_PACK_BESIDE");
+        no_pos_flat = on("RM_DEBUG_NO_POS_FLAT");
         free_mb = num("RM_DEBUG_FREE_MB"); stream_budget_mb = num("RM_STREAM_BUDGET_MB"); dense_always_mb = num("RM_DEBUG_DENSE_ALWAYS_MB");
         noise_budget_mb = num("RM_NOISE_BUDGET_MB");
         const char *b = getenv("RM_BATCH_USERS"); batch_users = b ? atof(b) : 0.0;
@@ -131,8 +132,8 @@ struct Ctx {
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false, ev_recorded = false;
     hipStream_t side_stream = nullptr;      // second sweep launch of a depth-split call runs beside the first
-    hipStream_t pos_stream = nullptr; hipEvent_t pos_ev[2] = {nullptr, nullptr};      // the streamed users' positives beside the table users' (run())
-    hipEvent_t side_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t pos_stream = nullptr; hipEvent_t pos_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // the streamed users' positives beside the table users' (run())
+    hipEvent_t side_ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t done = nullptr;               // end of the device work of the most recent call on this context
     hipStream_t own_stream = nullptr;        // stream of a shard worker (multi-device calls)
     hipStream_t up_stream = nullptr;         // host-pointer calls: uploads of the NEXT user batch run beside the current batch's kernels
@@ -399,10 +400,8 @@ template <class C> inline void set_train_bits(SweepArgs &sa, Ctx &cx, const C &c
     const bool ready = (early && early_masked == mask_test) ||
                        (c.same_train_rows && !cx.bits_partial && cx.bits_ptr == (const void *)bits && cx.bits_words == words && cx.bits_m == m && cx.bits_masked == mask_test);
     if (!ready) {
-        const unsigned blocks = (unsigned)std::min<long long>(((long long)m + TRAIN_BITS_WAVES - 1) / TRAIN_BITS_WAVES, 256 * 8);
-        hipLaunchKernelGGL(k_train_bits, dim3(blocks), dim3(TRAIN_BITS_WAVES * WAVE), sizeof(unsigned) * (size_t)TRAIN_BITS_WAVES * (size_t)words, stream,
-                           m, n, (int)words, c.train_p, c.train_i, mask_test ? c.test_p : nullptr, c.test_i, bits,
-                           (const Plan *)ws.get("plan", sizeof(Plan)), c.only_users);
+        launch_train_bits(stream, m, n, (int)words, c.train_p, c.train_i, mask_test ? c.test_p : nullptr, c.test_i, bits,
+                          (const Plan *)ws.get("plan", sizeof(Plan)), c.only_users);
         cx.bits_partial = c.only_users != nullptr;
     }
     cx.bits_ptr = (const void *)bits; cx.bits_words = words; cx.bits_m = m; cx.bits_masked = mask_test;
@@ -502,7 +501,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     auto side_stream = [&]() -> hipStream_t {
         if (!cx.side_stream) {
             HIP_CHECK(create_stream(&cx.side_stream, cx.high_priority));
-            for (int i = 0; i < 6; i++) HIP_CHECK(hipEventCreateWithFlags(&cx.side_ev[i], hipEventDisableTiming));
+            for (int i = 0; i < 7; i++) HIP_CHECK(hipEventCreateWithFlags(&cx.side_ev[i], hipEventDisableTiming));
         }
         return cx.side_stream;
     };
@@ -580,10 +579,39 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     // carries the first pass's answer; rows handed over by another pass are proof that they fit)
     const bool dense_ok = std::is_same<T, float>::value && (c.ext_bits ? true : c.dense_fit >= 0 ? c.dense_fit != 0 : dense_rows_fit(ws, m, n));
     bool bits_early = false, bits_early_masked = false;
+    // the positives' stream: the streamed users' chain beside the table users', and what is made per test entry beside the plan chain
+    struct PosGuard { hipStream_t st = nullptr; ~PosGuard() { if (st) (void)hipStreamSynchronize(st); } } pos_guard;     // (an error between fork and join)
+    auto pos_stream = [&]() {
+        if (!cx.pos_stream) {
+            HIP_CHECK(create_stream(&cx.pos_stream, cx.high_priority));
+            for (int i = 0; i < 5; i++) HIP_CHECK(hipEventCreateWithFlags(&cx.pos_ev[i], hipEventDisableTiming));
+        }
+        return cx.pos_stream;
+    };
+    const bool flat_early = want_auc && !c.only_users && c.nnz_test > 0 && !g_sw.no_pos_flat;
+    int *ent_user = nullptr; unsigned char *ent_masked = nullptr;
+    PosArgs<T> pf{};
+    if (flat_early) {
+        ent_user = (int *)ws.get("ent_user", sizeof(int) * (size_t)c.nnz_test);
+        ent_masked = (unsigned char *)ws.get("ent_masked", (size_t)c.nnz_test);
+        pf.m = m; pf.n = n; pf.k = k; pf.A = c.A; pf.lda = c.lda; pf.B = c.B; pf.ldb = c.ldb;
+        pf.train_p = c.train_p; pf.train_i = c.train_i; pf.test_p = c.test_p; pf.test_i = c.test_i; pf.flags = flags;
+        pf.pos_tmp = (T *)ws.get("pos_tmp", sizeof(T) * (size_t)c.nnz_test);
+        if (sizeof(T) == 4 && !g_sw.no_pos_keys) pf.pos_key = (unsigned long long *)ws.get("pos_key", 8 * ((size_t)c.nnz_test + 8));
+        pf.noise_row = c.noise_row; pf.noise_row0 = c.noise_row0; pf.noise_E = c.noise_E; pf.noise_ld = c.noise_ld;
+        pf.noise_flag = c.noise_flag; pf.plan = plan;
+    }
     Plan hp;
     for (int attempt = 0; ; attempt++) {
         // ---- the plan chain: five launches that depend on one another, on the call's stream (index pointers only) ----
-        HIP_CHECK(hipMemsetAsync(plan, 0, sizeof(Plan), stream));
+        if (attempt == 0) HIP_CHECK(hipMemsetAsync(plan, 0, sizeof(Plan), stream));
+        else {
+            // (a second plan keeps the count of the users the tie noise's first pass has flagged so far: the positives' scores of the
+            // first attempt, which count them, are not made again)
+            const size_t at = offsetof(Plan, n_noise_flagged);
+            HIP_CHECK(hipMemsetAsync(plan, 0, at, stream));
+            HIP_CHECK(hipMemsetAsync((char *)plan + at + sizeof(int), 0, sizeof(Plan) - at - sizeof(int), stream));
+        }
         hipLaunchKernelGGL(k_classify, dim3(cdiv(m, 1024)), dim3(1024), 0, stream, ca);
         // ---- beside it, on the side stream: everything that reads the index arrays and the factors ----
         // the CSR rows' validation (gated on the index pointers k_classify has just checked), max |A| and max |B|, and the dense
@@ -593,6 +621,25 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         // answer, and a wrong guess costs one more launch of the kernel behind it.
         hipStream_t aux = use_side ? fork_side() : stream;
         if (!c.csr_checked) launch_csr_index_checks(m, n, c.train_p, c.train_i, c.nnz_train, c.test_p, c.test_i, c.nnz_test, plan, aux);
+        if (attempt == 0 && flat_early) {
+            // The scores of the test entries (k_pos_scores_flat) and what they need to know about every entry -- its user, and whether
+            // the train row holds the item -- depend on the inputs and on the users' flags alone: they run on the positives' stream
+            // beside the plan chain, the read-back and the host's work behind it.  The scores index the item factors by the test
+            // items: they wait for the index checks (and return when those found a defect).
+            hipStream_t es = stream;
+            if (use_side) {
+                es = pos_stream();
+                HIP_CHECK(hipEventRecord(cx.pos_ev[0], stream));
+                HIP_CHECK(hipStreamWaitEvent(es, cx.pos_ev[0], 0));
+                pos_guard.st = es;
+                HIP_CHECK(hipEventRecord(cx.side_ev[6], aux));
+            }
+            hipLaunchKernelGGL(k_entry_users, dim3(cdiv(cdiv(m, WAVE) * WAVE, 256)), dim3(256), 0, es, m, c.test_p, ent_user, plan);
+            hipLaunchKernelGGL(k_test_masked, dim3(cdiv(m, TM_USERS)), dim3(256), 0, es, m, c.test_p, c.test_i, c.train_p, c.train_i, ent_user, ent_masked, plan);
+            if (use_side) HIP_CHECK(hipStreamWaitEvent(es, cx.side_ev[6], 0));
+            hipLaunchKernelGGL(k_pos_scores_flat<T>, dim3(cdiv(c.nnz_test, POSF_WAVES * WAVE)), dim3(POSF_WAVES * WAVE), 0, es, pf, ent_user, ent_masked);
+            if (use_side) HIP_CHECK(hipEventRecord(cx.pos_ev[1], es));
+        }
         hipLaunchKernelGGL(k_absmax<T>, dim3(512), dim3(256), 0, aux, c.A, c.lda, (long long)m, k, &plan->amax_a, &plan->nonfinite);
         if (!items_known) hipLaunchKernelGGL(k_absmax<T>, dim3(1024), dim3(256), 0, aux, c.B, c.ldb, (long long)n, k, &plan->amax_b, &plan->nonfinite_b);
         if (use_side) HIP_CHECK(hipEventRecord(cx.side_ev[2], aux));                  // the plan read-back waits for this much of the side stream
@@ -608,8 +655,8 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         hipLaunchKernelGGL(k_block_tables, dim3(1), dim3(1024), 0, stream, plan, slot_j, gj, grow, GU);
         if (use_side) HIP_CHECK(hipStreamWaitEvent(stream, cx.side_ev[2], 0));
         HIP_CHECK(hipMemcpyAsync(cx.pinned_plan, plan, sizeof(Plan), hipMemcpyDeviceToHost, stream));
-        // (the dense train rows are 463 MB of writes at BASELINE C2: launched BEHIND the read-back's copy -- in front of it they
-        // kept the copy, and with it the host, waiting for 0.1 ms)
+        // (the dense train rows are 463 MB of writes at BASELINE C2: launched BEHIND the read-back's copy -- in front of it the plan's
+        // kernels and the copy wait for wave slots: blocks of 1,024 threads beside a device full of resident waves, +0.15 ms)
         if (use_side) { HIP_CHECK(hipEventRecord(cx.side_ev[5], stream)); HIP_CHECK(hipStreamWaitEvent(aux, cx.side_ev[5], 0)); }
         if (attempt == 0 && std::is_same<T, float>::value && use_side && !c.ext_bits && dense_ok && !g_sw.no_early_bits) {
             SweepArgs probe{};
@@ -829,48 +876,47 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             hist = (unsigned *)ws.get("hist", sizeof(unsigned) * (size_t)(rows + 1) * GU);
             T *pos_tmp = (T *)ws.get("pos_tmp", sizeof(T) * (size_t)std::max<long long>(c.nnz_test, 1));
             pos_order = (int *)ws.get("pos_order", sizeof(int) * (size_t)std::max<long long>(c.nnz_test, 1));
-            hipLaunchKernelGGL(k_init_tables<T>, dim3(cdiv(rows * GU, 256)), dim3(256), 0, stream, pos_score, hist, rows * GU);
             PosArgs<T> pa{m, n, k, c.A, c.lda, c.B, c.ldb, c.train_p, c.train_i, c.test_p, c.test_i,
                           flags, user_nslots, uslot_base, slot_index, grow, pos_tmp, pos_order, pos_score, pos_item, GU};
             pa.noise_row = c.noise_row; pa.noise_row0 = c.noise_row0; pa.noise_E = c.noise_E; pa.noise_ld = c.noise_ld;
             pa.noise_flag = c.noise_flag; pa.plan = plan;
             if (sizeof(T) == 4 && !g_sw.no_pos_keys)
                 pa.pos_key = (unsigned long long *)ws.get("pos_key", 8 * ((size_t)std::max<long long>(c.nnz_test, 1) + 8));
-            // The streamed users' positives (scores, then the all-pairs rank of long test rows: vector work) run on the side stream
-            // beside the table users' (whose scoring is an L2 gather): two chains of two kernels each instead of four kernels in a row
+            // Scores of the test entries: by entry (k_pos_scores_flat, launched beside the plan chain: every lane busy) unless the call
+            // evaluates a few of its users only -- then a wavefront per slot is less work.
+            const bool flat = flat_early;
+            // The streamed users' positives (the all-pairs rank of long test rows: vector work) run on a stream of their own beside
+            // the table users'
             hipStream_t ps = stream;
-            struct PosGuard { hipStream_t st = nullptr; ~PosGuard() { if (st) (void)hipStreamSynchronize(st); } } pos_guard;     // (an error between fork and join)
             const bool pos_beside = use_side && n_stream > 0 && stream_slot0 > 0 && !g_sw.no_pos_beside;
+            if (pos_beside) {
+                // (not the side stream: that one carries the dense train rows and the operand packing, 0.3 ms the streamed users' chain
+                // used to queue behind.  The host has waited for the call's stream since: nothing to wait for over there.)
+                ps = pos_stream();
+                pos_guard.st = ps;
+            }
+            PosArgs<T> pb = pa;
             if (n_stream > 0) {
                 const size_t nz = (size_t)std::max<long long>(c.nnz_test, 1);
                 spos_score = (T *)ws.get("spos_score", sizeof(T) * nz);
                 spos_item = (int *)ws.get("spos_item", sizeof(int) * nz);
                 shist = (unsigned *)ws.get("shist", sizeof(unsigned) * nz);
-                if (pos_beside) {
-                    // (a stream of their own, not the side stream: that one carries the dense train rows and the operand packing, 0.3 ms the
-                    // streamed users' chain used to queue behind)
-                    if (!cx.pos_stream) {
-                        HIP_CHECK(create_stream(&cx.pos_stream, cx.high_priority));
-                        for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&cx.pos_ev[i], hipEventDisableTiming));
-                    }
-                    ps = cx.pos_stream;
-                    HIP_CHECK(hipEventRecord(cx.pos_ev[0], stream));
-                    HIP_CHECK(hipStreamWaitEvent(ps, cx.pos_ev[0], 0));
-                    pos_guard.st = ps;
-                }
+                pb.stream = 1; pb.spos_score = spos_score; pb.spos_item = spos_item;
                 // (+inf in every rank: entries that repeat an item -- a non-canonical CSR row -- share a rank and leave one unused)
                 hipLaunchKernelGGL(k_init_tables<T>, dim3(cdiv((long long)nz, 256)), dim3(256), 0, ps, spos_score, shist, (long long)nz);
-                PosArgs<T> pb = pa;
-                pb.stream = 1; pb.spos_score = spos_score; pb.spos_item = spos_item;
-                const int nsc = hp.n_stream_chunks;
-                hipLaunchKernelGGL(k_pos_scores<T>, dim3(cdiv(nsc, POSS_WAVES)), dim3(POSS_WAVES * WAVE), 0, ps, pb, sc_user, sc_chunk, nsc);
-                hipLaunchKernelGGL(k_pos_place<T>, dim3(cdiv((long long)nsc * WAVE, 256)), dim3(256), 0, ps, pb, sc_user, sc_chunk, nsc);
             }
-            if (stream_slot0 > 0) {
-                hipLaunchKernelGGL(k_pos_scores<T>, dim3(cdiv(stream_slot0, POSS_WAVES)), dim3(POSS_WAVES * WAVE), 0, stream, pa, slot_user, slot_chunk, stream_slot0);
-                hipLaunchKernelGGL(k_pos_place<T>, dim3(cdiv((long long)stream_slot0 * WAVE, 256)), dim3(256), 0, stream, pa, slot_user, slot_chunk, stream_slot0);
+            const int nsc = hp.n_stream_chunks;
+            hipLaunchKernelGGL(k_init_tables<T>, dim3(cdiv(rows * GU, 256)), dim3(256), 0, stream, pos_score, hist, rows * GU);
+            if (flat) {
+                // (the scores are the last thing on the positives' stream: whoever is not on it waits for them)
+                if (use_side) { HIP_CHECK(hipStreamWaitEvent(stream, cx.pos_ev[1], 0)); if (!pos_beside) pos_guard.st = nullptr; }
+            } else {
+                if (n_stream > 0) hipLaunchKernelGGL(k_pos_scores<T>, dim3(cdiv(nsc, POSS_WAVES)), dim3(POSS_WAVES * WAVE), 0, ps, pb, sc_user, sc_chunk, nsc);
+                if (stream_slot0 > 0) hipLaunchKernelGGL(k_pos_scores<T>, dim3(cdiv(stream_slot0, POSS_WAVES)), dim3(POSS_WAVES * WAVE), 0, stream, pa, slot_user, slot_chunk, stream_slot0);
             }
-            if (pos_beside) { HIP_CHECK(hipEventRecord(cx.pos_ev[1], ps)); HIP_CHECK(hipStreamWaitEvent(stream, cx.pos_ev[1], 0)); pos_guard.st = nullptr; }
+            if (n_stream > 0) hipLaunchKernelGGL(k_pos_place<T>, dim3(cdiv((long long)nsc * WAVE, 256)), dim3(256), 0, ps, pb, sc_user, sc_chunk, nsc);
+            if (stream_slot0 > 0) hipLaunchKernelGGL(k_pos_place<T>, dim3(cdiv((long long)stream_slot0 * WAVE, 256)), dim3(256), 0, stream, pa, slot_user, slot_chunk, stream_slot0);
+            if (pos_beside) { HIP_CHECK(hipEventRecord(cx.pos_ev[4], ps)); HIP_CHECK(hipStreamWaitEvent(stream, cx.pos_ev[4], 0)); pos_guard.st = nullptr; }
         }
 
         if (n_stream > 0) stream_scores = (T *)ws.get("stream_scores", sizeof(T) * (size_t)n_stream * (size_t)stream_ld);
@@ -1666,9 +1712,7 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
         if (fit) {                                                    // rows of the flagged users alone, train items only
             bits = (unsigned *)pw.get("train_bits", (size_t)m * (size_t)words * 4);
             pc.bits_tag = 0; pc.bits_ptr = nullptr;
-            const unsigned blocks = (unsigned)std::min<long long>(((long long)m + TRAIN_BITS_WAVES - 1) / TRAIN_BITS_WAVES, 256 * 8);
-            hipLaunchKernelGGL(k_train_bits, dim3(blocks), dim3(TRAIN_BITS_WAVES * WAVE), sizeof(unsigned) * (size_t)TRAIN_BITS_WAVES * (size_t)words, ps,
-                               m, n, (int)words, dtrp, dtri, (const int *)nullptr, dtei, bits, (const Plan *)nullptr, only);
+            launch_train_bits(ps, m, n, (int)words, dtrp, dtri, (const int *)nullptr, dtei, bits, (const Plan *)nullptr, only);
             c.ext_bits = bits; c.ext_words = words; c.ext_masked = false;
         }
         c.dense_fit = fit ? 1 : 0;

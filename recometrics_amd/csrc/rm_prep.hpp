@@ -468,9 +468,13 @@ template <class T> __global__ void k_init_tables(T *scores, unsigned *hist, long
     if (i < count) { scores[i] = (T)__int_as_float(0x7f800000); hist[i] = 0u; }
 }
 
-// dense train rows for the sweep (SweepArgs::train_bits): one wavefront per user builds the row in LDS (coalesced reads of the
-// CSR row, LDS atomic OR per item, the padding beyond n set) and writes it out in one coalesced sweep -- every word of the
-// buffer is written, no memset.  words <= TRAIN_BITS_MAX_WORDS.
+// dense train rows for the sweep (SweepArgs::train_bits): a wavefront builds a user's row in LDS (the padding beyond n set, LDS
+// atomic OR per item) and writes it out in one coalesced sweep -- every word of the buffer is written, no memset.  The wavefronts
+// are resident and walk the users with a stride; a user's index pointers and first items are loaded while the row of the user
+// before is built and written (one user in flight per wavefront hides nothing: the round-4 kernel needed every wave slot of the
+// device and 107 KB of LDS per CU for its 0.2 ms, and the plan's kernels, the read-back's copy and the positives' kernels beside
+// it had to wait for a slot).  Four blocks per CU.  words <= TRAIN_BITS_MAX_WORDS, a multiple of 6 (rows are 8-byte aligned).
+// (Measured and dropped: no LDS, background by stores and the items by L2 atomics -- 5 ms for BASELINE C2's 20 M items.)
 constexpr int TRAIN_BITS_MAX_WORDS = 4096;            // 131,072 items: 16 KiB of LDS per wavefront
 constexpr int TRAIN_BITS_WAVES = 4;
 // With `test_p` the TEST items are marked as well (`bits`), and the sweep then never sees a user's own test items: they come
@@ -479,6 +483,8 @@ constexpr int TRAIN_BITS_WAVES = 4;
 // `plan`: the CSR arrays are only walked when the plan's validation kernels found every index pointer and index in range (an item
 // beyond n would be an LDS write out of the row).  `only` (optional): rows of the users with a non-zero entry only -- the others'
 // are never read (a pass over a few flagged users of a large range).
+struct TrainRowPtrs { int tr0, tr1, te0, te1; };
+struct TrainRowHead { int ia, ib, it; };                          // a user's first 128 train items and first 64 test items (-1: none)
 __global__ __launch_bounds__(TRAIN_BITS_WAVES * WAVE) void k_train_bits(int m, int n, int words, const int *train_p, const int *train_i,
                                                                         const int *test_p, const int *test_i, unsigned *bits,
                                                                         const Plan *plan, const unsigned char *only)
@@ -487,26 +493,76 @@ __global__ __launch_bounds__(TRAIN_BITS_WAVES * WAVE) void k_train_bits(int m, i
     if (plan && (plan->csr_bad & (CSR_BAD_INDPTR | CSR_BAD_INDEX))) return;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     unsigned *row = tb_lds + (size_t)wv * words;
-    for (int u = blockIdx.x * TRAIN_BITS_WAVES + wv; u < m; u += gridDim.x * TRAIN_BITS_WAVES) {
-        if (only && !only[u]) continue;
-        for (int w = lane; w < words; w += WAVE) row[w] = (w << 5) >= n ? 0xffffffffu : (((w << 5) + 32 > n) ? (0xffffffffu << (n & 31)) : 0u);
+    const int stride = gridDim.x * TRAIN_BITS_WAVES;
+    auto next_user = [&](int v) { while (v < m && only && !only[v]) v += stride; return v; };
+    // (the index pointers are wave-uniform, but loaded as per-lane values: as scalars the compiler wants them at once -- a wait for
+    // the load in front of everything else -- and the point is to have them arrive during the work on another row)
+    int lane0;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane0));
+    auto ptrs = [&](int u) {
+        TrainRowPtrs p;
+        const int v = u + lane0;
+        p.tr0 = train_p[v]; p.tr1 = train_p[v + 1];
+        p.te0 = test_p ? test_p[v] : 0; p.te1 = test_p ? test_p[v + 1] : 0;
+        return p;
+    };
+    auto head = [&](const TrainRowPtrs &p) {
+        TrainRowHead h;
+        h.ia = p.tr0 + lane < p.tr1 ? train_i[p.tr0 + lane] : -1;
+        h.ib = p.tr0 + WAVE + lane < p.tr1 ? train_i[p.tr0 + WAVE + lane] : -1;
+        h.it = p.te0 + lane < p.te1 ? test_i[p.te0 + lane] : -1;
+        return h;
+    };
+    auto background = [n](int w) { return (w << 5) >= n ? 0xffffffffu : (((w << 5) + 32 > n) ? (0xffffffffu << (n & 31)) : 0u); };
+    // two users ahead: the index pointers of the user after next and the first items of the next user are in flight while this
+    // user's row is built and written.  Three sets of registers take turns (a loop over one set would copy the loaded values at
+    // its back edge, i.e. wait for them there).
+    struct Row { int u; TrainRowPtrs p; TrainRowHead h; };
+    Row r0, r1, r2;
+    r0.u = next_user(blockIdx.x * TRAIN_BITS_WAVES + wv);
+    if (r0.u >= m) return;
+    r0.p = ptrs(r0.u);
+    r1.u = next_user(r0.u + stride);
+    r1.p = r1.u < m ? ptrs(r1.u) : r0.p;
+    r0.h = head(r0.p);
+    r1.h = r0.h; r2 = r1;
+    auto step = [&](Row &cur, Row &nxt, Row &nn) {
+        nn.u = nxt.u < m ? next_user(nxt.u + stride) : m;
+        if (nn.u < m) nn.p = ptrs(nn.u);
+        if (nxt.u < m) nxt.h = head(nxt.p);
+        for (int w = 2 * lane; w < words; w += 2 * WAVE) *(uint2 *)(row + w) = make_uint2(background(w), background(w + 1));
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int e = train_p[u] + lane; e < train_p[u + 1]; e += WAVE) { const int item = train_i[e]; atomicOr(&row[item >> 5], 1u << (item & 31)); }
+        if (cur.h.ia >= 0) atomicOr(&row[cur.h.ia >> 5], 1u << (cur.h.ia & 31));
+        if (cur.h.ib >= 0) atomicOr(&row[cur.h.ib >> 5], 1u << (cur.h.ib & 31));
+        for (int e = cur.p.tr0 + 2 * WAVE + lane; e < cur.p.tr1; e += WAVE) { const int item = train_i[e]; atomicOr(&row[item >> 5], 1u << (item & 31)); }
+        if (cur.h.it >= 0) atomicOr(&row[cur.h.it >> 5], 1u << (cur.h.it & 31));
+        for (int e = cur.p.te0 + WAVE + lane; e < cur.p.te1; e += WAVE) { const int item = test_i[e]; atomicOr(&row[item >> 5], 1u << (item & 31)); }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (test_p) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (int e = test_p[u] + lane; e < test_p[u + 1]; e += WAVE) { const int item = test_i[e]; atomicOr(&row[item >> 5], 1u << (item & 31)); }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+        unsigned *out = bits + (size_t)cur.u * words;
+        // (streaming stores: 463 MB at BASELINE C2 that nothing reads before the sweep -- as ordinary stores they wash the item factors
+        // out of the L2 under the positives' scores that run beside this kernel)
+        for (int w = 2 * lane; w < words; w += 2 * WAVE) {
+            const uint2 v = *(const uint2 *)(row + w);
+            __builtin_nontemporal_store(v.x, out + w); __builtin_nontemporal_store(v.y, out + w + 1);
         }
-        unsigned *out = bits + (size_t)u * words;
-        for (int w = lane; w < words; w += WAVE) out[w] = row[w];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        return nxt.u < m;
+    };
+    for (;;) {
+        if (!step(r0, r1, r2)) break;
+        if (!step(r1, r2, r0)) break;
+        if (!step(r2, r0, r1)) break;
     }
+}
+inline void launch_train_bits(hipStream_t stream, int m, int n, int words, const int *train_p, const int *train_i, const int *test_p, const int *test_i,
+                              unsigned *bits, const Plan *plan, const unsigned char *only)
+{
+    const unsigned blocks = (unsigned)std::min<long long>(((long long)m + TRAIN_BITS_WAVES - 1) / TRAIN_BITS_WAVES, 256 * 8);
+    hipLaunchKernelGGL(k_train_bits, dim3(blocks), dim3(TRAIN_BITS_WAVES * WAVE), sizeof(unsigned) * (size_t)TRAIN_BITS_WAVES * (size_t)words, stream,
+                       m, n, words, train_p, train_i, test_p, test_i, bits, plan, only);
 }
 
 template <class T> __global__ void k_fill(T *p, T v, long long count)
@@ -748,12 +804,203 @@ __global__ __launch_bounds__(POSS_WAVES * WAVE) void k_pos_scores(PosArgs<T> a, 
     }
 }
 
+// ---- the same scores, by ENTRY instead of by slot ------------------------------------------------------------------------------
+// k_pos_scores gives every slot a wavefront of its own: a user with a dozen test items keeps a dozen lanes busy, and every wavefront
+// pays the whole chain of dependent loads (slot -> row bounds -> items -> train row search -> item factors) for at most 63 entries --
+// at BASELINE C2 170,000 wavefronts of ~10 us each, 0.5 ms in front of the sweep, and NOT bound by the gather itself (test items
+// squeezed into an eighth of the item factors: the same time; r5_ab_c2.txt).  By entry: a wavefront takes 64 CONSECUTIVE test entries
+// whatever rows they belong to, every lane busy.  What an entry needs to know about its row depends on the CSR inputs alone: its
+// user (k_entry_users) and whether the train row holds the item (k_test_masked).  All three kernels run BESIDE the plan chain, the
+// plan read-back and the host's work behind it, on a stream of their own: nothing in them depends on the plan.  The user's factors are read per lane, 16 bytes at a time
+// (the lanes of one user ask for the same addresses: one request per distinct user of the 64 entries).
+// Same arithmetic: k-ordered fma chain from +0.  Users that are not evaluated (or need no ranks) are skipped per lane.
+__global__ __launch_bounds__(256) void k_entry_users(int m, const int *test_p, int *ent_user, const Plan *plan)
+{
+    if (plan->csr_bad & CSR_BAD_INDPTR) return;
+    const int lane = threadIdx.x & 63;
+    const int ub = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * WAVE;       // a wavefront per 64 users, one row at a time: coalesced writes
+    if (ub >= m) return;
+    const int u = ub + lane;
+    const int s = u < m ? test_p[u] : 0, e = u < m ? test_p[u + 1] : 0;
+    const int nu = min(WAVE, m - ub);
+    for (int j = 0; j < nu; j++) {
+        const int sj = __builtin_amdgcn_readlane(s, j), ej = __builtin_amdgcn_readlane(e, j);
+        for (int x = sj + lane; x < ej; x += WAVE) ent_user[x] = ub + j;
+    }
+}
+// k_test_masked: a block owns TM_USERS consecutive users.  Their train rows are CONSECUTIVE rows of the CSR, i.e. one contiguous
+// piece of the index array: it is staged in LDS with coalesced loads and the binary searches run there (a search in memory is seven
+// or eight DEPENDENT loads per entry at BASELINE C2: the kernel was 0.23 ms of latency).  The users are taken in runs whose rows fit
+// TM_CAP entries together; a single row longer than that is searched in memory.  39.5 KB of LDS per block also means four blocks per
+// CU: half of the wave slots stay free while this kernel runs beside the plan chain, whose blocks of 1,024 threads otherwise wait
+// for sixteen slots of one CU to fall free at once (measured: the plan read-back 60 us later).
+constexpr int TM_CAP = 9984, TM_USERS = 64;
+__global__ __launch_bounds__(256) void k_test_masked(int m, const int *test_p, const int *test_i, const int *train_p, const int *train_i,
+                                                     const int *ent_user, unsigned char *ent_masked, const Plan *plan)
+{
+    __shared__ int seg[TM_CAP];
+    __shared__ int tp[TM_USERS + 1], trp[TM_USERS + 1];
+    if (plan->csr_bad & CSR_BAD_INDPTR) return;
+    const int u0 = blockIdx.x * TM_USERS, nu = min(TM_USERS, m - u0), tid = threadIdx.x;
+    if (tid <= nu) { tp[tid] = test_p[u0 + tid]; trp[tid] = train_p[u0 + tid]; }
+    __syncthreads();
+    constexpr int SB = 4, EB = 4;                                 // loads in flight per thread: staging / entries
+    for (int a = 0; a < nu; ) {
+        int b = a + 1, longest = trp[a + 1] - trp[a];             // users [a, b): as many as fit, at least one
+        while (b < nu && trp[b + 1] - trp[a] <= TM_CAP) { longest = max(longest, trp[b + 1] - trp[b]); b++; }
+        const int s0 = trp[a], len = trp[b] - s0;
+        const bool fits = len <= TM_CAP;
+        if (fits) {
+            for (int base = 0; base < len; base += SB * 256) {
+                int v[SB];
+                #pragma unroll
+                for (int q = 0; q < SB; q++) { const int i = base + q * 256 + tid; v[q] = i < len ? train_i[s0 + i] : 0; }
+                #pragma unroll
+                for (int q = 0; q < SB; q++) { const int i = base + q * 256 + tid; if (i < len) seg[i] = v[q]; }
+            }
+            __syncthreads();
+        }
+        const int steps = 32 - __clz(longest);                    // binary search steps that settle the longest row of the run
+        const int e_end = tp[b];
+        for (int e0 = tp[a] + tid; e0 < e_end; e0 += EB * 256) {
+            // EB entries per thread at a time: their loads, then their searches step by step (independent chains of LDS reads)
+            int ul[EB], item[EB];
+            #pragma unroll
+            for (int q = 0; q < EB; q++) { const int e = e0 + q * 256; const bool in = e < e_end; ul[q] = in ? ent_user[e] - u0 : a; item[q] = in ? test_i[e] : 0; }
+            if (fits) {
+                int lo[EB], n[EB], end[EB];
+                #pragma unroll
+                for (int q = 0; q < EB; q++) { lo[q] = trp[ul[q]] - s0; end[q] = trp[ul[q] + 1] - s0; n[q] = end[q] - lo[q]; }
+                for (int st = 0; st < steps; st++) {
+                    #pragma unroll
+                    for (int q = 0; q < EB; q++) {
+                        const int half = n[q] >> 1, mid = lo[q] + half;
+                        const bool lt = n[q] > 0 && seg[mid] < item[q];
+                        lo[q] = lt ? mid + 1 : lo[q];
+                        n[q] = lt ? n[q] - half - 1 : half;
+                    }
+                }
+                #pragma unroll
+                for (int q = 0; q < EB; q++) { const int e = e0 + q * 256; if (e < e_end) ent_masked[e] = lo[q] < end[q] && seg[lo[q]] == item[q]; }
+            } else {
+                #pragma unroll
+                for (int q = 0; q < EB; q++) {
+                    const int e = e0 + q * 256;
+                    if (e >= e_end) continue;
+                    const int tr0 = trp[ul[q]], ntr = trp[ul[q] + 1] - tr0;
+                    ent_masked[e] = ntr && in_sorted_row(train_i + tr0, ntr, item[q]);
+                }
+            }
+        }
+        __syncthreads();
+        a = b;
+    }
+}
+
+constexpr int POSF_WAVES = 4;
+template <class T>
+__global__ __launch_bounds__(POSF_WAVES * WAVE) void k_pos_scores_flat(PosArgs<T> a, const int *ent_user, const unsigned char *ent_masked)
+{
+    constexpr int PB = 64;                                      // bytes of a row per staged piece
+    constexpr int CH = PB / (int)sizeof(T);                     // factors per piece: 32 floats / 16 doubles
+    constexpr int VE = 16 / (int)sizeof(T);                     // factors per 16-byte vector
+    constexpr int LPR = PB / 16;                                // lanes per row piece
+    constexpr int RPI = WAVE / LPR;                             // rows covered by one load instruction: 8
+    constexpr int LD = CH + VE;                                 // padded row stride in LDS (144 B)
+    typedef T VT __attribute__((ext_vector_type(16 / sizeof(T))));
+    __shared__ __attribute__((aligned(16))) T rows[POSF_WAVES][WAVE][LD];
+    if (a.plan->csr_bad & (CSR_BAD_INDPTR | CSR_BAD_INDEX)) return;       // (the test items index the item factors)
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const long long e = (long long)a.test_p[0] + ((long long)blockIdx.x * POSF_WAVES + wv) * WAVE + lane;
+    const bool in = e < (long long)a.test_p[a.m];
+    const int u = in ? ent_user[e] : 0;
+    const int item = in ? a.test_i[e] : 0;
+    const bool masked = in && ent_masked[e];
+    const int f = in ? a.flags[u] : 0;
+    const bool mine = in && (f & UF_ACTIVE) && !(f & UF_ONLY_NDCG);
+    const unsigned long long live = __ballot(mine);
+    if (!live) return;
+    const int rsub = lane / LPR, piece = lane % LPR;
+    const bool vec_ok = ((((size_t)a.B) | (a.ldb * sizeof(T))) & 15) == 0, avec_ok = ((((size_t)a.A) | (a.lda * sizeof(T))) & 15) == 0;
+    const T *brow[WAVE / RPI];
+    #pragma unroll
+    for (int q = 0; q < WAVE / RPI; q++) brow[q] = a.B + (size_t)__shfl(item, q * RPI + rsub) * a.ldb;
+    const T *Au = a.A + (size_t)u * a.lda;
+    T s = 0;
+    for (int k0 = 0; k0 < a.k; k0 += CH) {
+        const int e0 = k0 + piece * VE;                         // first factor of this lane's 16 bytes
+        VT bv[WAVE / RPI];
+        #pragma unroll
+        for (int q = 0; q < WAVE / RPI; q++) {
+            const int p = q * RPI + rsub;
+            VT x;
+            #pragma unroll
+            for (int i = 0; i < VE; i++) x[i] = (T)0;
+            if (((live >> p) & 1) && e0 < a.k) {
+                if (vec_ok && e0 + VE <= a.k) x = *(const VT *)(brow[q] + e0);
+                else {
+                    #pragma unroll
+                    for (int i = 0; i < VE; i++) if (e0 + i < a.k) x[i] = brow[q][e0 + i];
+                }
+            }
+            bv[q] = x;
+        }
+        VT av[CH / VE];
+        #pragma unroll
+        for (int j = 0; j < CH / VE; j++) {
+            VT x;
+            #pragma unroll
+            for (int i = 0; i < VE; i++) x[i] = (T)0;
+            const int f0 = k0 + j * VE;
+            if (mine && f0 < a.k) {
+                if (avec_ok && f0 + VE <= a.k) x = *(const VT *)(Au + f0);
+                else {
+                    #pragma unroll
+                    for (int i = 0; i < VE; i++) if (f0 + i < a.k) x[i] = Au[f0 + i];
+                }
+            }
+            av[j] = x;
+        }
+        #pragma unroll
+        for (int q = 0; q < WAVE / RPI; q++) *(VT *)&rows[wv][q * RPI + rsub][piece * VE] = bv[q];
+        const T *r = rows[wv][lane];
+        if (k0 + CH <= a.k) {
+            #pragma unroll
+            for (int j = 0; j < CH / VE; j++) {
+                const VT b = *(const VT *)(r + j * VE);
+                #pragma unroll
+                for (int i = 0; i < VE; i++) s = fma_chain_step(av[j][i], b[i], s);
+            }
+        } else {
+            #pragma unroll
+            for (int j = 0; j < CH / VE; j++) {
+                const VT b = *(const VT *)(r + j * VE);
+                #pragma unroll
+                for (int i = 0; i < VE; i++) if (k0 + j * VE + i < a.k) s = fma_chain_step(av[j][i], b[i], s);
+            }
+        }
+    }
+    if (mine && !masked && a.noise_E) {
+        const long long nr = a.noise_row ? a.noise_row[u] - a.noise_row0 : u;
+        s += a.noise_E[(size_t)nr * (size_t)a.noise_ld + item];
+    }
+    if (mine && !masked && a.noise_flag && (s < (T)0 ? -s : s) < (T)6.103515625e-05f) {
+        if (atomicExch(&a.noise_flag[u], 1) == 0) atomicAdd(&a.plan->n_noise_flagged, 1);
+    }
+    if (mine) {
+        const T sv = masked ? (T)__int_as_float(0x7f800000) : s;
+        a.pos_tmp[e] = sv;
+        if (sizeof(T) == 4 && a.pos_key) a.pos_key[e] = ((unsigned long long)ord_key((float)sv) << 32) | (unsigned)~item;
+    }
+}
+
 // One wavefront per SLOT (= up to 63 test entries of one user, by row position): rank of each of them among ALL the
 // user's entries in (score asc, item desc) order, by all-pairs counting.  The row is walked 64 entries at a time out
 // of registers (lane broadcasts), so the inner loop touches no memory, and a user with thousands of positives is
 // spread over as many waves as it has slots instead of serialising the kernel behind one wave.
+constexpr int PLACE_THREADS = 256;
 template <class T>
-__global__ void k_pos_place(PosArgs<T> a, const int *slot_user, const int *slot_chunk, int n_slots)
+__global__ __launch_bounds__(PLACE_THREADS) void k_pos_place(PosArgs<T> a, const int *slot_user, const int *slot_chunk, int n_slots)
 {
     const int w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;     // (a wave's index: uniform, and known to be)
     if (w >= n_slots) return;
@@ -767,22 +1014,33 @@ __global__ void k_pos_place(PosArgs<T> a, const int *slot_user, const int *slot_
     int rank = 0;
     if (sizeof(T) == 4 && a.pos_key) {
         // fp32: (score asc, item desc) is the order of the packed key (ordered score bits << 32) | ~item, so an entry's rank is the
-        // number of smaller keys.  The keys of the row (written by k_pos_scores) are read with a wave-uniform index -- scalar
-        // loads, eight keys per instruction -- and each costs one 64-bit compare and one add-with-carry: 2 vector instructions
-        // per pair instead of the 5 of a lane broadcast (two v_readlane, compare, add), which made the all-pairs rank of the
-        // streamed users' long rows 0.19 ms at BASELINE C2.  (Scores are never -0: the chain starts at +0.)
+        // number of smaller keys (k_pos_scores wrote them).  The row's keys pass through a small LDS buffer of the wavefront, 64 at a
+        // time: one coalesced load per piece (the next piece in flight while this one is compared), then every key is read back with
+        // a wave-uniform address -- an LDS broadcast, two keys per instruction -- and costs one 64-bit compare and one add-with-carry.
+        // (Round 4 read them through the scalar cache, eight keys per load: the loads come back one latency after the other, and the
+        // all-pairs rank of the streamed users' long rows, 32 us of vector work at BASELINE C2, took 140 us.)
+        // (Scores are never -0: the chain starts at +0.)
+        __shared__ __attribute__((aligned(16))) unsigned long long kbuf[PLACE_THREADS / WAVE][2][WAVE];
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const unsigned long long key = ((unsigned long long)ord_key((float)s) << 32) | (unsigned)~item;
         const unsigned long long *keys = a.pos_key + te0;
         const int P = te1 - te0;
-        int j = 0;
-        for (; j + 8 <= P; j += 8) {
-            unsigned long long k8[8];
-            #pragma unroll
-            for (int q = 0; q < 8; q++) k8[q] = __builtin_nontemporal_load(keys + j + q);
-            #pragma unroll
-            for (int q = 0; q < 8; q++) rank += k8[q] < key;
+        // (beyond the row the buffer holds the largest key, which is smaller than nothing: whole groups of 16 are compared)
+        unsigned long long nxt = lane < P ? keys[lane] : ~0ull;
+        for (int j0 = 0; j0 < P; j0 += WAVE) {
+            const unsigned long long cur = nxt;
+            if (j0 + WAVE < P) nxt = j0 + WAVE + lane < P ? keys[j0 + WAVE + lane] : ~0ull;
+            unsigned long long *kb = kbuf[wv][(j0 >> 6) & 1];
+            kb[lane] = cur;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int cnt = min(WAVE, P - j0);
+            typedef unsigned long long K2 __attribute__((ext_vector_type(2)));
+            for (int j = 0; j < cnt; j += 16) {
+                #pragma unroll
+                for (int q = 0; q < 16; q += 2) { const K2 k2 = *(const K2 *)&kb[j + q]; rank += k2.x < key; rank += k2.y < key; }
+            }
         }
-        for (; j < P; j++) rank += __builtin_nontemporal_load(keys + j) < key;
     } else if (sizeof(T) == 4) {
         const unsigned long long key = ((unsigned long long)ord_key((float)s) << 32) | (unsigned)~item;
         for (int f0 = te0; f0 < te1; f0 += WAVE) {

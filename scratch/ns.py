@@ -18,6 +18,8 @@ torch.cuda.set_device(0); binding.load(); binding.set_device(0)
 cumulative = wl == "C3" or bool(os.environ.get("NS_CUMULATIVE"))          # C3 is quoted with K = 1..20 (cumulative)
 p = DeviceProblem(torch, torch.device("cuda", 0), m, n, k, mean_c, seed, K, dtype, cumulative=cumulative)
 p.noise = bool(os.environ.get("NS_NOISE"))
+if os.environ.get("NS_TEST_DIV"):       # experiment: the test items squeezed into the first n/DIV items (rows stay sorted; repeats allowed)
+    p.tei = torch.div(p.tei, int(os.environ["NS_TEST_DIV"]), rounding_mode="floor").to(p.tei.dtype)
 dt, sw, pr, fi, tm = measure(torch, dist, binding, p, steps, 1, 1, None)
 tf = 2.0 * n * k * m / (sw * 1e-3) / 1e12
 peak = 157.3 if dtype == np.float32 else 78.6

@@ -19,6 +19,6 @@ with open(sys.argv[2], "w") as o:
     o.write("# start_us  dur_us  queue  kernel   (one step of the workload; times relative to the step's first kernel)\n")
     for r in rows[i0:]:
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-        o.write("%9.1f %8.1f  q%s  %s\n" % ((s - t0) / 1e3, (e - s) / 1e3, r.get("Queue_Id", "?"), r["Kernel_Name"][:90]))
+        o.write("%9.1f %8.1f  q%s  %s\n" % ((s - t0) / 1e3, (e - s) / 1e3, str(r.get("Queue_Id", "?")) + "/s" + str(r.get("Stream_Id", "?")), r["Kernel_Name"][:90]))
 print(open(sys.argv[2]).read())
 PY

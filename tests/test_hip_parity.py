@@ -253,7 +253,7 @@ def test_every_factor_group_count_has_its_kernel(hip, oracle, k, env, monkeypatc
                                  {"RM_DEBUG_NO_TRAIN_BITS": "1"}, {"RM_DEBUG_NO_SEED": "1"}, {"RM_DEBUG_SPLITS": "5"},
                                  {"RM_DEBUG_SPLITS": "2,1,5"}, {"RM_DEBUG_SPLITS": "1,2,3"}, {"RM_DEBUG_SPLITS": "3,1,7", "RM_DEBUG_HBM_LISTS": "1"},
                                  {"RM_DEBUG_HBM_LISTS": "1", "RM_DEBUG_NO_PENDING": "1"},
-                                 {"RM_DEBUG_NSUB2": "1"}, {"RM_DEBUG_NSUB2": "1", "RM_DEBUG_NO_PENDING": "1"}])
+                                 {"RM_DEBUG_NSUB2": "1"}, {"RM_DEBUG_NSUB2": "1", "RM_DEBUG_NO_PENDING": "1"}, {"RM_DEBUG_NO_POS_FLAT": "1"}])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_list_schemes_agree(hip, oracle, env, dtype, monkeypatch):
     """the same problem through every top-K list scheme the sweep has (the library reads the switches at load; conftest.py makes it read them again after every monkeypatch.setenv), with the
@@ -303,6 +303,27 @@ def test_long_test_rows_streamed_or_chunked(hip, oracle, dtype, budget, monkeypa
         _check_against_oracle(hip, oracle, pr, 10, dtype=dtype)
 
 
+def test_second_plan_keeps_the_users_the_tie_noise_flagged(hip, monkeypatch):
+    """fp32 tie noise + a budget too small for the streamed users' score rows: the plan is made twice (second time with the long rows
+    in chunks), while the positives' scores -- whose kernel flags the users with a test item the noise can move, and counts them --
+    were launched beside the FIRST plan and are not made again: the count survives the second plan's reset (a lost count would skip
+    the exact pass and leave the un-noised values).  Cold items (all-zero factors) make sure users are flagged.  Bit for bit the
+    call that never streams."""
+    from recometrics_amd.synth import make_problem
+    pr = make_problem(500, 7000, 40, np.float32, mean_c=260, seed=33)
+    rng = np.random.default_rng(8)
+    pr["B"] = pr["B"].copy()
+    pr["B"][rng.random(7000) < 0.2] = 0
+    monkeypatch.setenv("RM_STREAM_BUDGET_MB", "0")
+    ref = hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], 10, noise=True, seed=7)
+    quiet = hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], 10, noise=False)
+    assert any((np.asarray(ref[name]) != np.asarray(quiet[name]))[~np.isnan(np.asarray(quiet[name]))].any() for name in ref), "the noise changed nothing: the case does not test it"
+    monkeypatch.setenv("RM_STREAM_BUDGET_MB", "1")
+    got = hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], 10, noise=True, seed=7)
+    for name in ref:
+        assert_same_bits(got[name], ref[name], "second plan, tie noise: " + name)
+
+
 @pytest.mark.parametrize("noise", [False, True])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_test_items_that_are_also_train_items(hip, oracle, dtype, noise):
@@ -327,7 +348,8 @@ def test_test_items_that_are_also_train_items(hip, oracle, dtype, noise):
 
 @pytest.mark.parametrize("env", [{}, {"RM_DEBUG_RANK_GENERIC": "1"}, {"RM_DEBUG_NO_SIDE": "1"},
                                  {"RM_DEBUG_RANK_GENERIC": "1", "RM_DEBUG_NO_SIDE": "1"}, {"RM_DEBUG_NO_FUSED_AUC": "1"},
-                                 {"RM_DEBUG_NO_DEFER_AUC": "1"}, {"RM_DEBUG_NO_TEST_MASK": "1"}])
+                                 {"RM_DEBUG_NO_DEFER_AUC": "1"}, {"RM_DEBUG_NO_TEST_MASK": "1"}, {"RM_DEBUG_NO_POS_FLAT": "1"},
+                                 {"RM_DEBUG_NO_POS_FLAT": "1", "RM_DEBUG_NO_SIDE": "1"}, {"RM_DEBUG_NO_POS_BESIDE": "1"}])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_streamed_ranks_fast_routine_and_side_stream(hip, oracle, env, dtype, monkeypatch):
     """streamed users of every table depth the fast routine of k_rank_streamed is built for (64 .. 1023 test items: 128, 256, 512
