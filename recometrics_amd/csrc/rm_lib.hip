@@ -388,7 +388,8 @@ inline bool dense_rows_fit(const Workspace &ws, int m, long long n)
 // the test items' bits in its own copy of a row)
 // `early`: the rows were launched before the plan was known (run(): on the side stream, beside the plan kernels) with the guess
 // `early_masked`; when the guess holds nothing is launched here
-template <class C> inline void set_train_bits(SweepArgs &sa, Ctx &cx, const C &c, int m, int n, bool fit, hipStream_t stream, bool mask_test, bool early = false, bool early_masked = false)
+template <class C> inline void set_train_bits(SweepArgs &sa, Ctx &cx, const C &c, int m, int n, bool fit, hipStream_t stream, bool mask_test, bool early = false, bool early_masked = false,
+                                              unsigned char *ent_masked = nullptr)
 {
     Workspace &ws = cx.ws;
     const long long words = dense_row_words(n);
@@ -400,15 +401,15 @@ template <class C> inline void set_train_bits(SweepArgs &sa, Ctx &cx, const C &c
     const bool ready = (early && early_masked == mask_test) ||
                        (c.same_train_rows && !cx.bits_partial && cx.bits_ptr == (const void *)bits && cx.bits_words == words && cx.bits_m == m && cx.bits_masked == mask_test);
     if (!ready) {
-        launch_train_bits(stream, m, n, (int)words, c.train_p, c.train_i, mask_test ? c.test_p : nullptr, c.test_i, bits,
-                          (const Plan *)ws.get("plan", sizeof(Plan)), c.only_users);
+        launch_train_bits(stream, m, n, (int)words, c.train_p, c.train_i, (mask_test || ent_masked) ? c.test_p : nullptr, c.test_i, bits,
+                          (const Plan *)ws.get("plan", sizeof(Plan)), c.only_users, ent_masked, mask_test);
         cx.bits_partial = c.only_users != nullptr;
     }
     cx.bits_ptr = (const void *)bits; cx.bits_words = words; cx.bits_m = m; cx.bits_masked = mask_test;
     cx.bits_tag = c.items_tag; cx.bits_train_p = c.train_p;
     sa.train_bits = bits; sa.train_words = (int)words;
 }
-template <class C> inline void set_train_bits(Sweep64Args &, Ctx &, const C &, int, int, bool, hipStream_t, bool, bool = false, bool = false) {}
+template <class C> inline void set_train_bits(Sweep64Args &, Ctx &, const C &, int, int, bool, hipStream_t, bool, bool = false, bool = false, unsigned char * = nullptr) {}
 inline void set_part_extra(SweepArgs &sa, int extra) { sa.part_extra = extra; }
 inline void set_part_extra(Sweep64Args &, int) {}
 // the sweep variant with the epilogue's switches as constants (rm_sweep.hpp k_sweep SPEC): 1 = dense train rows, 2 = CSR cursor,
@@ -578,7 +579,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     // (one answer per call: a later pass -- the exact passes of the tie noise, on this or on a peer context with less free memory --
     // carries the first pass's answer; rows handed over by another pass are proof that they fit)
     const bool dense_ok = std::is_same<T, float>::value && (c.ext_bits ? true : c.dense_fit >= 0 ? c.dense_fit != 0 : dense_rows_fit(ws, m, n));
-    bool bits_early = false, bits_early_masked = false;
+    bool bits_early = false, bits_early_masked = false, masked_from_bits = false;
     // the positives' stream: the streamed users' chain beside the table users', and what is made per test entry beside the plan chain
     struct PosGuard { hipStream_t st = nullptr; ~PosGuard() { if (st) (void)hipStreamSynchronize(st); } } pos_guard;     // (an error between fork and join)
     auto pos_stream = [&]() {
@@ -601,6 +602,13 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         pf.noise_row = c.noise_row; pf.noise_row0 = c.noise_row0; pf.noise_E = c.noise_E; pf.noise_ld = c.noise_ld;
         pf.noise_flag = c.noise_flag; pf.plan = plan;
     }
+    auto launch_flat = [&](hipStream_t es) {
+        hipLaunchKernelGGL(k_pos_scores_flat<T>, dim3(cdiv(c.nnz_test, POSF_WAVES * WAVE)), dim3(POSF_WAVES * WAVE), 0, es, pf, ent_user);
+        // test items that are train items: +inf, once the answer (the dense train rows' kernel, or k_test_masked) is there
+        if (masked_from_bits) HIP_CHECK(hipStreamWaitEvent(es, cx.side_ev[5], 0));
+        else hipLaunchKernelGGL(k_test_masked, dim3(cdiv(m, TM_USERS)), dim3(256), 0, es, m, c.test_p, c.test_i, c.train_p, c.train_i, ent_user, ent_masked, plan);
+        hipLaunchKernelGGL(k_pos_apply_masked<T>, dim3(cdiv(c.nnz_test, 256)), dim3(256), 0, es, pf, ent_masked);
+    };
     Plan hp;
     for (int attempt = 0; ; attempt++) {
         // ---- the plan chain: five launches that depend on one another, on the call's stream (index pointers only) ----
@@ -621,28 +629,40 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         // answer, and a wrong guess costs one more launch of the kernel behind it.
         hipStream_t aux = use_side ? fork_side() : stream;
         if (!c.csr_checked) launch_csr_index_checks(m, n, c.train_p, c.train_i, c.nnz_train, c.test_p, c.test_i, c.nnz_test, plan, aux);
+        hipLaunchKernelGGL(k_absmax<T>, dim3(512), dim3(256), 0, aux, c.A, c.lda, (long long)m, k, &plan->amax_a, &plan->nonfinite);
+        if (!items_known) hipLaunchKernelGGL(k_absmax<T>, dim3(1024), dim3(256), 0, aux, c.B, c.ldb, (long long)n, k, &plan->amax_b, &plan->nonfinite_b);
+        if (use_side) HIP_CHECK(hipEventRecord(cx.side_ev[2], aux));                  // the plan read-back waits for this much of the side stream
+        // The dense train rows (463 MB of writes at BASELINE C2) follow at once: four resident blocks per CU leave half of the wave
+        // slots to the plan's kernels and the read-back's copy.  With the positives' scores by entry they also say which test items
+        // are train items (`ent_masked`): a bit of the row they have just built.
+        if (attempt == 0 && std::is_same<T, float>::value && use_side && !c.ext_bits && dense_ok && !g_sw.no_early_bits) {
+            SweepArgs probe{};
+            const bool guess = want_auc && !ext_topk && !g_sw.no_test_mask;
+            const unsigned *had = (const unsigned *)cx.bits_ptr;
+            const bool reuse = c.same_train_rows && had && !cx.bits_partial && cx.bits_words == dense_row_words(n) && cx.bits_m == m && cx.bits_masked == guess &&
+                               had == (const unsigned *)ws.get("train_bits", (size_t)m * (size_t)dense_row_words(n) * 4);
+            if (!reuse) {
+                set_train_bits(probe, cx, c, m, n, dense_ok, aux, guess, false, false, flat_early ? ent_masked : nullptr);
+                HIP_CHECK(hipEventRecord(cx.side_ev[4], aux));
+                HIP_CHECK(hipEventRecord(cx.side_ev[5], aux));
+                bits_early = true; bits_early_masked = guess; masked_from_bits = flat_early;
+            }
+        }
         if (attempt == 0 && flat_early) {
-            // The scores of the test entries (k_pos_scores_flat) and what they need to know about every entry -- its user, and whether
-            // the train row holds the item -- depend on the inputs and on the users' flags alone: they run on the positives' stream
-            // beside the plan chain, the read-back and the host's work behind it.  The scores index the item factors by the test
-            // items: they wait for the index checks (and return when those found a defect).
+            // The scores of the test entries (k_pos_scores_flat) and the user of every entry depend on the inputs and on the users'
+            // flags alone: they run on the positives' stream, the scores beside the read-back and the host's work behind it.  The
+            // scores index the item factors by the test items: they follow the index checks (and return when those found a defect).
+            // Without dense train rows k_test_masked says which test items are train items, behind the scores.
             hipStream_t es = stream;
             if (use_side) {
                 es = pos_stream();
                 HIP_CHECK(hipEventRecord(cx.pos_ev[0], stream));
                 HIP_CHECK(hipStreamWaitEvent(es, cx.pos_ev[0], 0));
                 pos_guard.st = es;
-                HIP_CHECK(hipEventRecord(cx.side_ev[6], aux));
             }
             hipLaunchKernelGGL(k_entry_users, dim3(cdiv(cdiv(m, WAVE) * WAVE, 256)), dim3(256), 0, es, m, c.test_p, ent_user, plan);
-            hipLaunchKernelGGL(k_test_masked, dim3(cdiv(m, TM_USERS)), dim3(256), 0, es, m, c.test_p, c.test_i, c.train_p, c.train_i, ent_user, ent_masked, plan);
-            if (use_side) HIP_CHECK(hipStreamWaitEvent(es, cx.side_ev[6], 0));
-            hipLaunchKernelGGL(k_pos_scores_flat<T>, dim3(cdiv(c.nnz_test, POSF_WAVES * WAVE)), dim3(POSF_WAVES * WAVE), 0, es, pf, ent_user, ent_masked);
-            if (use_side) HIP_CHECK(hipEventRecord(cx.pos_ev[1], es));
+            if (!use_side) launch_flat(es);
         }
-        hipLaunchKernelGGL(k_absmax<T>, dim3(512), dim3(256), 0, aux, c.A, c.lda, (long long)m, k, &plan->amax_a, &plan->nonfinite);
-        if (!items_known) hipLaunchKernelGGL(k_absmax<T>, dim3(1024), dim3(256), 0, aux, c.B, c.ldb, (long long)n, k, &plan->amax_b, &plan->nonfinite_b);
-        if (use_side) HIP_CHECK(hipEventRecord(cx.side_ev[2], aux));                  // the plan read-back waits for this much of the side stream
         if (tile_total) {
             hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(1024), 0, stream, user_nslots, uslot_base, m, tile_total);
             hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, tile_total, tile_offset, n_tiles, &plan->n_slots, plan, GU);
@@ -655,20 +675,14 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         hipLaunchKernelGGL(k_block_tables, dim3(1), dim3(1024), 0, stream, plan, slot_j, gj, grow, GU);
         if (use_side) HIP_CHECK(hipStreamWaitEvent(stream, cx.side_ev[2], 0));
         HIP_CHECK(hipMemcpyAsync(cx.pinned_plan, plan, sizeof(Plan), hipMemcpyDeviceToHost, stream));
-        // (the dense train rows are 463 MB of writes at BASELINE C2: launched BEHIND the read-back's copy -- in front of it the plan's
-        // kernels and the copy wait for wave slots: blocks of 1,024 threads beside a device full of resident waves, +0.15 ms)
-        if (use_side) { HIP_CHECK(hipEventRecord(cx.side_ev[5], stream)); HIP_CHECK(hipStreamWaitEvent(aux, cx.side_ev[5], 0)); }
-        if (attempt == 0 && std::is_same<T, float>::value && use_side && !c.ext_bits && dense_ok && !g_sw.no_early_bits) {
-            SweepArgs probe{};
-            const bool guess = want_auc && !ext_topk && !g_sw.no_test_mask;
-            const unsigned *had = (const unsigned *)cx.bits_ptr;
-            const bool reuse = c.same_train_rows && had && !cx.bits_partial && cx.bits_words == dense_row_words(n) && cx.bits_m == m && cx.bits_masked == guess &&
-                               had == (const unsigned *)ws.get("train_bits", (size_t)m * (size_t)dense_row_words(n) * 4);
-            if (!reuse) {
-                set_train_bits(probe, cx, c, m, n, dense_ok, aux, guess);
-                HIP_CHECK(hipEventRecord(cx.side_ev[4], aux));
-                bits_early = true; bits_early_masked = guess;
-            }
+        if (attempt == 0 && flat_early && use_side) {
+            // (behind the plan's last kernel and the copy, which have waited for the index checks: the scores' blocks take every wave
+            // slot they find, and a plan kernel's block of 1,024 threads then waits for sixteen slots of one CU to fall free at once --
+            // measured: the read-back 0.2 ms late)
+            HIP_CHECK(hipEventRecord(cx.pos_ev[3], stream));
+            HIP_CHECK(hipStreamWaitEvent(cx.pos_stream, cx.pos_ev[3], 0));
+            launch_flat(cx.pos_stream);
+            HIP_CHECK(hipEventRecord(cx.pos_ev[1], cx.pos_stream));
         }
         HIP_CHECK(hipStreamSynchronize(stream));
         // (the stream has waited for side_ev[2]: only the dense train rows of the first attempt may still be running over there)

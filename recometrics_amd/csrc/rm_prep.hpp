@@ -473,7 +473,7 @@ template <class T> __global__ void k_init_tables(T *scores, unsigned *hist, long
 // are resident and walk the users with a stride; a user's index pointers and first items are loaded while the row of the user
 // before is built and written (one user in flight per wavefront hides nothing: the round-4 kernel needed every wave slot of the
 // device and 107 KB of LDS per CU for its 0.2 ms, and the plan's kernels, the read-back's copy and the positives' kernels beside
-// it had to wait for a slot).  Four blocks per CU.  words <= TRAIN_BITS_MAX_WORDS, a multiple of 6 (rows are 8-byte aligned).
+// it had to wait for a slot).  Four blocks per CU: half of the wave slots stay free.  words <= TRAIN_BITS_MAX_WORDS, a multiple of 6 (rows are 8-byte aligned).
 // (Measured and dropped: no LDS, background by stores and the items by L2 atomics -- 5 ms for BASELINE C2's 20 M items.)
 constexpr int TRAIN_BITS_MAX_WORDS = 4096;            // 131,072 items: 16 KiB of LDS per wavefront
 constexpr int TRAIN_BITS_WAVES = 4;
@@ -487,7 +487,8 @@ struct TrainRowPtrs { int tr0, tr1, te0, te1; };
 struct TrainRowHead { int ia, ib, it; };                          // a user's first 128 train items and first 64 test items (-1: none)
 __global__ __launch_bounds__(TRAIN_BITS_WAVES * WAVE) void k_train_bits(int m, int n, int words, const int *train_p, const int *train_i,
                                                                         const int *test_p, const int *test_i, unsigned *bits,
-                                                                        const Plan *plan, const unsigned char *only)
+                                                                        const Plan *plan, const unsigned char *only,
+                                                                        unsigned char *ent_masked, int mark_test)
 {
     extern __shared__ unsigned tb_lds[];                      // [TRAIN_BITS_WAVES][words]
     if (plan && (plan->csr_bad & (CSR_BAD_INDPTR | CSR_BAD_INDEX))) return;
@@ -536,8 +537,20 @@ __global__ __launch_bounds__(TRAIN_BITS_WAVES * WAVE) void k_train_bits(int m, i
         if (cur.h.ia >= 0) atomicOr(&row[cur.h.ia >> 5], 1u << (cur.h.ia & 31));
         if (cur.h.ib >= 0) atomicOr(&row[cur.h.ib >> 5], 1u << (cur.h.ib & 31));
         for (int e = cur.p.tr0 + 2 * WAVE + lane; e < cur.p.tr1; e += WAVE) { const int item = train_i[e]; atomicOr(&row[item >> 5], 1u << (item & 31)); }
-        if (cur.h.it >= 0) atomicOr(&row[cur.h.it >> 5], 1u << (cur.h.it & 31));
-        for (int e = cur.p.te0 + WAVE + lane; e < cur.p.te1; e += WAVE) { const int item = test_i[e]; atomicOr(&row[item >> 5], 1u << (item & 31)); }
+        if (ent_masked) {
+            // with the train items in and before the test items are: is a test item a train item?  (what the positives' scores by
+            // entry need to know, k_pos_apply_masked: one LDS read here instead of a binary search of the train row)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (cur.h.it >= 0) ent_masked[cur.p.te0 + lane] = (row[cur.h.it >> 5] >> (cur.h.it & 31)) & 1u;
+            for (int e = cur.p.te0 + WAVE + lane; e < cur.p.te1; e += WAVE) { const int item = test_i[e]; ent_masked[e] = (row[item >> 5] >> (item & 31)) & 1u; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (mark_test) {
+            if (cur.h.it >= 0) atomicOr(&row[cur.h.it >> 5], 1u << (cur.h.it & 31));
+            for (int e = cur.p.te0 + WAVE + lane; e < cur.p.te1; e += WAVE) { const int item = test_i[e]; atomicOr(&row[item >> 5], 1u << (item & 31)); }
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         unsigned *out = bits + (size_t)cur.u * words;
@@ -557,12 +570,13 @@ __global__ __launch_bounds__(TRAIN_BITS_WAVES * WAVE) void k_train_bits(int m, i
         if (!step(r2, r0, r1)) break;
     }
 }
+// (`test_p` with `mark_test` = 0: the test rows are read for `ent_masked` only)
 inline void launch_train_bits(hipStream_t stream, int m, int n, int words, const int *train_p, const int *train_i, const int *test_p, const int *test_i,
-                              unsigned *bits, const Plan *plan, const unsigned char *only)
+                              unsigned *bits, const Plan *plan, const unsigned char *only, unsigned char *ent_masked = nullptr, bool mark_test = true)
 {
-    const unsigned blocks = (unsigned)std::min<long long>(((long long)m + TRAIN_BITS_WAVES - 1) / TRAIN_BITS_WAVES, 256 * 8);
+    const unsigned blocks = (unsigned)std::min<long long>(((long long)m + TRAIN_BITS_WAVES - 1) / TRAIN_BITS_WAVES, 256 * 4);
     hipLaunchKernelGGL(k_train_bits, dim3(blocks), dim3(TRAIN_BITS_WAVES * WAVE), sizeof(unsigned) * (size_t)TRAIN_BITS_WAVES * (size_t)words, stream,
-                       m, n, words, train_p, train_i, test_p, test_i, bits, plan, only);
+                       m, n, words, train_p, train_i, test_p, test_i, bits, plan, only, ent_masked, (test_p && mark_test) ? 1 : 0);
 }
 
 template <class T> __global__ void k_fill(T *p, T v, long long count)
@@ -899,7 +913,7 @@ __global__ __launch_bounds__(256) void k_test_masked(int m, const int *test_p, c
 
 constexpr int POSF_WAVES = 4;
 template <class T>
-__global__ __launch_bounds__(POSF_WAVES * WAVE) void k_pos_scores_flat(PosArgs<T> a, const int *ent_user, const unsigned char *ent_masked)
+__global__ __launch_bounds__(POSF_WAVES * WAVE) void k_pos_scores_flat(PosArgs<T> a, const int *ent_user)
 {
     constexpr int PB = 64;                                      // bytes of a row per staged piece
     constexpr int CH = PB / (int)sizeof(T);                     // factors per piece: 32 floats / 16 doubles
@@ -915,7 +929,6 @@ __global__ __launch_bounds__(POSF_WAVES * WAVE) void k_pos_scores_flat(PosArgs<T
     const bool in = e < (long long)a.test_p[a.m];
     const int u = in ? ent_user[e] : 0;
     const int item = in ? a.test_i[e] : 0;
-    const bool masked = in && ent_masked[e];
     const int f = in ? a.flags[u] : 0;
     const bool mine = in && (f & UF_ACTIVE) && !(f & UF_ONLY_NDCG);
     const unsigned long long live = __ballot(mine);
@@ -980,18 +993,30 @@ __global__ __launch_bounds__(POSF_WAVES * WAVE) void k_pos_scores_flat(PosArgs<T
             }
         }
     }
-    if (mine && !masked && a.noise_E) {
+    // (whether the train row holds the item is not known here: k_pos_apply_masked overwrites those entries afterwards.  A user
+    // flagged for one of them goes through an exact pass it did not need -- same results.)
+    if (mine && a.noise_E) {
         const long long nr = a.noise_row ? a.noise_row[u] - a.noise_row0 : u;
         s += a.noise_E[(size_t)nr * (size_t)a.noise_ld + item];
     }
-    if (mine && !masked && a.noise_flag && (s < (T)0 ? -s : s) < (T)6.103515625e-05f) {
+    if (mine && a.noise_flag && (s < (T)0 ? -s : s) < (T)6.103515625e-05f) {
         if (atomicExch(&a.noise_flag[u], 1) == 0) atomicAdd(&a.plan->n_noise_flagged, 1);
     }
     if (mine) {
-        const T sv = masked ? (T)__int_as_float(0x7f800000) : s;
-        a.pos_tmp[e] = sv;
-        if (sizeof(T) == 4 && a.pos_key) a.pos_key[e] = ((unsigned long long)ord_key((float)sv) << 32) | (unsigned)~item;
+        a.pos_tmp[e] = s;
+        if (sizeof(T) == 4 && a.pos_key) a.pos_key[e] = ((unsigned long long)ord_key((float)s) << 32) | (unsigned)~item;
     }
+}
+// test entries whose item is a train item of the user: score +inf (the reference never scores a train item, recometrics.hpp:491-497)
+template <class T>
+__global__ void k_pos_apply_masked(PosArgs<T> a, const unsigned char *ent_masked)
+{
+    if (a.plan->csr_bad & (CSR_BAD_INDPTR | CSR_BAD_INDEX)) return;
+    const long long e = (long long)a.test_p[0] + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)a.test_p[a.m] || !ent_masked[e]) return;
+    const T inf = (T)__int_as_float(0x7f800000);
+    a.pos_tmp[e] = inf;
+    if (sizeof(T) == 4 && a.pos_key) a.pos_key[e] = ((unsigned long long)ord_key((float)inf) << 32) | (unsigned)~a.test_i[e];
 }
 
 // One wavefront per SLOT (= up to 63 test entries of one user, by row position): rank of each of them among ALL the
