@@ -303,6 +303,40 @@ def test_long_test_rows_streamed_or_chunked(hip, oracle, dtype, budget, monkeypa
         _check_against_oracle(hip, oracle, pr, 10, dtype=dtype)
 
 
+@pytest.mark.parametrize("env", [{}, {"RM_DEBUG_NO_TRAIN_BITS": "1"}, {"RM_DEBUG_NO_POS_FLAT": "1"}])
+@pytest.mark.parametrize("dtype,k", [(np.float32, 50), (np.float32, 3), (np.float64, 17)])
+def test_scores_of_the_test_entries_by_entry(hip, oracle, dtype, k, env, monkeypatch):
+    """the positives' scores by ENTRY (k_pos_scores_flat: 64 consecutive test entries per wavefront, whatever rows they belong to) and
+    the kernels that tell it about its entries (k_entry_users; the train-item test from the dense rows' kernel, or k_test_masked
+    without them -- RM_DEBUG_NO_TRAIN_BITS, fp64): empty test rows between the others, rows of one entry, rows that straddle the
+    64-entry pieces, users that are not evaluated (no train items), factor counts that leave ragged 16-byte vectors and ragged
+    pieces, one user whose train row is longer than k_test_masked's LDS piece (searched in memory), test items that are train
+    items at the start, inside and at the end of rows.  Against the oracle, bit for bit; RM_DEBUG_NO_POS_FLAT: the by-slot kernels."""
+    from recometrics_amd.synth import make_factors
+    rng = np.random.default_rng(4242)
+    m, n = 333, 30011
+    A, B = make_factors(m, n, k, dtype, seed=9)
+    lens = [0, 1, 1, 63, 64, 65, 2, 0, 0, 127, 5, 62, 1, 200, 0, 31, 33, 700, 1, 1]
+    rows_tr, rows_te = [], []
+    for u in range(m):
+        nte = lens[u % len(lens)]
+        ntr = 0 if u % 17 == 5 else (11000 if u == 40 else int(rng.integers(1, 400)))
+        items = rng.permutation(n)[: nte + ntr]
+        te, tr = np.sort(items[:nte]), np.sort(items[nte:])
+        if nte and u % 3 == 0:                                     # some test items are train items too: first, middle, last of the row
+            tr = np.union1d(tr, te[[0, nte // 2, nte - 1]])
+        rows_te.append(te); rows_tr.append(tr)
+    def csr(rows):
+        indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+        return indptr, np.concatenate(rows).astype(np.int32)
+    tep, tei = csr(rows_te)
+    pr = {"A": A, "B": B, "train": csr(rows_tr), "test": (tep, tei, rng.integers(1, 21, size=tei.shape[0]).astype(dtype))}
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    _check_against_oracle(hip, oracle, pr, 7, dtype=dtype)
+    _check_against_oracle(hip, oracle, pr, 7, dtype=dtype, cold=False)                # (users without train items are not evaluated)
+
+
 def test_second_plan_keeps_the_users_the_tie_noise_flagged(hip, monkeypatch):
     """fp32 tie noise + a budget too small for the streamed users' score rows: the plan is made twice (second time with the long rows
     in chunks), while the positives' scores -- whose kernel flags the users with a test item the noise can move, and counts them --
