@@ -621,20 +621,20 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             HIP_CHECK(hipMemsetAsync((char *)plan + at + sizeof(int), 0, sizeof(Plan) - at - sizeof(int), stream));
         }
         hipLaunchKernelGGL(k_classify, dim3(cdiv(m, 1024)), dim3(1024), 0, stream, ca);
-        // ---- beside it, on the side stream: everything that reads the index arrays and the factors ----
-        // the CSR rows' validation (gated on the index pointers k_classify has just checked), max |A| and max |B|, and the dense
-        // train rows (fp32, small item counts; set_train_bits), which depend on the CSR inputs alone: they run during the plan chain
-        // and the plan read-back -- the host's one wait of the call, otherwise an idle device -- and beside the packing kernels.
-        // Whether the rows also mark the test items (`mask_test`) is only decided behind the read-back; the guess here is the usual
-        // answer, and a wrong guess costs one more launch of the kernel behind it.
+        // ---- beside it, on the side stream: what reads the index arrays and the factors ----
+        // the CSR rows' validation (gated on the index pointers k_classify has just checked), max |A| and max |B| (the plan carries the
+        // verdicts and the maxima: its read-back waits for them), then the dense train rows (fp32, small item counts; set_train_bits),
+        // which depend on the CSR inputs alone: they run during the rest of the plan chain, the read-back -- the host's one wait of
+        // the call -- and the positives' scores.  Whether the rows also mark the test items (`mask_test`) is only decided behind the
+        // read-back; the guess here is the usual answer, and a wrong guess costs one more launch of the kernel behind it.
         hipStream_t aux = use_side ? fork_side() : stream;
         if (!c.csr_checked) launch_csr_index_checks(m, n, c.train_p, c.train_i, c.nnz_train, c.test_p, c.test_i, c.nnz_test, plan, aux);
         hipLaunchKernelGGL(k_absmax<T>, dim3(512), dim3(256), 0, aux, c.A, c.lda, (long long)m, k, &plan->amax_a, &plan->nonfinite);
         if (!items_known) hipLaunchKernelGGL(k_absmax<T>, dim3(1024), dim3(256), 0, aux, c.B, c.ldb, (long long)n, k, &plan->amax_b, &plan->nonfinite_b);
         if (use_side) HIP_CHECK(hipEventRecord(cx.side_ev[2], aux));                  // the plan read-back waits for this much of the side stream
-        // The dense train rows (463 MB of writes at BASELINE C2) follow at once: four resident blocks per CU leave half of the wave
-        // slots to the plan's kernels and the read-back's copy.  With the positives' scores by entry they also say which test items
-        // are train items (`ent_masked`): a bit of the row they have just built.
+        // (463 MB of writes at BASELINE C2; four resident blocks per CU leave half of the wave slots to the plan's kernels and the
+        // read-back's copy.  With the positives' scores by entry the kernel also says which test items are train items, `ent_masked`:
+        // a bit of the row it has just built.)
         if (attempt == 0 && std::is_same<T, float>::value && use_side && !c.ext_bits && dense_ok && !g_sw.no_early_bits) {
             SweepArgs probe{};
             const bool guess = want_auc && !ext_topk && !g_sw.no_test_mask;

@@ -17,4 +17,6 @@ run RM_BATCH_USERS=1024
 run RM_BATCH_USERS=1024 RM_DEBUG_NO_NOISE_BESIDE_LAST=1
 run RM_STREAM_BUDGET_MB=0
 run RM_DEBUG_NO_SPEC=1 RM_DEBUG_NO_PENDING=1
+run RM_DEBUG_NO_POS_FLAT=1
+run RM_DEBUG_NO_POS_BESIDE=1 RM_DEBUG_NO_EARLY_BITS=1
 run FUZZ_TIES=1
