@@ -621,17 +621,43 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             HIP_CHECK(hipMemsetAsync((char *)plan + at + sizeof(int), 0, sizeof(Plan) - at - sizeof(int), stream));
         }
         hipLaunchKernelGGL(k_classify, dim3(cdiv(m, 1024)), dim3(1024), 0, stream, ca);
-        // ---- beside it, on the side stream: what reads the index arrays and the factors ----
-        // the CSR rows' validation (gated on the index pointers k_classify has just checked), max |A| and max |B| (the plan carries the
-        // verdicts and the maxima: its read-back waits for them), then the dense train rows (fp32, small item counts; set_train_bits),
-        // which depend on the CSR inputs alone: they run during the rest of the plan chain, the read-back -- the host's one wait of
-        // the call -- and the positives' scores.  Whether the rows also mark the test items (`mask_test`) is only decided behind the
-        // read-back; the guess here is the usual answer, and a wrong guess costs one more launch of the kernel behind it.
-        hipStream_t aux = use_side ? fork_side() : stream;
+        // (the two forks behind k_classify, recorded BEFORE the rest of the chain is enqueued: the host needs ~4 us per launch, and the
+        // chain's kernels used to reach the device 60 us late, behind everything that was enqueued for the other streams)
+        if (use_side) {
+            side_stream(); pos_stream();
+            HIP_CHECK(hipEventRecord(cx.side_ev[0], stream));
+            HIP_CHECK(hipEventRecord(cx.pos_ev[0], stream));
+        }
+        if (tile_total) {
+            hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(1024), 0, stream, user_nslots, uslot_base, m, tile_total);
+            hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, tile_total, tile_offset, n_tiles, &plan->n_slots, plan, GU);
+        } else {
+            hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, user_nslots, uslot_base, m, &plan->n_slots, plan, GU);
+        }
+        AssignArgs aa{m, c.test_p, flags, user_nslots, uslot_base, want_auc ? 1 : 0, plan, slot_user, slot_chunk, slot_index, slot_j, sc_user, sc_chunk,
+                      ext_topk ? 1 : 0, tile_offset};
+        hipLaunchKernelGGL(k_assign_slots, dim3(cdiv(m, ASSIGN_THREADS)), dim3(ASSIGN_THREADS), 0, stream, aa);
+        hipLaunchKernelGGL(k_block_tables, dim3(1), dim3(1024), 0, stream, plan, slot_j, gj, grow, GU);
+        // ---- beside it: what reads the index arrays and the factors ----
+        // On the side stream the CSR rows' validation (gated on the index pointers k_classify has just checked), then the dense train
+        // rows (fp32, small item counts; set_train_bits), which depend on the CSR inputs alone: they run during the rest of the plan
+        // chain, the read-back -- the host's one wait of the call -- and the positives' scores.  Whether the rows also mark the test
+        // items (`mask_test`) is only decided behind the read-back; the guess here is the usual answer, and a wrong guess costs one
+        // more launch of the kernel behind it.  On the positives' stream max |A| and max |B| and the user of every test entry.  The
+        // plan carries the checks' verdicts and the maxima: its read-back waits for both streams.
+        hipStream_t aux = stream, aux2 = stream;
+        if (use_side) {
+            aux = cx.side_stream; aux2 = cx.pos_stream;
+            HIP_CHECK(hipStreamWaitEvent(aux, cx.side_ev[0], 0)); side_guard.pending++;
+            HIP_CHECK(hipStreamWaitEvent(aux2, cx.pos_ev[0], 0)); pos_guard.st = aux2;
+        }
         if (!c.csr_checked) launch_csr_index_checks(m, n, c.train_p, c.train_i, c.nnz_train, c.test_p, c.test_i, c.nnz_test, plan, aux);
-        hipLaunchKernelGGL(k_absmax<T>, dim3(512), dim3(256), 0, aux, c.A, c.lda, (long long)m, k, &plan->amax_a, &plan->nonfinite);
-        if (!items_known) hipLaunchKernelGGL(k_absmax<T>, dim3(1024), dim3(256), 0, aux, c.B, c.ldb, (long long)n, k, &plan->amax_b, &plan->nonfinite_b);
-        if (use_side) HIP_CHECK(hipEventRecord(cx.side_ev[2], aux));                  // the plan read-back waits for this much of the side stream
+        if (use_side) HIP_CHECK(hipEventRecord(cx.side_ev[2], aux));
+        hipLaunchKernelGGL(k_absmax<T>, dim3(512), dim3(256), 0, aux2, c.A, c.lda, (long long)m, k, &plan->amax_a, &plan->nonfinite);
+        if (!items_known) hipLaunchKernelGGL(k_absmax<T>, dim3(1024), dim3(256), 0, aux2, c.B, c.ldb, (long long)n, k, &plan->amax_b, &plan->nonfinite_b);
+        if (use_side) HIP_CHECK(hipEventRecord(cx.pos_ev[2], aux2));
+        // (the user of every test entry, for the positives' scores by entry: index pointers only)
+        if (attempt == 0 && flat_early) hipLaunchKernelGGL(k_entry_users, dim3(cdiv(cdiv(m, WAVE) * WAVE, 256)), dim3(256), 0, aux2, m, c.test_p, ent_user, plan);
         // (463 MB of writes at BASELINE C2; four resident blocks per CU leave half of the wave slots to the plan's kernels and the
         // read-back's copy.  With the positives' scores by entry the kernel also says which test items are train items, `ent_masked`:
         // a bit of the row it has just built.)
@@ -648,45 +674,27 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
                 bits_early = true; bits_early_masked = guess; masked_from_bits = flat_early;
             }
         }
-        if (attempt == 0 && flat_early) {
-            // The scores of the test entries (k_pos_scores_flat) and the user of every entry depend on the inputs and on the users'
-            // flags alone: they run on the positives' stream, the scores beside the read-back and the host's work behind it.  The
-            // scores index the item factors by the test items: they follow the index checks (and return when those found a defect).
-            // Without dense train rows k_test_masked says which test items are train items, behind the scores.
-            hipStream_t es = stream;
-            if (use_side) {
-                es = pos_stream();
-                HIP_CHECK(hipEventRecord(cx.pos_ev[0], stream));
-                HIP_CHECK(hipStreamWaitEvent(es, cx.pos_ev[0], 0));
-                pos_guard.st = es;
-            }
-            hipLaunchKernelGGL(k_entry_users, dim3(cdiv(cdiv(m, WAVE) * WAVE, 256)), dim3(256), 0, es, m, c.test_p, ent_user, plan);
-            if (!use_side) launch_flat(es);
-        }
-        if (tile_total) {
-            hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(1024), 0, stream, user_nslots, uslot_base, m, tile_total);
-            hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, tile_total, tile_offset, n_tiles, &plan->n_slots, plan, GU);
-        } else {
-            hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, user_nslots, uslot_base, m, &plan->n_slots, plan, GU);
-        }
-        AssignArgs aa{m, c.test_p, flags, user_nslots, uslot_base, want_auc ? 1 : 0, plan, slot_user, slot_chunk, slot_index, slot_j, sc_user, sc_chunk,
-                      ext_topk ? 1 : 0, tile_offset};
-        hipLaunchKernelGGL(k_assign_slots, dim3(cdiv(m, ASSIGN_THREADS)), dim3(ASSIGN_THREADS), 0, stream, aa);
-        hipLaunchKernelGGL(k_block_tables, dim3(1), dim3(1024), 0, stream, plan, slot_j, gj, grow, GU);
-        if (use_side) HIP_CHECK(hipStreamWaitEvent(stream, cx.side_ev[2], 0));
+        if (use_side) { HIP_CHECK(hipStreamWaitEvent(stream, cx.side_ev[2], 0)); HIP_CHECK(hipStreamWaitEvent(stream, cx.pos_ev[2], 0)); }
         HIP_CHECK(hipMemcpyAsync(cx.pinned_plan, plan, sizeof(Plan), hipMemcpyDeviceToHost, stream));
-        if (attempt == 0 && flat_early && use_side) {
-            // (behind the plan's last kernel and the copy, which have waited for the index checks: the scores' blocks take every wave
-            // slot they find, and a plan kernel's block of 1,024 threads then waits for sixteen slots of one CU to fall free at once --
-            // measured: the read-back 0.2 ms late)
-            HIP_CHECK(hipEventRecord(cx.pos_ev[3], stream));
-            HIP_CHECK(hipStreamWaitEvent(cx.pos_stream, cx.pos_ev[3], 0));
-            launch_flat(cx.pos_stream);
-            HIP_CHECK(hipEventRecord(cx.pos_ev[1], cx.pos_stream));
+        if (attempt == 0 && flat_early) {
+            // The scores of the test entries (k_pos_scores_flat) depend on the inputs and on the users' flags alone: they run on the
+            // positives' stream beside the read-back and the host's work behind it.  They index the item factors by the test items, so
+            // they follow the index checks (and return when those found a defect) -- and they follow the plan's last kernel and the
+            // copy: their blocks take every wave slot they find, and a plan kernel's block of 1,024 threads then waits for sixteen
+            // slots of one CU to fall free at once (measured: the read-back 0.2 ms late).  Without dense train rows k_test_masked says
+            // which test items are train items, behind the scores.
+            if (use_side) {
+                HIP_CHECK(hipEventRecord(cx.pos_ev[3], stream));
+                HIP_CHECK(hipStreamWaitEvent(cx.pos_stream, cx.pos_ev[3], 0));
+            }
+            launch_flat(aux2);
+            if (use_side) HIP_CHECK(hipEventRecord(cx.pos_ev[1], cx.pos_stream));
         }
         HIP_CHECK(hipStreamSynchronize(stream));
-        // (the stream has waited for side_ev[2]: only the dense train rows of the first attempt may still be running over there)
+        // (the stream has waited for the checks and the maxima: only the dense train rows of the first attempt may still be running on
+        // the side stream, only the positives' scores on theirs)
         if (use_side && !(attempt == 0 && bits_early)) side_guard.pending--;
+        if (use_side && !flat_early) pos_guard.st = nullptr;
         hp = *cx.pinned_plan;
         throw_csr_defects(hp, c, cx);
         // the streamed users' score rows must fit the budget; if not (memory pressure), plan again with those users in chunks
