@@ -918,6 +918,8 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
                 pos_guard.st = ps;
             }
             PosArgs<T> pb = pa;
+            // (with the scores by entry the positives' stream is busy with them: the tables are filled on the call's stream meanwhile)
+            const hipStream_t fill = (flat && pos_beside) ? stream : ps;
             if (n_stream > 0) {
                 const size_t nz = (size_t)std::max<long long>(c.nnz_test, 1);
                 spos_score = (T *)ws.get("spos_score", sizeof(T) * nz);
@@ -925,11 +927,12 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
                 shist = (unsigned *)ws.get("shist", sizeof(unsigned) * nz);
                 pb.stream = 1; pb.spos_score = spos_score; pb.spos_item = spos_item;
                 // (+inf in every rank: entries that repeat an item -- a non-canonical CSR row -- share a rank and leave one unused)
-                hipLaunchKernelGGL(k_init_tables<T>, dim3(cdiv((long long)nz, 256)), dim3(256), 0, ps, spos_score, shist, (long long)nz);
+                hipLaunchKernelGGL(k_init_tables<T>, dim3(cdiv((long long)nz, 256)), dim3(256), 0, fill, spos_score, shist, (long long)nz);
             }
             const int nsc = hp.n_stream_chunks;
             hipLaunchKernelGGL(k_init_tables<T>, dim3(cdiv(rows * GU, 256)), dim3(256), 0, stream, pos_score, hist, rows * GU);
             if (flat) {
+                if (pos_beside && n_stream > 0) { HIP_CHECK(hipEventRecord(cx.pos_ev[2], stream)); HIP_CHECK(hipStreamWaitEvent(ps, cx.pos_ev[2], 0)); }
                 // (the scores are the last thing on the positives' stream: whoever is not on it waits for them)
                 if (use_side) { HIP_CHECK(hipStreamWaitEvent(stream, cx.pos_ev[1], 0)); if (!pos_beside) pos_guard.st = nullptr; }
             } else {
