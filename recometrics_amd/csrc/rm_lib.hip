@@ -1540,14 +1540,17 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
         const long long row = (((long long)n + 191) / 192 * 192) * (long long)sizeof(T);    // with a margin for what run() allocates first
         batch = std::max<long long>(1, std::min<long long>(batch, stream_budget_bytes(ws) * 3 / 4 / row));
     }
-    // batch boundaries: a first batch of an eighth of the users (whole kilo-users) when the range is large enough for the
-    // pipeline to matter -- its upload is the only one nothing hides --, then three times the batch before (its upload hides
-    // behind the batch before, whose kernels take ~2.5 x as long per user as the copy), at most `batch` users.  BASELINE C2:
-    // 17,408 + 52,224 + 68,861 users, 10.4 ms per call against 10.6 with (1/4, 3/4) and 11.7 without the second context
-    // (profiles/r3_host_entry.txt)
+    // batch boundaries: a first batch of a QUARTER of the users (whole kilo-users) when the range is large enough for the pipeline to
+    // matter -- its upload is the only one nothing hides --, then three times the batch before (its upload hides behind the batch
+    // before, whose kernels take ~2.5 x as long per user as the copy), at most `batch` users.  BASELINE C2: 34,816 + 103,677 users.
+    // Every batch pays the fixed parts of preparation and finalisation again and its plan only comes back when the sweep in front
+    // of it has drained, so fewer batches win once the first upload is paid for: round 5 (preparation 0.88 -> 0.56 ms) 9.6 ms per
+    // call against 9.9 with (1/8, 3/8, 1/2), and with the tie noise 10.3 against 10.85 (one batch fewer for the exact pass to
+    // wait behind; `profiles/r5_host_entry.txt`).  Round 3, when a batch's fixed parts cost twice as much: (1/8, 3/8, 1/2) 10.4,
+    // (1/4, 3/4) 10.6, without the second context 11.7 (`profiles/r3_host_entry.txt`).
     std::vector<long long> cuts{0};
     {
-        const int r0 = g_sw.ramp > 0 ? std::max(2, g_sw.ramp) : 8;    // (RM_DEBUG_RAMP, A/B timing: another first fraction; default: an eighth)
+        const int r0 = g_sw.ramp > 0 ? std::max(2, g_sw.ramp) : 4;    // (RM_DEBUG_RAMP, A/B timing: another first fraction; default: a quarter)
         long long next = (forced || m <= 16384) ? batch : std::min<long long>(batch, std::max<long long>(8192, ((long long)m / r0 + 1023) / 1024 * 1024));
         while (cuts.back() < m) {
             long long b1 = std::min<long long>(m, cuts.back() + next);
