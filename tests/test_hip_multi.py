@@ -369,11 +369,11 @@ def test_k_metrics_beyond_the_lists_in_user_batches(hip, monkeypatch, noise):
 
 
 def test_pipelined_uploads_equal_one_batch(hip, monkeypatch):
-    """large user ranges are uploaded and evaluated as a ramp of batches (m/16, m/8, ...: the rows of batch i + 1 travel while
-    batch i computes); every output equals the single-batch call bit for bit, also with the API-default tie noise and through
+    """large user ranges are uploaded and evaluated as a ramp of batches (a quarter of the users, then three times the batch before:
+    the rows of batch i + 1 travel while batch i computes); every output equals the single-batch call bit for bit, also with the API-default tie noise and through
     rm_rank_*"""
     from recometrics_amd.synth import make_problem
-    pr = make_problem(40000, 1200, 16, np.float32, mean_c=30, seed=15)     # > 16,384 users: 8,192 + 24,576 + 7,232, alternating between two contexts
+    pr = make_problem(40000, 1200, 16, np.float32, mean_c=30, seed=15)     # > 16,384 users: 10,240 + 29,760, on two contexts
     trp, tri = pr["train"]; tep, tei, tev = pr["test"]
     for noise in (False, True):
         got = hip.calc_metrics(pr["A"], 16, pr["B"], 16, trp, tri, tep, tei, tev, 5, ALL, False, noise, True, 2, 1, 1, 3)
