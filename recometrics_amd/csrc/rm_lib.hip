@@ -330,7 +330,15 @@ inline void dispatch_sweep(bool auc, bool dump, bool llds, int, int NG, dim3 gri
 inline void pack_operands(const float *A, size_t lda, const float *B, size_t ldb, int n, int k, int NG, int tile_items, const int *slot_user,
                           int n_slots, float4 *Ap, long long ap, float4 *Bp, long long bp, hipStream_t stream, bool items = true)
 {
-    if (items) hipLaunchKernelGGL(k_pack_items<float>, dim3(cdiv(bp, 256)), dim3(256), 0, stream, B, ldb, n, k, NG, tile_items, Bp, bp);
+    if (items) {
+        const size_t lds = pack_items_tile_lds(NG, tile_items);
+        const long long tiles = bp / ((long long)NG * 2 * tile_items);
+        if (lds <= 96 * 1024 && tiles * NG * 2 * tile_items == bp) {
+            static bool once = [] { (void)hipFuncSetAttribute((const void *)k_pack_items_tile<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); return true; }();
+            (void)once;
+            hipLaunchKernelGGL(k_pack_items_tile<float>, dim3((unsigned)tiles), dim3(256), lds, stream, B, ldb, n, k, NG, tile_items, Bp);
+        } else hipLaunchKernelGGL(k_pack_items<float>, dim3(cdiv(bp, 256)), dim3(256), 0, stream, B, ldb, n, k, NG, tile_items, Bp, bp);
+    }
     hipLaunchKernelGGL(k_pack_users<float>, dim3(cdiv(ap, 256)), dim3(256), 0, stream, A, lda, k, NG, slot_user, n_slots, Ap, ap);
 }
 inline void pack_operands(const double *A, size_t lda, const double *B, size_t ldb, int n, int k, int NG, int, const int *slot_user,
