@@ -12,6 +12,7 @@ namespace rm {
 constexpr int MAX_PARTS = 128;
 constexpr int FIN_THREADS = 128;      // block size of k_finalize
 constexpr int FIN_TOPV = 64;          // sorted buffer of the largest test values (ideal DCG) per thread
+constexpr int HEAVY_TOPV_MAX = 256;   // ... per user in k_top_values' output (k_metrics beyond it: the lists are out of reach anyway, ext_topk)
 template <class T> inline size_t finalize_lds_bytes(int K, int n_part) { return (sizeof(T) * (size_t)(K < FIN_TOPV ? K : FIN_TOPV) + 4 * (size_t)n_part) * FIN_THREADS; }
 
 // per-slot result of the rank-histogram walk (k_auc_slots), combined per user by k_finalize
@@ -29,6 +30,7 @@ template <class T, class S> struct FinalArgs {     // T = real_t of inputs/outpu
     T *heavy_topv;               // [m][min(K, FIN_TOPV)] largest test values (descending) of users with more than
     unsigned char *heavy_nan;    // [m]    ... HEAVY_NPOS test items, and whether any of their values is NaN (k_top_values)
     const int *heavy_users; int n_heavy;     // those users (k_classify)
+    int heavy_npos, heavy_ld;                // ... rows longer than heavy_npos; heavy_topv holds heavy_ld = min(K, HEAVY_TOPV_MAX) values per user
     const double *log2tab;
     T *p, *tp, *r, *ap, *tap, *ndcg, *hit, *rr, *roc, *pr;
     Entry<S> *merged;            // [m][K]   final ordered top-K (also the rm_rank_* output)
@@ -609,9 +611,9 @@ __global__ void k_top_values(FinalArgs<T, S> a)
     const int u = a.heavy_users[w];
     const int te0 = a.test_p[u], npos = a.test_p[u + 1] - te0;
     const int L = a.K < npos ? a.K : npos;
-    if (L > FIN_TOPV) return;
+    if (L > a.heavy_ld) return;
     const T *tv = a.test_v + te0;
-    T *out = a.heavy_topv + (size_t)u * (a.K < FIN_TOPV ? a.K : FIN_TOPV);
+    T *out = a.heavy_topv + (size_t)u * a.heavy_ld;
     bool any_nan = false;
     T pv = 0; int pi = -1;
     // rows up to 64 * CACHE entries are read once into registers (all loads in flight together); longer ones are
@@ -890,10 +892,15 @@ __global__ void k_finalize(FinalArgs<T, S> a)
             }
             ov = bv; oi = bi; return found;
         };
-        if (buffered && npos > HEAVY_NPOS) {                      // computed by k_top_values, one wave per such user
-            const T *hv = a.heavy_topv + (size_t)u * (K < FIN_TOPV ? K : FIN_TOPV);
+        // (k_top_values' list, one wave per such user: rows longer than a.heavy_npos -- HEAVY_NPOS, or FIN_TOPV when k_metrics is beyond
+        // the buffer: the repeated selection below is L x npos DEPENDENT loads on one thread, 2.4 ms for ONE user with 70 test items
+        // at K = 100 among BASELINE C4's 8,192 and seconds for a row of thousands)
+        const bool listed = a.heavy_topv && npos > a.heavy_npos && L <= a.heavy_ld;
+        const T *hv = listed ? a.heavy_topv + (size_t)u * a.heavy_ld : nullptr;
+        if (listed) has_nan_val = a.heavy_nan[u] != 0;
+        if (listed && buffered) {
             for (int i = 0; i < L; i++) topv[i * FIN_THREADS] = hv[i];
-            has_nan_val = a.heavy_nan[u] != 0;
+        } else if (listed) {
         } else if (buffered) {
             int cnt = 0;
             T kth = 0;                                               // topv[L - 1] once the buffer is full
@@ -922,10 +929,12 @@ __global__ void k_finalize(FinalArgs<T, S> a)
         T pv = 0; int pi = -1; bool hp = false;
         auto next_value = [&](int i) -> T {
             if (buffered) return topv[i * FIN_THREADS];
+            if (listed) return hv[i];
             T x; int xi; pick_next(hp, pv, pi, x, xi); hp = true; pv = x; pi = xi; return x;
         };
         T vmaxv = 0, vlast = 0;
         if (buffered) { vmaxv = topv[0]; vlast = topv[(L - 1) * FIN_THREADS]; }
+        else if (listed) { vmaxv = hv[0]; vlast = hv[L - 1]; }
         else {
             for (int i = 0; i < L; i++) { const T x = next_value(i); if (i == 0) vmaxv = x; vlast = x; }
             hp = false; pv = 0; pi = -1;

@@ -532,6 +532,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     ClassifyArgs ca{m, n, K, c.train_p, c.test_p, req, c.cold ? 1 : 0, min_items_pool, min_pos_test, want_auc ? 1 : 0,
                     flags, user_nslots, heavy_users, plan};
     ca.only = c.only_users;
+    ca.heavy_npos = K > FIN_TOPV ? FIN_TOPV : HEAVY_NPOS;
     // the caller's CSR arrays are validated in front of everything that indexes by them (an out-of-range column index in
     // k_train_bits would be a memory fault; on the CPU reference it is a segfault): the index pointers by k_classify itself, the
     // 80 MB of indices of BASELINE C2 by k_check_csr_rows beside the plan chain (~40 us)
@@ -844,8 +845,10 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     // rounds -- latency, 0.16 ms at BASELINE C2): they depend on the test rows alone, so they are computed on the side stream
     // beside the preparation kernels instead of between the sweep and k_finalize, which waits for them
     bool topv_pending = false;
+    fa.heavy_npos = ca.heavy_npos;
     if (fa.ndcg && hp.n_heavy > 0) {
-        fa.heavy_topv = (T *)ws.get("heavy_topv", sizeof(T) * (size_t)m * std::min(K, FIN_TOPV));
+        fa.heavy_ld = std::min(K, HEAVY_TOPV_MAX);
+        fa.heavy_topv = (T *)ws.get("heavy_topv", sizeof(T) * (size_t)m * (size_t)fa.heavy_ld);
         fa.heavy_nan = (unsigned char *)ws.get("heavy_nan", (size_t)m);
         fa.heavy_users = heavy_users; fa.n_heavy = hp.n_heavy;
         hipStream_t tv_stream = stream;

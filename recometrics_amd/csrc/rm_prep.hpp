@@ -23,6 +23,7 @@ struct ClassifyArgs {
     int allow_stream;            // 1 = users with more than POS_CHUNK test items are streamed (the host has a budget for score rows; it
                                  //     looks at the count afterwards and plans again without when the rows do not fit)
     int check_ptr;               // 1 = validate the index pointers of every row here (first pass of a call over these users)
+    int heavy_npos;              // test rows longer than this are listed in `heavy_users` (HEAVY_NPOS; FIN_TOPV when k_metrics is beyond k_finalize's buffer)
     long long nnz_train, nnz_test;
 };
 
@@ -154,7 +155,9 @@ __global__ void k_classify(ClassifyArgs a)
     }
     // counts are aggregated per block in LDS, then one global atomic per block and class (the counters share a line)
     __shared__ int blk_count[N_CLASSES + 3];                      // [N_CLASSES] = evaluated users, [+1] long rows, [+2] the longest of them
+    __shared__ int blk_heavy[2];                                  // heavy users of the block, their first place in the list
     if (threadIdx.x < N_CLASSES + 3) blk_count[threadIdx.x] = 0;
+    if (threadIdx.x < 2) blk_heavy[threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const unsigned long long act = __ballot(!isnan_user);
@@ -173,9 +176,15 @@ __global__ void k_classify(ClassifyArgs a)
         if (lane == __ffsll((long long)lm) - 1) { atomicAdd(&blk_count[N_CLASSES + 1], __popcll(lm)); atomicMax(&blk_count[N_CLASSES + 2], mx); }
     }
     if (live) { a.flags[u] = f; a.user_nslots[u] = nsl; }
-    if (live && !isnan_user && npos > HEAVY_NPOS) a.heavy_users[atomicAdd(&a.plan->n_heavy, 1)] = u;      // rare
-    if (live && !isnan_user && only_ndcg) atomicAdd(&a.plan->n_only_ndcg, 1);                              // rarer
+    // (the list's places are taken per block: with k_metrics beyond k_finalize's buffer every row of more than 64 test items is
+    // listed -- a fifth of the users at BASELINE C2's shape -- and one returning atomic per user on one counter is 10 ns each)
+    const bool heavy = live && !isnan_user && npos > a.heavy_npos;
+    const int heavy_at = heavy ? atomicAdd(&blk_heavy[0], 1) : 0;
+    if (live && !isnan_user && only_ndcg) atomicAdd(&a.plan->n_only_ndcg, 1);                              // rare
     __syncthreads();
+    if (threadIdx.x == 0 && blk_heavy[0]) blk_heavy[1] = atomicAdd(&a.plan->n_heavy, blk_heavy[0]);
+    __syncthreads();
+    if (heavy) a.heavy_users[blk_heavy[1] + heavy_at] = u;
     if (threadIdx.x < N_CLASSES && blk_count[threadIdx.x]) atomicAdd(&a.plan->class_count[threadIdx.x], blk_count[threadIdx.x]);
     if (threadIdx.x == N_CLASSES && blk_count[N_CLASSES]) atomicAdd(&a.plan->n_active, blk_count[N_CLASSES]);
     if (threadIdx.x == N_CLASSES + 1 && blk_count[N_CLASSES + 1]) { atomicAdd(&a.plan->n_long, blk_count[N_CLASSES + 1]); atomicMax(&a.plan->max_npos, blk_count[N_CLASSES + 2]); }

@@ -20,6 +20,10 @@ p = DeviceProblem(torch, torch.device("cuda", 0), m, n, k, mean_c, seed, K, dtyp
 p.noise = bool(os.environ.get("NS_NOISE"))
 if os.environ.get("NS_TEST_DIV"):       # experiment: the test items squeezed into the first n/DIV items (rows stay sorted; repeats allowed)
     p.tei = torch.div(p.tei, int(os.environ["NS_TEST_DIV"]), rounding_mode="floor").to(p.tei.dtype)
+if os.environ.get("NS_DROP"):            # experiment: metrics that are not asked for (indices into METRIC_ORDER, comma separated)
+    drop = [int(x) for x in os.environ["NS_DROP"].split(",")]
+    full = p.out_ptrs
+    p.out_ptrs = lambda o: [0 if i in drop else q for i, q in enumerate(full(o))]
 dt, sw, pr, fi, tm = measure(torch, dist, binding, p, steps, 1, 1, None)
 tf = 2.0 * n * k * m / (sw * 1e-3) / 1e12
 peak = 157.3 if dtype == np.float32 else 78.6

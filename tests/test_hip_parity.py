@@ -337,6 +337,36 @@ def test_scores_of_the_test_entries_by_entry(hip, oracle, dtype, k, env, monkeyp
     _check_against_oracle(hip, oracle, pr, 7, dtype=dtype, cold=False)                # (users without train items are not evaluated)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("K", [65, 100, 256])
+def test_ideal_dcg_with_k_metrics_beyond_the_finalize_buffer(hip, oracle, dtype, K):
+    """NDCG's ideal DCG needs the min(K, positives) largest test VALUES in order.  k_finalize sorts up to 64 of them in its own
+    buffer; with k_metrics > 64 every row of more than 64 test items goes through k_top_values (a wavefront per user, its list read
+    back by k_finalize) instead of a repeated selection on one thread.  Rows of 1 ... 600 test items around every threshold (64, K,
+    256), values with ties, zeros and negatives (the reference stops the ideal sum at the first non-positive value when the K-th
+    is negative, src/recometrics.hpp:868-961), single and cumulative outputs -- against the oracle, bit for bit."""
+    from recometrics_amd.synth import make_factors
+    rng = np.random.default_rng(77 + K)
+    lens = [1, 40, 63, 64, 65, 66, 99, 100, 101, 128, 200, 255, 256, 257, 300, 600]
+    m, n, k = 64, 6000, 16
+    A, B = make_factors(m, n, k, dtype, seed=21)
+    rows_tr, rows_te, vals = [], [], []
+    for u in range(m):
+        nte = lens[u % len(lens)]
+        items = rng.permutation(n)[: nte + 50]
+        rows_te.append(np.sort(items[:nte])); rows_tr.append(np.sort(items[nte:]))
+        kind = u // len(lens)
+        v = rng.integers(-3, 6, size=nte) if kind % 2 == 0 else rng.integers(1, 4, size=nte)       # with / without non-positive values
+        if kind == 3 and nte > 2: v[:] = 2                                                         # every value tied
+        vals.append(v.astype(dtype))
+    def csr(rows):
+        indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+        return indptr, np.concatenate(rows).astype(np.int32)
+    tep, tei = csr(rows_te)
+    pr = {"A": A, "B": B, "train": csr(rows_tr), "test": (tep, tei, np.concatenate(vals).astype(dtype))}
+    _check_against_oracle(hip, oracle, pr, K, dtype=dtype)
+
+
 def test_second_plan_keeps_the_users_the_tie_noise_flagged(hip, monkeypatch):
     """fp32 tie noise + a budget too small for the streamed users' score rows: the plan is made twice (second time with the long rows
     in chunks), while the positives' scores -- whose kernel flags the users with a test item the noise can move, and counts them --
