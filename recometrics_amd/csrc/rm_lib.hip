@@ -844,9 +844,12 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     // ideal-DCG values of the users with very long test rows (k_top_values: a wavefront per such user, a chain of K dependent
     // rounds -- latency, 0.16 ms at BASELINE C2): they depend on the test rows alone, so they are computed on the side stream
     // beside the preparation kernels instead of between the sweep and k_finalize, which waits for them
+    // (launched BEHIND the operand packing on the side stream, which the sweep waits for: with k_metrics > 64 every row of more than
+    // 64 test items is listed and the kernel is half a millisecond at BASELINE C2's shape)
     bool topv_pending = false;
     fa.heavy_npos = ca.heavy_npos;
-    if (fa.ndcg && hp.n_heavy > 0) {
+    auto launch_top_values = [&]() {
+        if (!(fa.ndcg && hp.n_heavy > 0)) return;
         fa.heavy_ld = std::min(K, HEAVY_TOPV_MAX);
         fa.heavy_topv = (T *)ws.get("heavy_topv", sizeof(T) * (size_t)m * (size_t)fa.heavy_ld);
         fa.heavy_nan = (unsigned char *)ws.get("heavy_nan", (size_t)m);
@@ -855,7 +858,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         if (use_side) tv_stream = fork_side();
         hipLaunchKernelGGL((k_top_values<T, T>), dim3(cdiv((long long)hp.n_heavy * WAVE, 256)), dim3(256), 0, tv_stream, fa);
         if (use_side) { HIP_CHECK(hipEventRecord(cx.side_ev[3], tv_stream)); topv_pending = true; }
-    }
+    };
     const int stream_parts = (int)cdiv(n, STREAM_RANK_THREADS * STREAM_RANK_ITEMS);
     const int stream_ipt = ((int)cdiv(n, (long long)stream_parts * STREAM_RANK_THREADS) + 7) / 8 * 8;     // equal pieces of the row
     auto rank_streamed_rows = [&](int r0, int r1, hipStream_t st) {
@@ -887,6 +890,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             if (!bits_early) side_guard.pending++;
         }
         cx.packed_tag = c.items_tag; cx.packed_tile = tile_items; cx.packed_ng = NG; cx.packed_ptr = (const void *)Bp;
+        launch_top_values();
 
         // ---- dense train rows (fp32, small item counts) ----
         // (measured: on the side stream beside the positives' kernels they gain nothing -- both are bound by memory; r3_ab_c2.txt)
