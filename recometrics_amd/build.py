@@ -71,8 +71,17 @@ def needs_build(extra_flags=()):
 SWEEP_FLAGS = ["-fno-slp-vectorize"]
 
 
-def _compile(src, extra):
+def _headers():
+    root = os.path.dirname(os.path.dirname(CSRC))
+    return glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(os.path.join(root, "include", "*.h"))
+
+
+def _compile(src, extra, incremental=False):
     obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+    # (development only, `build(incremental=True)`: an object newer than its source and every header is kept; the library's own
+    # stamp stays content-based)
+    if incremental and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(p) for p in [os.path.join(CSRC, src)] + _headers()):
+        return obj, ""
     if src.startswith("rm_sweep"):
         extra = list(extra) + SWEEP_FLAGS
     if src.endswith(".cpp"):        # host-only translation unit
@@ -85,14 +94,14 @@ def _compile(src, extra):
     return obj, res.stderr
 
 
-def build(force=False, verbose=False, extra_flags=(), out=None):
+def build(force=False, verbose=False, extra_flags=(), out=None, incremental=False):
     out = out or LIB
     if not force and out == LIB and not needs_build(extra_flags):
         return LIB
     import time
     t_start = time.time()
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
-        results = list(ex.map(lambda s: _compile(s, extra_flags), SOURCES))
+        results = list(ex.map(lambda s: _compile(s, extra_flags, incremental), SOURCES))
     if verbose:
         for _, err in results:
             print(err)

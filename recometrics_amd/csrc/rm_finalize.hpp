@@ -27,7 +27,7 @@ template <class T, class S> struct FinalArgs {     // T = real_t of inputs/outpu
     const Entry<S> *pl; const PartialStat<S> *pst; const unsigned *hist; const S *pos_score;
     const int *pos_item_tab;     // item ids of the tables of sorted positives (same shape as pos_score)
     AucPart *auc_part;           // [n_slots]
-    T *heavy_topv;               // [m][min(K, FIN_TOPV)] largest test values (descending) of users with more than
+    T *heavy_topv;               // [m][heavy_ld] largest test values (descending) of users with more than
     unsigned char *heavy_nan;    // [m]    ... HEAVY_NPOS test items, and whether any of their values is NaN (k_top_values)
     const int *heavy_users; int n_heavy;     // those users (k_classify)
     int heavy_npos, heavy_ld;                // ... rows longer than heavy_npos; heavy_topv holds heavy_ld = min(K, HEAVY_TOPV_MAX) values per user
@@ -48,6 +48,7 @@ template <class T, class S> struct FinalArgs {     // T = real_t of inputs/outpu
     // top-K lists longer than the sweep keeps (k_metrics > 256): EVERY user is streamed and k_select_topk picks its top-K
     // from the stored row straight into `merged`
     int ext_topk; unsigned long long *sel_hi; unsigned *sel_lo; int sel_ld;      // scratch [n_slots][sel_ld] (sel_ld = power of two >= K)
+    int collected;               // `merged` holds the ordered top-K already: k_collect_topk has written it (k_metrics beyond the LDS lists)
     int *noise_flag; Plan *plan; // first pass of an fp32 noise call: flag the users with a top-K score the noise can change
 };
 
@@ -586,6 +587,116 @@ __global__ __launch_bounds__(SELECT_THREADS) void k_select_topk(FinalArgs<T, S> 
     }
 }
 
+// ---- ordered top-K out of the sweep's lane buffers (k_metrics beyond the LDS lists; rm_list.hpp) -----------------------------
+// Block per primary slot.  The user's candidates are spread over the lane buffers of every (item range, sub-tile wave) that swept
+// it -- per wave the entries of its lanes, unsorted, every one at or above the bound the wave had when it appended it.  The block
+// gathers them into LDS as (order-preserving score key, ~item) pairs -- only those that reach the user's final shared bound, a
+// lower bound of its K-th best that at least K entries meet -- together with the entries of the "extra" part of `pl` (the user's own
+// test items, when the sweep ran over rows that mask them: rm_sweep.hpp, k_merge_positives), sorts them by a bitonic network and
+// writes the first K to `merged`, where k_finalize finds them.  When more entries come than LDS holds, it sorts and keeps K in
+// between.  Order: (score desc, item asc) = (key desc, ~item desc).
+constexpr int COLLECT_THREADS = 256;
+constexpr int COLLECT_CAP = 4096;                                // entries in LDS: 32 KB (fp32) / 48 KB (fp64)
+struct CollectGeom {
+    int ublock0, n_ublocks, n_splits, tail_ublocks, tail_splits;   // the sweep's grid (rm_launch.hpp SweepArgs)
+    int nsub, gu, lpu;                                              // sub-tile waves per group, users per group, lanes per user
+    int lane_cap;
+    int extra_part;                                                 // part of `pl` that holds the users' own test items, or -1
+};
+template <class S> struct CollectKey;
+template <> struct CollectKey<float> { typedef unsigned T; };
+template <> struct CollectKey<double> { typedef unsigned long long T; };
+
+template <class T, class S, class ThrT>
+__global__ __launch_bounds__(COLLECT_THREADS) void k_collect_topk(FinalArgs<T, S> a, CollectGeom g, const char *glists, const int *lane_cnt, const ThrT *thr_shared)
+{
+    typedef typename CollectKey<S>::T KeyT;
+    __shared__ KeyT kh[COLLECT_CAP];
+    __shared__ unsigned kl[COLLECT_CAP];
+    __shared__ int sh_cur;
+    const int slot = blockIdx.x, tid = threadIdx.x;
+    if (a.slot_chunk[slot] != 0) return;
+    const int u = a.slot_user[slot];
+    const int K = a.K;
+    const int group = slot / g.gu, ul = slot % g.gu, gi = group % GROUPS_PER_BLOCK, blk_u = group / GROUPS_PER_BLOCK;
+    const int nwaves = GROUPS_PER_BLOCK * g.nsub;
+    // the sweep's two-level grid, inverted: the blocks that swept this user block (rm_sweep.hpp)
+    const int rel = blk_u - g.ublock0, n_ub1 = g.n_ublocks - g.tail_ublocks;
+    const bool in_tail = rel < g.tail_ublocks;
+    const int nsplit = in_tail ? g.tail_splits : g.n_splits;
+    const KeyT bound = (KeyT)thr_shared[slot];                      // (0 = none: below every key)
+    if (tid == 0) sh_cur = 0;
+    __syncthreads();
+    // sort LDS entries [0, cur) descending, keep the first K
+    auto reduce = [&]() {
+        const int cur = sh_cur;
+        int P = 2;
+        while (P < cur) P <<= 1;
+        for (int i = cur + tid; i < P; i += COLLECT_THREADS) { kh[i] = 0; kl[i] = 0u; }
+        __syncthreads();
+        for (int k2 = 2; k2 <= P; k2 <<= 1) {
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                for (int pr = tid; pr < (P >> 1); pr += COLLECT_THREADS) {
+                    const int i0 = ((pr & ~(j - 1)) << 1) | (pr & (j - 1)), i1 = i0 | j;
+                    const KeyT h0 = kh[i0], h1 = kh[i1];
+                    const unsigned l0 = kl[i0], l1 = kl[i1];
+                    const bool lt = h0 < h1 || (h0 == h1 && l0 < l1);         // entry 0 is worse than entry 1
+                    const bool desc = (i0 & k2) == 0;
+                    if (desc ? lt : (!lt && !(h0 == h1 && l0 == l1))) { kh[i0] = h1; kh[i1] = h0; kl[i0] = l1; kl[i1] = l0; }
+                }
+                __syncthreads();
+            }
+        }
+        if (tid == 0) sh_cur = cur < K ? cur : K;
+        __syncthreads();
+    };
+    auto room_for = [&](int c) {                                   // (block-uniform)
+        if (sh_cur + c > COLLECT_CAP) reduce();
+    };
+    for (int sp = 0; sp < nsplit; sp++) {
+        const int bidx = in_tail ? n_ub1 * g.n_splits + sp * g.tail_ublocks + (g.tail_ublocks - 1 - rel)
+                                 : sp * n_ub1 + (g.n_ublocks - 1 - rel);
+        for (int sub = 0; sub < g.nsub; sub++) {
+            const size_t wv = (size_t)bidx * nwaves + (size_t)(sub * GROUPS_PER_BLOCK + gi);
+            const char *wbase = glists + wv * ((size_t)g.lane_cap * WAVE * (sizeof(S) + 4));
+            const S *wsc = (const S *)wbase;
+            const int *wit = (const int *)(wbase + (size_t)g.lane_cap * WAVE * sizeof(S));
+            for (int l = 0; l < g.lpu; l++) {
+                const int lane = ul + l * g.gu;
+                const int c = lane_cnt[wv * WAVE + lane];
+                room_for(c);
+                for (int i = tid; i < c; i += COLLECT_THREADS) {
+                    const S x = wsc[(size_t)i * WAVE + lane];
+                    const KeyT key = ord_key(x);
+                    if (key >= bound) { const int at = atomicAdd(&sh_cur, 1); kh[at] = key; kl[at] = ~(unsigned)wit[(size_t)i * WAVE + lane]; }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (g.extra_part >= 0) {
+        const Entry<S> *px = a.pl + ((size_t)slot * a.n_part + g.extra_part) * K;
+        for (int i0 = 0; i0 < K; i0 += COLLECT_THREADS) {
+            room_for(COLLECT_THREADS);
+            const int i = i0 + tid;
+            if (i < K) {
+                const Entry<S> e = px[i];
+                if (e.idx != IDX_EMPTY) { const int at = atomicAdd(&sh_cur, 1); kh[at] = ord_key(e.s); kl[at] = ~(unsigned)e.idx; }
+            }
+            __syncthreads();
+        }
+    }
+    reduce();
+    const int got = sh_cur;
+    Entry<S> *M = a.merged + (size_t)u * K;
+    for (int i = tid; i < K; i += COLLECT_THREADS) {
+        Entry<S> e;
+        if (i < got) { e.s = ord_unkey(kh[i]); e.idx = (int)~kl[i]; }
+        else { e.s = (S)qnan<float>(); e.idx = -1; }
+        M[i] = e;
+    }
+}
+
 template <class T, class S>
 __global__ void k_auc_streamed(FinalArgs<T, S> a, int row0, int row1)
 {
@@ -714,7 +825,8 @@ __global__ void k_finalize(FinalArgs<T, S> a)
     const int te0 = a.test_p[u], npos = a.test_p[u + 1] - te0;
     if (a.status) a.status[u] = 1;
     Entry<S> *M = a.merged + (size_t)u * K;
-    if (!a.ext_topk) for (int i = 0; i < K; i++) { M[i].s = (S)qnan<float>(); M[i].idx = -1; }
+    const bool merged_ready = a.ext_topk || a.collected;          // k_select_topk / k_collect_topk have written M already
+    if (!merged_ready) for (int i = 0; i < K; i++) { M[i].s = (S)qnan<float>(); M[i].idx = -1; }
 
     const int ntr = a.train_p[u + 1] - a.train_p[u];
     const int C = n - ntr;
@@ -733,7 +845,7 @@ __global__ void k_finalize(FinalArgs<T, S> a)
         // a part without entries (the sub-tile waves that share a group's LDS list write it once; item ranges this user's
         // block was not cut into) is left out of the merge: with many item ranges (few users: the exact pass of the tie noise)
         // two parts out of three are empty
-        const bool empty = !a.ext_topk && PL[(size_t)q * K].idx == IDX_EMPTY;
+        const bool empty = !merged_ready && PL[(size_t)q * K].idx == IDX_EMPTY;
         head[q * FIN_THREADS] = empty ? (unsigned short)K : (unsigned short)0;
         if (!empty) alive[(n_alive++) * FIN_THREADS] = (unsigned short)q;
         const PartialStat<S> ps = a.pst[(size_t)s0 * NP + q];
@@ -741,7 +853,7 @@ __global__ void k_finalize(FinalArgs<T, S> a)
         vmin = ps.vmin < vmin ? ps.vmin : vmin;
         any_nan |= ps.has_nan != 0;
     }
-    for (int i = 0; i < (a.ext_topk ? 0 : K); i++) {            // (ext_topk: k_select_topk has written M already)
+    for (int i = 0; i < (merged_ready ? 0 : K); i++) {
         int best = -1; Entry<S> be; be.s = 0; be.idx = 0;
         for (int t = 0; t < n_alive; t++) {
             const int q = alive[t * FIN_THREADS];

@@ -40,7 +40,9 @@ struct SweepArgs {
     const int *pos_item;                  // same shape, item ids (read only when a candidate ties a positive's score)
     unsigned *hist;                       // [(total_rows + n_groups)][32]
     unsigned *thr_shared;                 // [n_slots] order-preserving key of the best K-th-best any partial of the user has seen
-    u32x2 *glists;                        // list scratch in HBM when the lists do not fit LDS: [block][wave][K][32]
+    u32x2 *glists;                        // list scratch in HBM when the lists do not fit LDS: K <= 32 [block][wave][K][32]; K > 32 the waves' lane
+                                          // buffers [block][wave]{[lane_cap][64] scores, [lane_cap][64] item ids} (rm_list.hpp)
+    int lane_cap; int *lane_cnt;          // K > 32: entries per lane buffer (a multiple of 16); [block][wave][64] entries left at the end of the sweep
     ListEntry *pl;                        // partial lists [slot][n_part][K]
     PartialStat<float> *pst;              // [slot][n_part]
     float *dump;                          // DUMP mode: dense [n_slots][n] scores
@@ -74,7 +76,8 @@ struct Sweep64Args {
     const int *pos_item;
     unsigned *hist;                       // [(total_rows + n_groups)][16]
     unsigned long long *thr_shared;       // [n_slots] (64-bit keys)
-    u32x4 *glists;                        // [block][wave][K][16]
+    u32x4 *glists;                        // K <= 32: [block][wave][K][16]; K > 32: lane buffers [block][wave]{[lane_cap][64] scores, [lane_cap][64] item ids}
+    int lane_cap; int *lane_cnt;          // as in SweepArgs
     Entry<double> *pl;                    // [slot][n_part][K]
     PartialStat<double> *pst;             // [slot][n_part]
     double *dump;

@@ -58,7 +58,7 @@ struct Switches {
     bool no_train_bits, no_spec, no_side, ext_topk, no_early_bits, no_test_mask, hbm_lists, nsub2, no_pending, no_pos_keys, no_pos_beside,
          no_seed, no_depth_split, rank_generic, no_fused_auc, no_defer_auc, noise_sequential, no_ext_bits, one_context, noise_per_batch,
          host_trace, no_noise_beside_last, no_pack_beside, no_pos_flat;
-    long long free_mb, stream_budget_mb, dense_always_mb, noise_budget_mb;      // -1 = not set
+    long long free_mb, stream_budget_mb, dense_always_mb, noise_budget_mb, lane_cap_min;      // -1 = not set
     double batch_users;                                                        // 0 = not set
     int ramp;                                                                  // 0 = not set
     std::string splits;
@@ -77,6 +77,7 @@ struct Switches {
         no_pos_flat = on("RM_DEBUG_NO_POS_FLAT");
         free_mb = num("RM_DEBUG_FREE_MB"); stream_budget_mb = num("RM_STREAM_BUDGET_MB"); dense_always_mb = num("RM_DEBUG_DENSE_ALWAYS_MB");
         noise_budget_mb = num("RM_NOISE_BUDGET_MB");
+        lane_cap_min = num("RM_DEBUG_LANE_CAP_MIN");          // the smallest lane buffers that work: a selection every few tiles (tests)
         const char *b = getenv("RM_BATCH_USERS"); batch_users = b ? atof(b) : 0.0;
         const char *r = getenv("RM_DEBUG_RAMP"); ramp = r ? atoi(r) : 0;
         const char *s = getenv("RM_DEBUG_SPLITS"); splits = s ? s : "";
@@ -292,6 +293,10 @@ template <> struct Prec<float> {
     static void set_pending(SweepArgs &sa, int cap, int off) { sa.pend_cap = cap; sa.pend_off = off; }
     static void set_sync(SweepArgs &sa, int off) { sa.sync_off = off; }
     static void set_ublocks(SweepArgs &sa, int first, int count) { sa.ublock0 = first; sa.n_ublocks = count; }
+    // K > 32: entries per lane buffer of the sweep (rm_list.hpp; a multiple of 16, and a selection's K + slack survivors plus a tile's
+    // sixteen appends must fit one lane: 2K + 16), lanes per user
+    static int lane_cap(int K) { return (2 * K + 16 + 15) / 16 * 16; }
+    static constexpr int lanes_per_user = 2;
 };
 template <> struct Prec<double> {
     static constexpr int GU = GROUP_USERS64;
@@ -310,6 +315,9 @@ template <> struct Prec<double> {
     static void set_pending(Sweep64Args &sa, int cap, int off) { sa.pend_cap = cap; sa.pend_off = off; }
     static void set_sync(Sweep64Args &sa, int off) { sa.sync_off = off; }
     static void set_ublocks(Sweep64Args &sa, int first, int count) { sa.ublock0 = first; sa.n_ublocks = count; }
+    // (four lanes per user: K + slack + a tile's eight appends must fit ONE lane, the user's four hold ~5K together)
+    static int lane_cap(int K) { return (K + lane_sel_slack(K) + 8 + 16 + 15) / 16 * 16; }
+    static constexpr int lanes_per_user = 4;
 };
 
 inline void check_launch(int rc)
@@ -333,11 +341,16 @@ inline void pack_operands(const float *A, size_t lda, const float *B, size_t ldb
     if (items) {
         const size_t lds = pack_items_tile_lds(NG, tile_items);
         const long long tiles = bp / ((long long)NG * 2 * tile_items);
-        if (lds <= 96 * 1024 && tiles * NG * 2 * tile_items == bp) {
-            static bool once = [] { (void)hipFuncSetAttribute((const void *)k_pack_items_tile<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); return true; }();
-            (void)once;
+        // (the attribute is per DEVICE -- rm_set_devices drives several -- so it is set at every launch, like every other kernel of
+        // the library that takes more than 64 KB; a refusal falls back to the kernel that needs no LDS)
+        bool tiled = lds <= 96 * 1024 && tiles * NG * 2 * tile_items == bp;
+        if (tiled && lds > 48 * 1024)
+            tiled = hipFuncSetAttribute((const void *)k_pack_items_tile<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        if (tiled) {
             hipLaunchKernelGGL(k_pack_items_tile<float>, dim3((unsigned)tiles), dim3(256), lds, stream, B, ldb, n, k, NG, tile_items, Bp);
-        } else hipLaunchKernelGGL(k_pack_items<float>, dim3(cdiv(bp, 256)), dim3(256), 0, stream, B, ldb, n, k, NG, tile_items, Bp, bp);
+            if (hipGetLastError() != hipSuccess) tiled = false;
+        }
+        if (!tiled) hipLaunchKernelGGL(k_pack_items<float>, dim3(cdiv(bp, 256)), dim3(256), 0, stream, B, ldb, n, k, NG, tile_items, Bp, bp);
     }
     hipLaunchKernelGGL(k_pack_users<float>, dim3(cdiv(ap, 256)), dim3(256), 0, stream, A, lda, k, NG, slot_user, n_slots, Ap, ap);
 }
@@ -709,7 +722,11 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         // the streamed users' score rows must fit the budget; if not (memory pressure), plan again with those users in chunks
         if (ca.allow_stream && !ca.force_stream && hp.class_count[STREAM_CLASS] > stream_cap && attempt == 0) {
             ca.allow_stream = 0; ca.check_ptr = 0;
-            if (use_side) { HIP_CHECK(hipStreamSynchronize(cx.side_stream)); side_guard.pending = bits_early ? 1 : 0; }
+            // (attempt 0's kernels on BOTH side streams read `flags` and `plan`, which the second plan rewrites: wait for them)
+            if (use_side) {
+                HIP_CHECK(hipStreamSynchronize(cx.side_stream)); side_guard.pending = bits_early ? 1 : 0;
+                if (cx.pos_stream) HIP_CHECK(hipStreamSynchronize(cx.pos_stream));
+            }
             continue;
         }
         break;
@@ -873,6 +890,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     Entry<T> *pl = nullptr; PartialStat<T> *pst = nullptr;
     T *stream_scores = nullptr, *spos_score = nullptr; int *spos_item = nullptr; unsigned *shist = nullptr;
     const long long stream_ld = (long long)tiles_total * tile_items;
+    struct { bool on = false; const char *glists = nullptr; const int *lane_cnt = nullptr; const void *thr = nullptr; CollectGeom g{}; } collect;
 
     if (n_slots > 0) {
         // ---- pack operands into the MFMA images ----
@@ -964,7 +982,15 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         pst = (PartialStat<T> *)ws.get("pst", sizeof(PartialStat<T>) * (size_t)n_slots * n_part);
         typename P::ListT *glists = nullptr;
         const unsigned n_blocks = (unsigned)((n_ublocks - tail_ublocks) * n_splits + tail_ublocks * tail_splits);
-        if (!list_in_lds && !ext_topk) {
+        const bool lane_lists = !list_in_lds && !ext_topk && K > 32;       // per-lane append buffers + k_collect_topk (rm_list.hpp)
+        int lane_cap = lane_lists ? P::lane_cap(K) : 0;
+        if (lane_lists && g_sw.lane_cap_min >= 0)        // K + slack survivors and one tile's appends (16: both precisions' bound) in one lane
+            lane_cap = std::min(lane_cap, (K + lane_sel_slack(K) + 16 + 1 + 15) / 16 * 16);
+        int *lane_cnt = nullptr;
+        if (lane_lists) {
+            glists = (typename P::ListT *)ws.get("glists", (size_t)n_blocks * n_waves * WAVE * (size_t)lane_cap * (sizeof(T) + 4));
+            lane_cnt = (int *)ws.get("lane_cnt", sizeof(int) * (size_t)n_blocks * n_waves * WAVE);
+        } else if (!list_in_lds && !ext_topk) {
             glists = (typename P::ListT *)ws.get("glists", sizeof(typename P::ListT) * (size_t)n_blocks * n_waves * GU * (2 * K + 32));
         }
 
@@ -979,7 +1005,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         sa.n_splits = n_splits; sa.tail_ublocks = tail_ublocks; sa.tail_splits = tail_splits; sa.part_splits = part_splits; sa.tiles_total = tiles_total; sa.jmax = jmax; sa.check_nan = check_nan ? 1 : 0; sa.buffered_lists = (K > 32 || ext_topk) ? 1 : 0; sa.ext_topk = ext_topk ? 1 : 0;
         sa.Ap = (decltype(sa.Ap))Ap; sa.Bp = (decltype(sa.Bp))Bp; sa.slot_user = slot_user; sa.slot_chunk = slot_chunk;
         sa.train_p = c.train_p; sa.train_i = c.train_i; sa.gj = gj; sa.grow = grow;
-        sa.pos_score = pos_score; sa.pos_item = pos_item; sa.hist = hist; sa.glists = glists; sa.pl = pl; sa.pst = pst; sa.dump = nullptr;
+        sa.pos_score = pos_score; sa.pos_item = pos_item; sa.hist = hist; sa.glists = glists; sa.lane_cap = lane_cap; sa.lane_cnt = lane_cnt; sa.pl = pl; sa.pst = pst; sa.dump = nullptr;
         P::set_pending(sa, pend_cap, (int)pend_off);
         P::set_sync(sa, (int)sync_off);
         sa.stream_slot0 = stream_slot0; sa.stream_ld = stream_ld; sa.stream_scores = stream_scores;
@@ -1035,6 +1061,10 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             dispatch_sweep(want_auc, false, list_in_lds, nsub, NG, dim3(n_blocks), lds_total, stream, sa);
         }
         HIP_CHECK(hipEventRecord(g_ev[2], stream));
+        if (lane_lists) {
+            collect.on = true; collect.glists = (const char *)glists; collect.lane_cnt = lane_cnt; collect.thr = (const void *)thr_shared;
+            collect.g = CollectGeom{sa.ublock0, sa.n_ublocks, n_splits, tail_ublocks, tail_splits, nsub, GU, P::lanes_per_user, lane_cap, part_extra ? n_part - 1 : -1};
+        }
         g_timings[4] = u_split > 0 ? 2 : 1; g_timings[5] = n_splits; g_timings[6] = n_blocks; g_timings[7] = (double)lds_total;
         cx.timed_slots = n_slots;
         cx.total_slots = n_slots;
@@ -1082,6 +1112,13 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     if (topv_pending) {                                           // (k_top_values, launched beside the preparation)
         HIP_CHECK(hipStreamWaitEvent(stream, cx.side_ev[3], 0));
         side_guard.pending--;
+    }
+    if (collect.on) {
+        // k_metrics beyond the LDS lists: the users' ordered top-K out of the sweep's lane buffers, straight into `merged` (behind
+        // k_merge_positives, whose part of `pl` -- the streamed users' own test items -- is one of the inputs)
+        typedef typename std::remove_pointer<decltype(typename P::Args{}.thr_shared)>::type ThrT;
+        fa.collected = 1;
+        hipLaunchKernelGGL((k_collect_topk<T, T, ThrT>), dim3(n_slots), dim3(COLLECT_THREADS), 0, stream, fa, collect.g, collect.glists, collect.lane_cnt, (const ThrT *)collect.thr);
     }
     if (n_slots > 0 && ext_topk) {
         int sel_ld = 2;
@@ -1419,6 +1456,7 @@ template <class T> struct HostCall {              // one host-pointer call (refe
     int K; bool cumulative, noise; T *outs[10]; bool cold; int mip, mpt;
     int *topk_idx; T *topk_score; long long *pos_rank; int *status;
     unsigned long long seed;
+    int nthreads = 0;                                 // host threads of the fall-back sort of unsorted CSR rows (0 = all)
 };
 
 // item factors of a sharded call: uploaded from the host by shard 0, copied device-to-device (xGMI) by the others
@@ -1852,7 +1890,10 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     // (the batch before the last one first: its outputs are copied to the caller while the last batch is still on the device)
     { const int older = two_ctx ? ((n_batches - 2) & 1) : 0; finish(older); finish(older ^ 1); }
     g_last_ctx = &cx;
-    if (range_noise && !g_interrupt && out_w) {
+    // (ONE look at the flag decides both: whether the exact passes run, and whether the flagged users' values are withdrawn -- an
+    // interrupt that arrives while the passes finish must not turn their finished, correct values into NaN)
+    const bool interrupted = g_interrupt;
+    if (range_noise && !interrupted && out_w) {
         if (bes.ran) {                                                // (its results left the device while the last batch was sweeping)
             HIP_CHECK(hipStreamSynchronize(bes.stream));
             scatter_exact(bes.hx, bes.hu, bes.count);
@@ -1879,7 +1920,7 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
             }
         }
     } else if (bes.pc) (void)hipStreamSynchronize(bes.stream);
-    if (g_interrupt) nan_flagged();
+    if (interrupted) nan_flagged();
     } catch (...) {
         for (int i = 0; i < 2; i++) (void)hipStreamSynchronize(streams[i]);      // nothing may still write into staging that goes away
         (void)hipStreamSynchronize(up);
@@ -1995,8 +2036,8 @@ void run_host(const HostCall<T> &h)
     std::vector<int> tri(h.tri, h.tri + nnz_tr), tei(h.tei, h.tei + nnz_te);
     std::vector<T> tev;
     if (h.tev) tev.assign(h.tev, h.tev + nnz_te);
-    int rc = rm_csr_sort_rows(h.trp, tri.data(), nullptr, 0, h.m, 0);
-    if (rc == RM_OK) rc = rm_csr_sort_rows(h.tep, tei.data(), h.tev ? (void *)tev.data() : nullptr, h.tev ? (int32_t)sizeof(T) : 0, h.m, 0);
+    int rc = rm_csr_sort_rows(h.trp, tri.data(), nullptr, 0, h.m, h.nthreads);
+    if (rc == RM_OK) rc = rm_csr_sort_rows(h.tep, tei.data(), h.tev ? (void *)tev.data() : nullptr, h.tev ? (int32_t)sizeof(T) : 0, h.m, h.nthreads);
     if (rc != RM_OK) throw RmError{rc, "sorting a copy of the CSR rows failed"};
     HostCall<T> h2 = h;
     h2.tri = tri.data(); h2.tei = tei.data(); h2.tev = h.tev ? tev.data() : nullptr;
@@ -2093,12 +2134,12 @@ extern "C" int rm_calc_metrics_##SUFFIX(                                        
     T *roc_auc, T *pr_auc, int consider_cold_start, int32_t min_items_pool, int32_t min_pos_test,                       \
     int32_t nthreads, uint64_t seed)                                                                                    \
 {                                                                                                                       \
-    (void)nthreads;                                                                                                     \
     return guarded([&] {                                                                                                \
         HostCall<T> h{A, lda, B, ldb, m, n, k, Xtrain_csr_p, Xtrain_csr_i, Xtest_csr_p, Xtest_csr_i, Xtest_csr,         \
                       k_metrics, cumulative != 0, break_ties_with_noise != 0,                                           \
                       {p_at_k, tp_at_k, r_at_k, ap_at_k, tap_at_k, ndcg_at_k, hit_at_k, rr_at_k, roc_auc, pr_auc},      \
                       consider_cold_start != 0, min_items_pool, min_pos_test, nullptr, nullptr, nullptr, nullptr, seed};\
+        h.nthreads = nthreads > 0 ? nthreads : 0;                                                                       \
         run_host<T>(h);                                                                                                 \
     });                                                                                                                 \
 }                                                                                                                       \
@@ -2239,7 +2280,8 @@ extern "C" int rm_release_workspace(void)
         for (Ctx *c : mine) {
             std::lock_guard<std::mutex> cl(c->mu);
             c->ws.release();
-            c->packed_tag = 0; c->bits_tag = 0; c->bits_ptr = nullptr;
+            // (every marker of cached CONTENT goes with the buffers: a fresh allocation may come back at the old address)
+            c->packed_tag = 0; c->packed_ptr = nullptr; c->bits_tag = 0; c->bits_ptr = nullptr; c->log2_ptr = nullptr; c->log2_K = 0;
         }
     });
 }

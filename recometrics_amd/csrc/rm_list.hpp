@@ -161,114 +161,211 @@ __device__ __forceinline__ void keylist_sort_desc(P L, int K)
     }
 }
 
-// ---- large K: append buffer + wave-cooperative compaction (lists that do not fit LDS live in HBM) -----------------------
-// A user's buffer holds up to CAP = 2K + 32 raw entries, user-major (contiguous) in HBM.  The owner lane appends every
-// candidate that passes its threshold (one store); when more than 2K have accumulated, the whole wave selects the K best:
-// every lane holds cnt/64 entries, the buffer is replayed 64 entries at a time through lane broadcasts, each entry gets
-// its rank in the (score desc, item asc) order by counting, and entries ranked < K are written back at [rank] -- so the
-// survivors are also sorted.  The threshold only rises at a compaction, so the stream position doubles between
-// compactions: ~log2(n/K) of them per user and ~K of appends per compaction.
-template <class S>
-__device__ __forceinline__ void wave_compact(typename ListRaw<S>::raw *Gu, int cnt, int K, int lane, S &kth_s, int &kth_idx)
-#include "rm_compact_body.inc"
-
-// Compaction DURING the sweep does not need the survivors sorted, only to be the K best: the K-th best key is found by
-// bisection over the bits of the order-preserving key (count of entries at or above the candidate by ballots: 64 steps of a
-// few instructions per held entry, against cnt x entries for the rank count above -- about a quarter of the instructions at
-// K = 100), then the survivors are packed to the front in their old order.  The waves of a block wait for one another at
-// every tile, so the time a wave spends here is paid by all of them: compaction skew, not the appends, is what holds the
-// append-buffer variants back (profiles/r2: 35-48 % of their wave cycles parked).
-// Order: (score desc, item asc); `hi` = order-preserving score key, ties by the smaller item.
-__device__ __forceinline__ unsigned long long sel_score_key(float s) { return (unsigned long long)ord_key(s); }
-__device__ __forceinline__ unsigned long long sel_score_key(double s) { return ord_key(s); }
-// (E = entries per lane as a template constant, loads unconditional with a clamped index: with a run-time E and predicated
-// loads the compiler shuffled the register arrays through 240 VGPRs of copies)
-template <class S, int E>
-__device__ __forceinline__ void wave_select_e(typename ListRaw<S>::raw *Gu, int cnt, int K, int lane, S &kth_s, int &kth_idx)
+// ---- K beyond the LDS lists: per-LANE append buffers in HBM + lane-parallel selection ---------------------------------------
+// (round 6; replaces the per-USER buffers whose compaction took the whole wave for one user at a time: 32 users x 7 compactions
+// per wave and item range at BASELINE C2's shape with K = 100, each ~1,000 instructions with the three partner waves of the
+// sub-tile waiting at the next barrier -- the sweep went 6.7 -> 22.7 ms from K = 10 to K = 100, profiles/r5_ab_c2.txt)
+//
+// Every lane owns a buffer of `cap` entries, laid out [entry][64 lanes] (the scores of a wave, then its item ids at the same
+// offsets), and appends each of ITS OWN scores that reaches the user's bound: a compare, two stores under the lane mask and an
+// add per score register -- no ballots, no shuffles to an owner lane.  A user's candidates are the union of the buffers of its
+// lanes (two in the fp32 sweep, four in the fp64 one).  When some lane of the wave is a tile away from full, ALL users of the
+// wave raise their bounds together, each lane working on its own buffer (the loops are wave-uniform, the data per lane):
+//   * a bisection for a bound T with K <= #(entries >= T) <= K + slack -- three probes per pass over the buffers (one load,
+//     three compares and adds per entry), first in value space (quartiles of [lo, hi]: the scores of a user are smooth), then in
+//     key space (which ends within 16 / 32 passes whatever the data); the counts of a user's lanes are added by a shuffle;
+//   * when the bisection ends on an exact score with more than K + slack entries at or above it (many exact ties), the ties
+//     are cut by item id (a second bisection; items arrive in ascending order, so a later entry with that score can never
+//     displace a kept one and the lane's own bound becomes strict);
+//   * every lane packs its survivors to the front of its own buffer, in place (slot j <= slot i: no hazard).
+// Nothing is sorted and nothing exact is needed here: ANY T with at least K entries at or above it is a valid lower bound of
+// the user's final K-th best.  The exact, ordered top-K is k_collect_topk's job after the sweep (rm_finalize.hpp): a block per
+// user, all item ranges and sub-tile waves of the user at once.
+// A buffer that holds K + slack entries after a selection refills after ~(cap - that) more: with cap = 2K + 16 the stream
+// position grows ~10x between selections (2 per item range at 27k items, 4 at 10M) instead of 2x between compactions.
+template <class S> struct LaneSel;
+template <> struct LaneSel<float> {
+    typedef unsigned Key;
+    static constexpr int LPU = 2;                                   // lanes per user: lane and lane ^ 32
+    static constexpr Key KEY_TOP = 0xff800001u;                     // ord_key(+inf) + 1
+    static __device__ __forceinline__ int usum(int x) { return x + __shfl_xor(x, 32); }
+    static __device__ __forceinline__ float umax(float x) { return __builtin_fmaxf(x, __shfl_xor(x, 32)); }
+    static __device__ __forceinline__ float umin(float x) { return __builtin_fminf(x, __shfl_xor(x, 32)); }
+    // (through L2: the entries were stored by this wave, the L1 may hold an older copy of the line)
+    static __device__ __forceinline__ float load(const float *p) { return __uint_as_float(__hip_atomic_load((const unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+    static __device__ __forceinline__ float nan() { return __uint_as_float(0xffffffffu); }
+    static __device__ __forceinline__ float ninf() { return __uint_as_float(0xff800000u); }
+    static __device__ __forceinline__ float pinf() { return __uint_as_float(0x7f800000u); }
+    static __device__ __forceinline__ bool finite(float x) { return (__float_as_uint(x) & 0x7f800000u) != 0x7f800000u; }
+};
+template <> struct LaneSel<double> {
+    typedef unsigned long long Key;
+    static constexpr int LPU = 4;                                   // lane, lane ^ 16, lane ^ 32, lane ^ 48
+    static constexpr Key KEY_TOP = 0xfff0000000000001ull;
+    static __device__ __forceinline__ int usum(int x) { x += __shfl_xor(x, 16); return x + __shfl_xor(x, 32); }
+    static __device__ __forceinline__ double umax(double x) { x = __builtin_fmax(x, __shfl_xor(x, 16)); return __builtin_fmax(x, __shfl_xor(x, 32)); }
+    static __device__ __forceinline__ double umin(double x) { x = __builtin_fmin(x, __shfl_xor(x, 16)); return __builtin_fmin(x, __shfl_xor(x, 32)); }
+    static __device__ __forceinline__ double load(const double *p) { return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+    static __device__ __forceinline__ double nan() { return __longlong_as_double(-1ll); }
+    static __device__ __forceinline__ double ninf() { return __longlong_as_double((long long)0xfff0000000000000ull); }
+    static __device__ __forceinline__ double pinf() { return __longlong_as_double(0x7ff0000000000000ll); }
+    static __device__ __forceinline__ bool finite(double x) { return ((unsigned long long)__double_as_longlong(x) & 0x7ff0000000000000ull) != 0x7ff0000000000000ull; }
+};
+__device__ __forceinline__ int lane_sel_load_item(const int *p) { return (int)__hip_atomic_load((const unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int wave_max_i32(int x)
 {
-    unsigned long long hi[E]; int it[E];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the owner lane's appends have reached L2
     #pragma unroll
-    for (int t = 0; t < E; t++) {
-        const int i = lane + t * WAVE;
-        S es; int ei;
-        ListRaw<S>::unpack(ListRaw<S>::load_l2(Gu + (i < cnt ? i : 0)), es, ei);
-        hi[t] = i < cnt ? sel_score_key(es) : 0ull;          // key 0 is below every real score's key
-        it[t] = i < cnt ? ei : IDX_EMPTY;
-    }
-    // K-th largest score key
-    constexpr int BITS = sizeof(S) == 4 ? 32 : 64;
-    unsigned long long T = 0ull;
-    for (int bit = BITS - 1; bit >= 0; bit--) {
-        const unsigned long long cand = T | (1ull << bit);
-        int c = 0;
+    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(x, d); x = o > x ? o : x; }
+    return __builtin_amdgcn_readfirstlane(x);
+}
+// slack of a selection: the bisection stops at the first bound that leaves between K and K + slack entries
+__host__ __device__ inline int lane_sel_slack(int K) { return K / 4 > 8 ? K / 4 : 8; }
+
+// counts of the lane's entries [0, cend) at or above each of three probes (cend a multiple of 16; the slots behind the lane's
+// own count hold NaN, which no compare accepts)
+template <class S>
+__device__ __forceinline__ void lane_count3(const S *sc, int cend, S p1, S p2, S p3, int &c1, int &c2, int &c3)
+{
+    typedef LaneSel<S> L;
+    c1 = 0; c2 = 0; c3 = 0;
+    for (int i = 0; i < cend; i += 16) {
+        S x[16];
         #pragma unroll
-        for (int t = 0; t < E; t++) c += __popcll(__ballot(hi[t] >= cand));
-        if (c >= K) T = cand;
+        for (int t = 0; t < 16; t++) x[t] = L::load(sc + (size_t)(i + t) * WAVE);
+        #pragma unroll
+        for (int t = 0; t < 16; t++) { c1 += x[t] >= p1; c2 += x[t] >= p2; c3 += x[t] >= p3; }
     }
-    int n_gt = 0, n_eq = 0;
-    #pragma unroll
-    for (int t = 0; t < E; t++) { n_gt += __popcll(__ballot(hi[t] > T)); n_eq += __popcll(__ballot(hi[t] == T)); }
-    // among the entries that tie the K-th score: the (K - n_gt) smallest items (usually there is exactly one such entry)
-    const int need = K - n_gt;
-    int item_max = IDX_EMPTY;                                 // keep equal-scored entries with item <= item_max
-    if (n_eq > need) {
-        unsigned I = 0u;                                      // the need-th smallest item among the ties, bit by bit
-        for (int bit = 30; bit >= 0; bit--) {
-            const unsigned cand = I | (1u << bit);
-            int c = 0;
-            #pragma unroll
-            for (int t = 0; t < E; t++) c += __popcll(__ballot(hi[t] == T && (unsigned)it[t] < cand));
-            if (c < need) I = cand;
-        }
-        item_max = (int)I;
-    }
-    // pack the survivors to the front (all entries are in registers: a write can only hit a slot already read)
-    int base = 0, worst_item = -1;
-    #pragma unroll
-    for (int t = 0; t < E; t++) {
-        const bool keep = hi[t] > T || (hi[t] == T && it[t] <= item_max);
-        const unsigned long long m = __ballot(keep);
-        if (keep) {
-            S es;
-            if (sizeof(S) == 4) es = (S)ord_unkey((unsigned)hi[t]); else es = (S)ord_unkey(hi[t]);
-            Gu[base + __popcll(m & ((1ull << lane) - 1ull))] = ListRaw<S>::pack(es, it[t]);
-        }
-        base += __popcll(m);
-        if (hi[t] == T && it[t] <= item_max && it[t] > worst_item) worst_item = it[t];
-    }
-    #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(worst_item, d); worst_item = o > worst_item ? o : worst_item; }
-    if (sizeof(S) == 4) kth_s = (S)ord_unkey((unsigned)T); else kth_s = (S)ord_unkey(T);
-    kth_idx = worst_item;                                     // the K-th best = the tie with the largest kept item
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // survivors written before anyone appends behind them
-}
-template <class S>
-__device__ __forceinline__ void wave_select(typename ListRaw<S>::raw *Gu, int cnt, int K, int lane, S &kth_s, int &kth_idx)
-{
-    switch ((cnt + WAVE - 1) / WAVE) {                        // (2 * 256 + 32) / 64 rounded up = 9 at most
-        case 1: wave_select_e<S, 1>(Gu, cnt, K, lane, kth_s, kth_idx); break;
-        case 2: wave_select_e<S, 2>(Gu, cnt, K, lane, kth_s, kth_idx); break;
-        case 3: wave_select_e<S, 3>(Gu, cnt, K, lane, kth_s, kth_idx); break;
-        case 4: wave_select_e<S, 4>(Gu, cnt, K, lane, kth_s, kth_idx); break;
-        case 5: wave_select_e<S, 5>(Gu, cnt, K, lane, kth_s, kth_idx); break;
-        case 6: wave_select_e<S, 6>(Gu, cnt, K, lane, kth_s, kth_idx); break;
-        case 7: wave_select_e<S, 7>(Gu, cnt, K, lane, kth_s, kth_idx); break;
-        case 8: wave_select_e<S, 8>(Gu, cnt, K, lane, kth_s, kth_idx); break;
-        default: wave_select_e<S, 9>(Gu, cnt, K, lane, kth_s, kth_idx); break;
-    }
-}
-template <class S>
-__device__ __attribute__((noinline)) void wave_select_call(typename ListRaw<S>::raw *Gu, int cnt, int K, int lane, S &kth_s, int &kth_idx)
-{
-    wave_select<S>(Gu, cnt, K, lane, kth_s, kth_idx);
 }
 
-// Out-of-line form for the fp64 sweep: inlined, the nine-entry-per-lane working set is added to a register budget that
-// is already full (256 factors) and the hot loop spills; as a real call only the live registers around this rare path
-// are saved.  The fp32 sweep has the room and keeps the inlined form (a call there costs more than it saves).
+// sc / it: the lane's columns (entry i at [i * 64]).  cnt: the lane's entries, in and out.  thr_in: the lane's present bound
+// (every entry is at or above its predecessor in float order -- see below).  hi_hint: a score no entry of the USER exceeds (+inf
+// if unknown).  Out: thr_out = the lane's new bound, kth_key = order-preserving key of the bound that may be published to the
+// user's other partial lists (0: nothing new).  All lanes of the wave call this together.
 template <class S>
-__device__ __attribute__((noinline)) void wave_compact_call(typename ListRaw<S>::raw *Gu, int cnt, int K, int lane, S &kth_s, int &kth_idx)
-#include "rm_compact_body.inc"
+__device__ __forceinline__ void lane_select(S *sc, int *it, int &cnt, const int K, const bool primary, const S thr_in, const S hi_hint,
+                                            const int n_items, S &thr_out, typename LaneSel<S>::Key &kth_key)
+{
+    typedef LaneSel<S> L;
+    typedef typename L::Key Key;
+    const int slack = lane_sel_slack(K);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the appends have reached L2
+    kth_key = 0; thr_out = thr_in;
+    const int C = L::usum(cnt);
+    const bool active = primary && C > K + slack;
+    if (!wave_any(active)) return;
+    const int cmax = wave_max_i32(active ? cnt : 0), cmin = -wave_max_i32(active ? -cnt : -0x7fffffff);
+    const int cend = (cmax + 15) & ~15;                             // (cap is a multiple of 16)
+    for (int i = cmin; i < cend; i++) if (active && i >= cnt) sc[(size_t)i * WAVE] = L::nan();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- bracket: #(>= unkey(lo)) >= K, #(>= unkey(hi)) < K.  Every entry is >= the float below the lane's bound: the bound is
+    // either the last selection's T, or the float above it when that selection cut exact ties by item (the kept ties sit AT T)
+    Key lo = ord_key(thr_in) - 1, hi = L::finite(hi_hint) ? ord_key(hi_hint) + 1 : L::KEY_TOP;
+    const bool unbounded = active && !(thr_in > L::ninf());       // no bound yet (-inf): the smallest entry is the bracket's low end
+    if (wave_any(unbounded)) {
+        S mn = L::pinf();
+        for (int i = 0; i < cend; i += 16) {
+            S x[16];
+            #pragma unroll
+            for (int t = 0; t < 16; t++) x[t] = L::load(sc + (size_t)(i + t) * WAVE);
+            #pragma unroll
+            for (int t = 0; t < 16; t++) mn = x[t] < mn ? x[t] : mn;      // (NaN: compare false)
+        }
+        mn = L::umin(mn);
+        if (unbounded) lo = ord_key(mn);
+    }
+    const Key lo0 = lo;
+    int cT = C;                                                     // entries at or above unkey(lo) (at lo0: an upper bound, see below)
+    bool done = !active;
+    for (int pass = 0; wave_any(!done); pass++) {
+        Key k1, k2, k3;
+        const Key d = hi - lo;                                      // >= 2 while not done
+        bool by_value = false;
+        if (pass < 8) {                                             // quartiles in value space
+            const S lf = ord_unkey(lo), hf = ord_unkey(hi - 1);
+            if (L::finite(lf) && L::finite(hf)) {
+                const S w = hf - lf;
+                k1 = ord_key(lf + w * (S)0.25); k2 = ord_key(lf + w * (S)0.5); k3 = ord_key(lf + w * (S)0.75);
+                by_value = k1 > lo && k2 >= k1 && k3 >= k2 && k3 < hi;
+            }
+        }
+        if (!by_value) {                                            // quartiles in key space: (d >> 2) * 3 < d
+            const Key q = d >> 2;
+            k1 = lo + (q ? q : (Key)1); k2 = lo + (q ? 2 * q : (Key)1); k3 = lo + (q ? 3 * q : (Key)1);
+        }
+        int c1, c2, c3;
+        lane_count3<S>(sc, cend, ord_unkey(k1), ord_unkey(k2), ord_unkey(k3), c1, c2, c3);
+        c1 = L::usum(c1); c2 = L::usum(c2); c3 = L::usum(c3);
+        if (!done) {
+            if (c3 >= K) { lo = k3; cT = c3; }
+            else if (c2 >= K) { lo = k2; cT = c2; hi = k3; }
+            else if (c1 >= K) { lo = k1; cT = c1; hi = k2; }
+            else hi = k1;
+            done = cT <= K + slack || hi - lo <= 1;
+        }
+    }
+    S T = ord_unkey(lo);
+    // The lane's bound may have come from ANOTHER partial list of the user since the entries were appended (the shared bound): then
+    // some entries lie below it and possibly fewer than K at or above it -- no probe found K, the bracket closed on its low end,
+    // whose count was never taken.  Take it: with fewer than K the lane keeps what reaches the bound it has and learns nothing new.
+    const bool below = active && lo == lo0 && !unbounded;
+    bool own_short = false;
+    if (wave_any(below)) {
+        int c0 = 0;
+        for (int i = 0; i < cend; i++) { const S x = L::load(sc + (size_t)i * WAVE); c0 += x >= T; }
+        c0 = L::usum(c0);
+        if (below) { cT = c0; own_short = c0 < K; }
+    }
+    if (own_short) T = thr_in;
+    // ---- exact ties: more than K + slack entries at or above the exact K-th best score -> cut the ties by item id ----
+    const bool ties = active && !own_short && cT > K + slack;
+    int item_max = IDX_EMPTY;
+    if (wave_any(ties)) {
+        const S above = ord_unkey(lo + 1);
+        int ngt = 0;
+        for (int i = 0; i < cend; i++) { const S x = L::load(sc + (size_t)i * WAVE); ngt += x >= above; }
+        const int need = K - L::usum(ngt);                          // >= 1 ties to keep: those with the smallest items
+        int ilo = -1, ihi = n_items - 1;                            // #(ties with item <= ilo) < need <= #(... <= ihi)
+        while (wave_any(ties && ihi - ilo > 1)) {
+            const int im = ilo + ((ihi - ilo) >> 1);
+            int c = 0;
+            for (int i = 0; i < cend; i++) {
+                const S x = L::load(sc + (size_t)i * WAVE);
+                const int id = lane_sel_load_item(it + (size_t)i * WAVE);
+                c += (x == T) && id <= im;
+            }
+            c = L::usum(c);
+            if (ties && ihi - ilo > 1) { if (c >= need) ihi = im; else ilo = im; }
+        }
+        if (ties) item_max = ihi;
+    }
+    // ---- pack the survivors to the front of the lane's own buffer ----
+    int j = 0;
+    for (int i = 0; i < cend; i += 8) {
+        S x[8]; int id[8];
+        #pragma unroll
+        for (int t = 0; t < 8; t++) { x[t] = L::load(sc + (size_t)(i + t) * WAVE); id[t] = lane_sel_load_item(it + (size_t)(i + t) * WAVE); }
+        #pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const bool keep = active && x[t] >= T && (!ties || x[t] > T || id[t] <= item_max);
+            if (keep) {
+                if (j != i + t) { sc[(size_t)j * WAVE] = x[t]; it[(size_t)j * WAVE] = id[t]; }
+                j++;
+            }
+        }
+    }
+    if (active) cnt = j;
+    if (active && !own_short) {
+        const S tn = ties ? ord_unkey(lo + 1) : T;
+        thr_out = tn > thr_in ? tn : thr_in;
+        kth_key = lo;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // survivors in place before anyone appends behind them
+}
+template <class S>
+__device__ __attribute__((noinline)) void lane_select_call(S *sc, int *it, int &cnt, const int K, const bool primary, const S thr_in, const S hi_hint,
+                                                           const int n_items, S &thr_out, typename LaneSel<S>::Key &kth_key)
+{
+    lane_select<S>(sc, it, cnt, K, primary, thr_in, hi_hint, n_items, thr_out, kth_key);
+}
 
 } // namespace rm

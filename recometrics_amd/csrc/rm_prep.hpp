@@ -1029,6 +1029,8 @@ __global__ __launch_bounds__(POSF_WAVES * WAVE) void k_pos_scores_flat(PosArgs<T
         }
         #pragma unroll
         for (int q = 0; q < WAVE / RPI; q++) *(VT *)&rows[wv][q * RPI + rsub][piece * VE] = bv[q];
+        // (the pieces change lanes through LDS: fenced like k_train_bits / k_pos_place, not left to the compiler's alias analysis)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
         const T *r = rows[wv][lane];
         if (k0 + CH <= a.k) {
             #pragma unroll
@@ -1045,6 +1047,7 @@ __global__ __launch_bounds__(POSF_WAVES * WAVE) void k_pos_scores_flat(PosArgs<T
                 for (int i = 0; i < VE; i++) if (k0 + j * VE + i < a.k) s = fma_chain_step(av[j][i], b[i], s);
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();      // the rows are rewritten by the next chunk
     }
     // (whether the train row holds the item is not known here: k_pos_apply_masked overwrites those entries afterwards.  A user
     // flagged for one of them goes through an exact pass it did not need -- same results.)

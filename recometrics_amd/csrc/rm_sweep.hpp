@@ -358,8 +358,8 @@ void k_sweep(SweepArgs a)
     for (int g = 0; g < NG; g++)
         af[g] = (group_ok || !AF_RESIDENT) ? af_src[(size_t)g * 2 * GROUP_USERS] : make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // top-K list of this wave, owned by the lanes with h == 0.  LDS: [K][32 users], unsorted, replace-the-minimum.
-    // HBM (lists that do not fit LDS): per user an append buffer of 2K + 32 entries + wave-cooperative compaction.
+    // top-K list of this wave.  LDS: [K][32 users], unsorted, replace-the-minimum, owned by the lanes with h == 0.
+    // HBM, K <= 32: the same scheme in memory.  HBM, K > 32: per-LANE append buffers + lane-parallel selection (rm_list.hpp).
     const int CAP = 2 * K + 32;
     // The LDS list is shared by the NSUB waves of a user group (same users, interleaved item sub-tiles): its K-th best is
     // the K-th best of everything the group has seen, not of a third of it, so fewer scores pass the bound (C2: 180
@@ -369,11 +369,16 @@ void k_sweep(SweepArgs a)
     LdsListPtr Lwk = Ll + K * GROUP_USERS, Lwp = Ll + (K + 1) * GROUP_USERS;
     LdsU32Ptr list_lock = (LdsU32Ptr)(smem + a.sync_off) + 4 + gi;
     unsigned long long wkey = 0;                                   // LDS list: key of its worst entry (0 = empty slot)
-    GblListPtr Gw = LLDS ? nullptr : a.glists + ((size_t)blockIdx.x * NWAVES + wave) * GROUP_USERS * CAP;    // wave's 32 buffers
-    GblListPtr Gu = LLDS ? nullptr : Gw + (size_t)ul * CAP;                                                // this user's
-    // small K in HBM: [K][32 users] replace-the-minimum like the LDS list (cheaper than compactions below K ~ 32)
-    GblListPtr Lr = LLDS ? nullptr : a.glists + ((size_t)blockIdx.x * NWAVES + wave) * GROUP_USERS * CAP + ul;
-    float ws = neg_inf_f(); int widx = IDX_EMPTY, wpos = 0, cnt = 0;
+    // small K in HBM: [K][32 users] replace-the-minimum like the LDS list (cheaper than selections below K ~ 32)
+    GblListPtr Lr = (LLDS || buffered) ? nullptr : a.glists + ((size_t)blockIdx.x * NWAVES + wave) * GROUP_USERS * CAP + ul;
+    // K > 32: the wave's lane buffers, [entry][64 lanes]: lane_cap scores, then lane_cap item ids (scalar bases, the lane's next
+    // entry as a 32-bit byte offset: a store is global_store_dword voff, data, sbase -- no 64-bit vector address arithmetic)
+    const int lane_cap = a.lane_cap;
+    const char *lb_scores = buffered ? (const char *)a.glists + ((size_t)blockIdx.x * NWAVES + wave) * ((size_t)lane_cap * (WAVE * 8)) : nullptr;
+    const char *lb_items = buffered ? lb_scores + (size_t)lane_cap * (WAVE * 4) : nullptr;
+    unsigned lb_off = (unsigned)lane * 4u;                        // (entries of the lane) * 256 + lane * 4
+    const unsigned lb_trigger = (unsigned)(lane_cap - 15) << 8;   // a tile appends at most 16 per lane: select when cnt > lane_cap - 16
+    float ws = neg_inf_f(); int widx = IDX_EMPTY, wpos = 0;
     if (LLDS) {
         if (sub == 0 && h == 0) for (int i = 0; i < K + 2; i++) Ll[i * GROUP_USERS] = 0ull;
         if (tid < 4) ((LdsU32Ptr)(smem + a.sync_off))[4 + tid] = 0u;
@@ -395,20 +400,6 @@ void k_sweep(SweepArgs a)
         if (h == 0) { Lwk[0] = wkey; Lwp[0] = (unsigned long long)wpos; }
         if (lane == 0) __hip_atomic_store(list_lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
-    // compaction of every owner lane in `need` (wave-uniform mask): K best kept, sorted; (ws, widx) = the K-th
-    auto compact_users = [&](unsigned long long need, bool final_sorted = false) {
-        while (need) {
-            const int l = __ffsll((long long)need) - 1;
-            need &= need - 1;
-            const int c = lane_bcast<int>(cnt, l);
-            RM_STAT(8, 1); RM_STAT(9, c);
-            float ks; int ki;
-            // during the sweep the K best need not be sorted (bisection select); the list handed to k_finalize must be
-            if (final_sorted || c < K) wave_compact<float>(Gw + (size_t)l * CAP, c, K, lane, ks, ki);
-            else wave_select_call<float>(Gw + (size_t)l * CAP, c, K, lane, ks, ki);
-            if (lane == l) { cnt = c < K ? c : K; if (c >= K) { ws = ks; widx = ki; } }
-        }
-    };
     // Pending buffers (a.pend_cap > 0, whenever LDS has room): a candidate is first appended to its LANE's small buffer
     // ([pend_cap][64 lanes] packed keys per wave: one LDS write), and the buffers are merged into the lists for all 32
     // users of the wave at once when one of them fills up.  Offering candidates one score register at a time keeps 1-2
@@ -422,8 +413,7 @@ void k_sweep(SweepArgs a)
         if (LLDS) { keylist_offer<GROUP_USERS>(Ll, K, key, wkey, wpos); return; }
         float s; int item;
         unpack_key(key, s, item);
-        if (buffered) { if (s > ws || (s == ws && item < widx)) Gu[cnt++] = ListRaw<float>::pack(s, item); }
-        else if (s >= ws) list_offer<float, GROUP_USERS>(Lr, K, s, item, ws, widx, wpos);
+        if (s >= ws) list_offer<float, GROUP_USERS>(Lr, K, s, item, ws, widx, wpos);
     };
     bool merged = false;                                          // a merge since the bound was last published
     auto merge_pending = [&]() {
@@ -442,7 +432,6 @@ void k_sweep(SweepArgs a)
         list_release();
         pcnt = 0;
         if (LLDS) ws = (wkey >> 32) ? ord_unkey((unsigned)(wkey >> 32)) : neg_inf_f();
-        else if (buffered) compact_users(__ballot(h == 0 && primary && cnt > 2 * K));   // <= 2 * pend_cap <= 32 appended since the last check
     };
 
     // positives -> LDS, histogram zeroed
@@ -591,6 +580,20 @@ void k_sweep(SweepArgs a)
     // last key this lane published / observed (lanes that own no list never follow the shared bound: all ones, so that the test
     // below is ONE compare whose lane mask the scalar unit can look at)
     unsigned thr_pub = primary ? 0u : 0xffffffffu;
+    auto lane_bounds = [&]() {
+        int c = (int)(lb_off >> 8);
+        float t_new; unsigned kk;
+        // (no entry of the user exceeds the larger of its two lanes' running maxima -- unless the tie noise moved it)
+        const float hi_hint = f_noise ? pos_inf_f() : LaneSel<float>::umax(vmax);
+        lane_select<float>((float *)lb_scores + lane, (int *)lb_items + lane, c, K, primary, thr, hi_hint, n, t_new, kk);
+        lb_off = ((unsigned)c << 8) | ((unsigned)lane * 4u);
+        RM_STAT(8, 1);
+        if (kk) {
+            thr = t_new;
+            if (h == 0 && kk > thr_pub) atomicMax(a.thr_shared + slot, kk);
+            thr_pub = kk > thr_pub ? kk : thr_pub;
+        }
+    };
     auto do_epi = [&](const f32x16 &acc, int tile, unsigned thr_seen, unsigned tile_bits) {
         const int sb = tile * TILE + sub * 32;            // first item of this wave's sub-tile
         float v[16];
@@ -701,6 +704,26 @@ void k_sweep(SweepArgs a)
         // (a.ext_topk: k_metrics beyond the lists' reach -- every lane streams its scores and k_select_topk picks the top-K)
         const unsigned long long cm = f_ext ? 0ull : __ballot(tmax >= thr);
         RM_STAT(0, 1); RM_STAT(1, cm != 0); RM_STAT(2, __popcll(cm));
+        if (buffered) {
+            // K > 32: every lane appends its own candidates to its own buffer (rm_list.hpp): per score register a compare, two
+            // stores under the lane mask, an add -- a register quad without a candidate in any lane is skipped with one test
+            if (cm) {
+                const int sbh = sb + 4 * h;
+                #pragma unroll
+                for (int qd = 0; qd < 4; qd++) {
+                    if (!__ballot(qmax[qd] >= thr)) continue;
+                    #pragma unroll
+                    for (int r = 4 * qd; r < 4 * qd + 4; r++) {
+                        if (v[r] >= thr) {
+                            const int item = sbh + (r & 3) + 8 * (r >> 2);
+                            asm volatile("global_store_dword %0, %1, %2" :: "v"(lb_off), "v"(v[r]), "s"(lb_scores) : "memory");
+                            asm volatile("global_store_dword %0, %1, %2" :: "v"(lb_off), "v"(item), "s"(lb_items) : "memory");
+                            lb_off += 256u;
+                        }
+                    }
+                }
+            }
+        } else
         if (cm && pend_cap) {
             unsigned ov = 0;                                    // score registers that did not fit the lane's buffer
             #pragma unroll
@@ -750,17 +773,14 @@ void k_sweep(SweepArgs a)
                         if (LLDS) { if (v[r] >= ws) keylist_offer<GROUP_USERS>(Ll, K, pack_key(v[r], item0), wkey, wpos);
                                     if (other >= ws) keylist_offer<GROUP_USERS>(Ll, K, pack_key(other, item1), wkey, wpos);
                                     ws = (wkey >> 32) ? ord_unkey((unsigned)(wkey >> 32)) : neg_inf_f(); }
-                        else if (buffered) { if (v[r] > ws || (v[r] == ws && item0 < widx)) Gu[cnt++] = ListRaw<float>::pack(v[r], item0);
-                                             if (other > ws || (other == ws && item1 < widx)) Gu[cnt++] = ListRaw<float>::pack(other, item1); }
                         else      { if (v[r] >= ws) list_offer<float, GROUP_USERS>(Lr, K, v[r], item0, ws, widx, wpos);
                                     if (other >= ws) list_offer<float, GROUP_USERS>(Lr, K, other, item1, ws, widx, wpos); }
                     }
                 }
             }
             list_release();
-            if (!LLDS && buffered) compact_users(__ballot(h == 0 && primary && cnt > 2 * K));
         }
-        if (cm && (!pend_cap || merged)) {                      // with pending buffers the K-th best only moves in a merge
+        if (!buffered && cm && (!pend_cap || merged)) {         // with pending buffers the K-th best only moves in a merge
             merged = false;
             const float t2 = __shfl(ws, ul);
             if (primary) {
@@ -792,6 +812,9 @@ void k_sweep(SweepArgs a)
             }
         }
 #endif
+        // K > 32: some lane is a tile away from a full buffer -> every user of the wave raises its bound (at the END of the
+        // epilogue: the tile's scores are dead, their registers hold the selection's loads in flight)
+        if (buffered && wave_any(lb_off >= lb_trigger)) lane_bounds();
     };
 
     // ---- main loop: one barrier per tile.  Measured on gfx950 (scratch/coexec2.hip): an f32-input MFMA chain and
@@ -964,14 +987,9 @@ void k_sweep(SweepArgs a)
             for (int i = 0; i < K; i++) ListRaw<float>::unpack(Lr[i * GROUP_USERS], dst[i].s, dst[i].idx);
         }
     } else if (!LLDS && !a.ext_topk) {
-        compact_users(__ballot(slot_ok && h == 0 && primary && cnt > 0), true);
-        if (slot_ok && h == 0) {
-            ListEntry *dst = a.pl + ((size_t)slot * n_part + part) * K;
-            for (int i = 0; i < K; i++) {
-                if (i < cnt) ListRaw<float>::unpack(ListRaw<float>::load_l2(Gu + i), dst[i].s, dst[i].idx);
-                else { dst[i].s = neg_inf_f(); dst[i].idx = IDX_EMPTY; }
-            }
-        }
+        // the lanes' entries stay where they are: k_collect_topk (rm_finalize.hpp) reads the buffers of all item ranges and sub-tile
+        // waves of a user and writes its ordered top-K
+        a.lane_cnt[((size_t)blockIdx.x * NWAVES + wave) * WAVE + lane] = (slot_ok && primary) ? (int)(lb_off >> 8) : 0;
     }
     if (AUC) {
         __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): the asm histogram atomics are invisible to the compiler

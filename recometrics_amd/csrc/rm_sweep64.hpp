@@ -185,33 +185,22 @@ void k_sweep64(Sweep64Args a)
         }
     }
 
-    // top-K list owned by the q == 0 lane of the user: LDS [K][16 users] replace-the-minimum, or HBM append buffer +
-    // wave-cooperative compaction when the lists do not fit LDS (rm_list.hpp)
+    // top-K list owned by the q == 0 lane of the user: LDS [K][16 users] replace-the-minimum, the same scheme in HBM (K <= 32), or --
+    // K > 32 -- per-LANE append buffers in HBM with lane-parallel selection (rm_list.hpp)
     const int CAP = 2 * K + 32;
     LdsList64Ptr Ll = (LdsList64Ptr)((GblList64Ptr)lists_lds + wave * K * GU + ul);
-    GblList64Ptr Gw = LLDS ? nullptr : a.glists + ((size_t)blockIdx.x * 8 + wave) * GU * CAP;
-    GblList64Ptr Gu = LLDS ? nullptr : Gw + (size_t)ul * CAP;
-    GblList64Ptr Lr = LLDS ? nullptr : a.glists + ((size_t)blockIdx.x * 8 + wave) * GU * CAP + ul;
-    double ws = neg_inf_d(); int widx = IDX_EMPTY, wpos = 0, cnt = 0;
+    GblList64Ptr Lr = (LLDS || buffered) ? nullptr : a.glists + ((size_t)blockIdx.x * 8 + wave) * GU * CAP + ul;
+    // the wave's lane buffers, [entry][64 lanes]: lane_cap scores (8 B), then lane_cap item ids (4 B); the lane's next entry as a
+    // 32-bit byte offset into the scores (the items' offset is half of it)
+    const int lane_cap = a.lane_cap;
+    const char *lb_scores = buffered ? (const char *)a.glists + ((size_t)blockIdx.x * 8 + wave) * ((size_t)lane_cap * (WAVE * 12)) : nullptr;
+    const char *lb_items = buffered ? lb_scores + (size_t)lane_cap * (WAVE * 8) : nullptr;
+    unsigned lb_off = (unsigned)lane * 8u;                        // (entries of the lane) * 512 + lane * 8
+    const unsigned lb_trigger = (unsigned)(lane_cap - 7) << 9;    // a tile appends at most 8 per lane: select when cnt > lane_cap - 8
+    double ws = neg_inf_d(); int widx = IDX_EMPTY, wpos = 0;
     if (q == 0 && (LLDS || !buffered)) for (int i = 0; i < K; i++) {
         if (LLDS) Ll[i * GU] = ListRaw<double>::pack(neg_inf_d(), IDX_EMPTY); else Lr[i * GU] = ListRaw<double>::pack(neg_inf_d(), IDX_EMPTY);
     }
-    auto compact_users = [&](unsigned long long need, bool final_sorted = false) {
-        while (need) {
-            const int l = __ffsll((long long)need) - 1;
-            need &= need - 1;
-            const int c = lane_bcast<int>(cnt, l);
-            double ks; int ki;
-#ifdef RM_ABL_NO_COMPACT
-            ks = 1e300; ki = 0;
-#else
-            // during the sweep the K best need not be sorted (bisection select); the list handed to k_finalize must be
-            if (final_sorted || c < K) wave_compact_call<double>(Gw + (size_t)l * CAP, c, K, lane, ks, ki);
-            else wave_select_call<double>(Gw + (size_t)l * CAP, c, K, lane, ks, ki);
-#endif
-            if (lane == l) { cnt = c < K ? c : K; if (c >= K) { ws = ks; widx = ki; } }
-        }
-    };
 
     // Pending buffers (a.pend_cap > 0): every lane appends its own candidates to a small LDS buffer ([pend_cap][64 lanes],
     // scores and items in separate arrays), and the buffers of all 16 users of the wave are merged into their lists
@@ -220,13 +209,12 @@ void k_sweep64(Sweep64Args a)
     typedef __attribute__((address_space(3))) double *LdsF64Ptr;
     typedef __attribute__((address_space(3))) int *LdsI32Ptr;
     const int pend_want = pend_room < a.pend_cap ? pend_room : a.pend_cap;        // a.pend_cap = the most that is useful (0 = off)
-    const int pend_cap = pend_want < 2 ? 0 : pend_want;
+    const int pend_cap = (buffered || pend_want < 2) ? 0 : pend_want;
     int pcnt = 0;
     LdsF64Ptr Ps = (LdsF64Ptr)pend_lds + wave * pend_cap * WAVE + lane;
     LdsI32Ptr Pi = (LdsI32Ptr)(pend_lds + 8 * pend_cap * WAVE * 8) + wave * pend_cap * WAVE + lane;
     auto offer_entry = [&](double s, int item) {                  // owner lanes only
         if (LLDS) { if (s >= ws) list_offer<double, GU>(Ll, K, s, item, ws, widx, wpos); }
-        else if (buffered) { if (s > ws || (s == ws && item < widx)) Gu[cnt++] = ListRaw<double>::pack(s, item); }
         else if (s >= ws) list_offer<double, GU>(Lr, K, s, item, ws, widx, wpos);
     };
     bool merged = false;                                          // a merge since the bound was last published
@@ -244,7 +232,6 @@ void k_sweep64(Sweep64Args a)
             }
         }
         pcnt = 0;
-        if (buffered) compact_users(__ballot(q == 0 && primary && cnt > 2 * K));     // <= 4 * pend_cap <= 32 appended since the last check
     };
 
     if (AUC) {
@@ -294,6 +281,19 @@ void k_sweep64(Sweep64Args a)
     };
 
     unsigned long long thr_pub = 0;
+    auto lane_bounds = [&]() {
+        int c = (int)(lb_off >> 9);
+        double t_new; unsigned long long kk;
+        const double hi_hint = f_noise ? pos_inf_d() : LaneSel<double>::umax(vmax);
+        // (out of line: inlined, the selection's working set is added to a register budget that is already full at 256 factors)
+        lane_select_call<double>((double *)lb_scores + lane, (int *)lb_items + lane, c, K, primary, thr, hi_hint, n, t_new, kk);
+        lb_off = ((unsigned)c << 9) | ((unsigned)lane * 8u);
+        if (kk) {
+            thr = t_new;
+            if (q == 0 && kk > thr_pub) atomicMax(a.thr_shared + slot, kk);
+            thr_pub = kk > thr_pub ? kk : thr_pub;
+        }
+    };
     auto do_epi = [&](const f64x4 &acc_lo, const f64x4 &acc_hi, int tile, unsigned long long thr_seen) {
         const int sb = tile * TILE_ITEMS + sub * 32;
         double v[8];
@@ -355,6 +355,22 @@ void k_sweep64(Sweep64Args a)
             #pragma unroll
             for (int r = 0; r < 8; r++) cm |= __ballot(v[r] >= thr);
         }
+        if (buffered) {
+            // K > 32: every lane appends its own candidates to its own buffer (rm_list.hpp)
+            if (cm) {
+                const int sbq = sb + q;
+                #pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    if (v[r] >= thr) {
+                        const int item = sbq + (r >> 2) * 16 + 4 * (r & 3);
+                        const unsigned ioff = lb_off >> 1;
+                        asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(lb_off), "v"(v[r]), "s"(lb_scores) : "memory");
+                        asm volatile("global_store_dword %0, %1, %2" :: "v"(ioff), "v"(item), "s"(lb_items) : "memory");
+                        lb_off += 512u;
+                    }
+                }
+            }
+        } else
         if (cm && pend_cap) {
             unsigned ov = 0;                                    // score registers that did not fit the lane's buffer
             #pragma unroll
@@ -396,11 +412,6 @@ void k_sweep64(Sweep64Args a)
                             if (o1 >= ws) list_offer<double, GU>(Ll, K, o1, ib + 1, ws, widx, wpos);
                             if (o2 >= ws) list_offer<double, GU>(Ll, K, o2, ib + 2, ws, widx, wpos);
                             if (o3 >= ws) list_offer<double, GU>(Ll, K, o3, ib + 3, ws, widx, wpos);
-                        } else if (buffered) {
-                            if (v[r] > ws || (v[r] == ws && ib < widx)) Gu[cnt++] = ListRaw<double>::pack(v[r], ib);
-                            if (o1 > ws || (o1 == ws && ib + 1 < widx)) Gu[cnt++] = ListRaw<double>::pack(o1, ib + 1);
-                            if (o2 > ws || (o2 == ws && ib + 2 < widx)) Gu[cnt++] = ListRaw<double>::pack(o2, ib + 2);
-                            if (o3 > ws || (o3 == ws && ib + 3 < widx)) Gu[cnt++] = ListRaw<double>::pack(o3, ib + 3);
                         } else {
                             if (v[r] >= ws) list_offer<double, GU>(Lr, K, v[r], ib, ws, widx, wpos);
                             if (o1 >= ws) list_offer<double, GU>(Lr, K, o1, ib + 1, ws, widx, wpos);
@@ -410,9 +421,8 @@ void k_sweep64(Sweep64Args a)
                     }
                 }
             }
-            if (!LLDS && buffered) compact_users(__ballot(q == 0 && primary && cnt > 2 * K));
         }
-        if (cm && (!pend_cap || merged)) {                      // with pending buffers the K-th best only moves in a merge
+        if (!buffered && cm && (!pend_cap || merged)) {                      // with pending buffers the K-th best only moves in a merge
             merged = false;
             const double t2 = __shfl(ws, ul);
             if (primary) {
@@ -439,6 +449,8 @@ void k_sweep64(Sweep64Args a)
                 default: break;
             }
         }
+        // K > 32: some lane is a tile away from a full buffer -> every user of the wave raises its bound (see the fp32 sweep)
+        if (buffered && wave_any(lb_off >= lb_trigger)) lane_bounds();
     };
 
     // ---- main loop over tiles, chunks of the factor axis statically unrolled inside; one barrier per chunk.  All waves
@@ -604,14 +616,8 @@ void k_sweep64(Sweep64Args a)
             for (int i = 0; i < K; i++) ListRaw<double>::unpack(Lr[i * GU], dst[i].s, dst[i].idx);
         }
     } else if (!LLDS && !a.ext_topk) {
-        compact_users(__ballot(slot_ok && q == 0 && primary && cnt > 0), true);
-        if (slot_ok && q == 0) {
-            Entry<double> *dst = a.pl + ((size_t)slot * n_part + part) * K;
-            for (int i = 0; i < K; i++) {
-                if (i < cnt) ListRaw<double>::unpack(ListRaw<double>::load_l2(Gu + i), dst[i].s, dst[i].idx);
-                else { dst[i].s = neg_inf_d(); dst[i].idx = IDX_EMPTY; }
-            }
-        }
+        // the lanes' entries stay where they are: k_collect_topk (rm_finalize.hpp) writes the user's ordered top-K from them
+        a.lane_cnt[((size_t)blockIdx.x * 8 + wave) * WAVE + lane] = (slot_ok && primary) ? (int)(lb_off >> 9) : 0;
     }
     if (AUC) {
         __syncthreads();

@@ -1010,3 +1010,41 @@ def test_baseline_c5_at_its_full_user_count(hip):
     """C5: 200,000 users x 500,000 items x 256 factors fp64, K = 50, all ten metrics, ONE device call"""
     got = _full_m_run("C5", False, 160, 8.0)
     _full_m_asserts(got, 200_000)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# k_metrics beyond the LDS lists (round 6): per-lane append buffers + lane-parallel selection in the sweep, k_collect_topk behind it
+@pytest.mark.parametrize("env", [{}, {"RM_DEBUG_LANE_CAP_MIN": "1"}, {"RM_DEBUG_LANE_CAP_MIN": "1", "RM_DEBUG_SPLITS": "3,2,5"},
+                                 {"RM_DEBUG_LANE_CAP_MIN": "1", "RM_DEBUG_NO_SEED": "1", "RM_DEBUG_NO_TRAIN_BITS": "1"}])
+@pytest.mark.parametrize("dtype,K", [(np.float32, 33), (np.float32, 100), (np.float32, 256), (np.float64, 40), (np.float64, 50), (np.float64, 256)])
+def test_lane_buffers_and_selections(hip, oracle, dtype, K, env, monkeypatch):
+    """the smallest lane buffers that work force a selection every few tiles (the default size sees two per item range at these sizes);
+    several item ranges per user make the shared bound overtake a lane's own entries (lane_select's `below` case) and give
+    k_collect_topk many sources"""
+    from recometrics_amd.synth import make_problem
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    pr = make_problem(140, 12000, 40 if dtype == np.float32 else 24, dtype, mean_c=70, seed=600 + K)
+    _check_against_oracle(hip, oracle, pr, K, dtype=dtype)
+
+
+@pytest.mark.parametrize("env", [{}, {"RM_DEBUG_LANE_CAP_MIN": "1"}])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_lane_selection_cuts_exact_ties_by_item(hip, oracle, dtype, env, monkeypatch):
+    """item factors repeated in runs: every score occurs 40 times in a row, far more exact ties at a user's K-th best than a
+    selection's slack -- the bisection ends on the exact score and the ties are cut by item id (rm_list.hpp lane_select)"""
+    from recometrics_amd.synth import make_problem
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    pr = make_problem(70, 8000, 16, dtype, mean_c=40, seed=77)
+    B = pr["B"].copy()
+    B[:] = B[(np.arange(B.shape[0]) // 40) * 40]
+    pr["B"] = B
+    trp, tri = pr["train"]
+    tep, tei = pr["test"][:2]
+    want = oracle.rank(pr["A"], pr["B"], pr["train"], pr["test"], 48, dtype=dtype, nthreads=NT)
+    got = hip.rank(np.ascontiguousarray(pr["A"], dtype), np.ascontiguousarray(B, dtype), trp, tri, tep, tei, 48)
+    assert (got["status"] == want["status"]).all()
+    assert (got["topk_idx"] == want["topk_idx"]).all(), "top-K index lists differ"
+    assert_same_bits(got["topk_score"], want["topk_score"], "top-K scores")
+    assert (got["pos_rank"] == want["pos_rank"]).all(), "positive ranks differ"
