@@ -80,8 +80,12 @@ def _compile(src, extra, incremental=False):
     obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
     # (development only, `build(incremental=True)`: an object newer than its source and every header is kept; the library's own
     # stamp stays content-based)
-    if incremental and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(p) for p in [os.path.join(CSRC, src)] + _headers()):
-        return obj, ""
+    if incremental and os.path.exists(obj):
+        hdrs = _headers()
+        if src.startswith("rm_sweep"):       # the sweeps' units include neither the preparation nor the finalisation kernels
+            hdrs = [h for h in hdrs if os.path.basename(h) not in ("rm_finalize.hpp", "rm_prep.hpp", "rm_noise.hpp")]
+        if os.path.getmtime(obj) > max(os.path.getmtime(p) for p in [os.path.join(CSRC, src)] + hdrs):
+            return obj, ""
     if src.startswith("rm_sweep"):
         extra = list(extra) + SWEEP_FLAGS
     if src.endswith(".cpp"):        # host-only translation unit
@@ -100,6 +104,7 @@ def build(force=False, verbose=False, extra_flags=(), out=None, incremental=Fals
         return LIB
     import time
     t_start = time.time()
+    digest_at_start = sources_digest()        # (what the objects are compiled FROM: an edit during the build must not be stamped as built)
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
         results = list(ex.map(lambda s: _compile(s, extra_flags, incremental), SOURCES))
     if verbose:
@@ -112,7 +117,7 @@ def build(force=False, verbose=False, extra_flags=(), out=None, incremental=Fals
     if out == LIB:                  # every build into LIB leaves its stamp, debug / ablation flags included (`extra_flags`)
         import json
         ver = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True).stdout.splitlines()
-        json.dump({"sources_sha256": sources_digest(), "library_bytes": os.path.getsize(LIB), "built_at": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
+        json.dump({"sources_sha256": digest_at_start, "library_bytes": os.path.getsize(LIB), "built_at": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
                    "translation_units": SOURCES, "flags": FLAGS, "sweep_flags": SWEEP_FLAGS, "extra_flags": list(extra_flags), "hipcc": ver[0] if ver else "?",
                    "seconds": round(time.time() - t_start, 1)}, open(STAMP, "w"), indent=1)
     return out

@@ -12,7 +12,6 @@ namespace rm {
 constexpr int MAX_PARTS = 128;
 constexpr int FIN_THREADS = 128;      // block size of k_finalize
 constexpr int FIN_TOPV = 64;          // sorted buffer of the largest test values (ideal DCG) per thread
-constexpr int HEAVY_TOPV_MAX = 256;   // ... per user in k_top_values' output (k_metrics beyond it: the lists are out of reach anyway, ext_topk)
 template <class T> inline size_t finalize_lds_bytes(int K, int n_part) { return (sizeof(T) * (size_t)(K < FIN_TOPV ? K : FIN_TOPV) + 4 * (size_t)n_part) * FIN_THREADS; }
 
 // per-slot result of the rank-histogram walk (k_auc_slots), combined per user by k_finalize
@@ -30,7 +29,7 @@ template <class T, class S> struct FinalArgs {     // T = real_t of inputs/outpu
     T *heavy_topv;               // [m][heavy_ld] largest test values (descending) of users with more than
     unsigned char *heavy_nan;    // [m]    ... HEAVY_NPOS test items, and whether any of their values is NaN (k_top_values)
     const int *heavy_users; int n_heavy;     // those users (k_classify)
-    int heavy_npos, heavy_ld;                // ... rows longer than heavy_npos; heavy_topv holds heavy_ld = min(K, HEAVY_TOPV_MAX) values per user
+    int heavy_npos, heavy_ld;                // ... rows longer than heavy_npos; heavy_topv holds heavy_ld = min(K, longest test row) values per user
     const double *log2tab;
     T *p, *tp, *r, *ap, *tap, *ndcg, *hit, *rr, *roc, *pr;
     Entry<S> *merged;            // [m][K]   final ordered top-K (also the rm_rank_* output)
@@ -595,8 +594,10 @@ __global__ __launch_bounds__(SELECT_THREADS) void k_select_topk(FinalArgs<T, S> 
 // test items, when the sweep ran over rows that mask them: rm_sweep.hpp, k_merge_positives), sorts them by a bitonic network and
 // writes the first K to `merged`, where k_finalize finds them.  When more entries come than LDS holds, it sorts and keeps K in
 // between.  Order: (score desc, item asc) = (key desc, ~item desc).
-constexpr int COLLECT_THREADS = 256;
-constexpr int COLLECT_CAP = 4096;                                // entries in LDS: 32 KB (fp32) / 48 KB (fp64)
+// One WAVEFRONT per user, its entries in a private piece of LDS, no block barrier anywhere: a bitonic pass is `pairs / 64` compare-
+// exchanges per lane between two wave-level fences.  (First version, round 6: a block of 256 threads per user with __syncthreads
+// per pass -- 45 passes of a microsecond each with four blocks per CU: 4.5 ms for BASELINE C2's 138,493 users at K = 100.)
+// CAPW = entries per wavefront: 1,024 (four users per block) up to K = 320, 4,096 (one user per block) beyond.
 struct CollectGeom {
     int ublock0, n_ublocks, n_splits, tail_ublocks, tail_splits;   // the sweep's grid (rm_launch.hpp SweepArgs)
     int nsub, gu, lpu;                                              // sub-tile waves per group, users per group, lanes per user
@@ -606,16 +607,21 @@ struct CollectGeom {
 template <class S> struct CollectKey;
 template <> struct CollectKey<float> { typedef unsigned T; };
 template <> struct CollectKey<double> { typedef unsigned long long T; };
+inline int collect_capw(int K, int lane_cap) { return K + lane_cap <= 1024 && 2 * K <= 1024 ? 1024 : 4096; }
+constexpr int COLLECT_MAX_ENTRIES = 4096;
 
-template <class T, class S, class ThrT>
-__global__ __launch_bounds__(COLLECT_THREADS) void k_collect_topk(FinalArgs<T, S> a, CollectGeom g, const char *glists, const int *lane_cnt, const ThrT *thr_shared)
+template <class T, class S, class ThrT, int CAPW>
+__global__ __launch_bounds__(CAPW == 1024 ? 256 : 64) void k_collect_topk(FinalArgs<T, S> a, CollectGeom g, const char *glists, const int *lane_cnt, const ThrT *thr_shared)
 {
     typedef typename CollectKey<S>::T KeyT;
-    __shared__ KeyT kh[COLLECT_CAP];
-    __shared__ unsigned kl[COLLECT_CAP];
-    __shared__ int sh_cur;
-    const int slot = blockIdx.x, tid = threadIdx.x;
-    if (a.slot_chunk[slot] != 0) return;
+    constexpr int WPB = CAPW == 1024 ? 4 : 1;                      // wavefronts (users) per block
+    __shared__ KeyT kh_all[WPB * CAPW];
+    __shared__ unsigned kl_all[WPB * CAPW];
+    const int lane = threadIdx.x & 63, wv_in_blk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = blockIdx.x * WPB + wv_in_blk;
+    if (slot >= a.n_slots || a.slot_chunk[slot] != 0) return;
+    KeyT *kh = kh_all + wv_in_blk * CAPW;
+    unsigned *kl = kl_all + wv_in_blk * CAPW;
     const int u = a.slot_user[slot];
     const int K = a.K;
     const int group = slot / g.gu, ul = slot % g.gu, gi = group % GROUPS_PER_BLOCK, blk_u = group / GROUPS_PER_BLOCK;
@@ -625,18 +631,69 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect_topk(FinalArgs<T, S
     const bool in_tail = rel < g.tail_ublocks;
     const int nsplit = in_tail ? g.tail_splits : g.n_splits;
     const KeyT bound = (KeyT)thr_shared[slot];                      // (0 = none: below every key)
-    if (tid == 0) sh_cur = 0;
-    __syncthreads();
-    // sort LDS entries [0, cur) descending, keep the first K
-    auto reduce = [&]() {
-        const int cur = sh_cur;
+    int cur = 0;                                                    // entries in LDS (wave-uniform)
+    auto wave_sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    // SELECT, then sort: the K best of the entries [0, cur) packed to the front in their old order.  The K-th best key by a radix
+    // descent over the keys in LDS -- a pass per bit below the prefix all keys share (scores between a user's bound and its best
+    // share a dozen leading bits), each a read, a compare and a ballot count per 64 entries -- then, only when more entries tie that
+    // key than are wanted, the same descent over the item words of the ties.  (First version: a bitonic sort of EVERYTHING gathered,
+    // 440 compare-exchanges per lane for 600 entries where this is ~25 passes of 10 reads and a 28-pass sort of the 128 kept.)
+    auto select_best = [&]() {
+        if (cur <= K) return;
+        wave_sync();
+        const int rows = (cur + WAVE - 1) / WAVE;
+        KeyT all_and = ~(KeyT)0, all_or = 0;
+        for (int r = 0; r < rows; r++) { const int i = r * WAVE + lane; if (i < cur) { const KeyT x = kh[i]; all_and &= x; all_or |= x; } }
+        #pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { all_and &= __shfl_xor(all_and, d); all_or |= __shfl_xor(all_or, d); }
+        const KeyT diff = all_and ^ all_or;
+        constexpr int BITS = (int)sizeof(KeyT) * 8;
+        int top = BITS - 1;                                         // highest bit in which two keys differ
+        while (top >= 0 && !((diff >> top) & 1)) top--;
+        KeyT Tk = top >= 0 ? (all_and & ~(((KeyT)2 << top) - 1)) : all_and;      // the shared prefix
+        for (int bit = top; bit >= 0; bit--) {
+            const KeyT cand = Tk | ((KeyT)1 << bit);
+            int c = 0;
+            for (int r = 0; r < rows; r++) { const int i = r * WAVE + lane; c += __popcll(__ballot(i < cur && kh[i] >= cand)); }
+            if (c >= K) Tk = cand;
+        }
+        int n_gt = 0, n_eq = 0;
+        for (int r = 0; r < rows; r++) {
+            const int i = r * WAVE + lane;
+            const KeyT x = i < cur ? kh[i] : 0;
+            n_gt += __popcll(__ballot(i < cur && x > Tk)); n_eq += __popcll(__ballot(i < cur && x == Tk));
+        }
+        const int need = K - n_gt;                                  // >= 1 of the n_eq ties: those with the largest item words
+        unsigned Lk = 0u;
+        if (n_eq > need) {
+            for (int bit = 31; bit >= 0; bit--) {
+                const unsigned cand = Lk | (1u << bit);
+                int c = 0;
+                for (int r = 0; r < rows; r++) { const int i = r * WAVE + lane; c += __popcll(__ballot(i < cur && kh[i] == Tk && kl[i] >= cand)); }
+                if (c >= need) Lk = cand;
+            }
+        }
+        int out = 0;
+        for (int r = 0; r < rows; r++) {
+            const int i = r * WAVE + lane;
+            const KeyT x = i < cur ? kh[i] : 0; const unsigned y = i < cur ? kl[i] : 0u;
+            const bool keep = i < cur && (x > Tk || (x == Tk && y >= Lk));
+            const unsigned long long m = __ballot(keep);
+            if (keep) { const int at = out + __popcll(m & ((1ull << lane) - 1ull)); kh[at] = x; kl[at] = y; }      // (at <= i: a slot already read)
+            out += __popcll(m);
+        }
+        cur = out;
+        wave_sync();
+    };
+    // sort the entries [0, cur), cur <= K, descending (bitonic network over the next power of two, padded with keys below every real one)
+    auto sort_kept = [&]() {
         int P = 2;
         while (P < cur) P <<= 1;
-        for (int i = cur + tid; i < P; i += COLLECT_THREADS) { kh[i] = 0; kl[i] = 0u; }
-        __syncthreads();
+        for (int i = cur + lane; i < P; i += WAVE) { kh[i] = 0; kl[i] = 0u; }
+        wave_sync();
         for (int k2 = 2; k2 <= P; k2 <<= 1) {
             for (int j = k2 >> 1; j > 0; j >>= 1) {
-                for (int pr = tid; pr < (P >> 1); pr += COLLECT_THREADS) {
+                for (int pr = lane; pr < (P >> 1); pr += WAVE) {
                     const int i0 = ((pr & ~(j - 1)) << 1) | (pr & (j - 1)), i1 = i0 | j;
                     const KeyT h0 = kh[i0], h1 = kh[i1];
                     const unsigned l0 = kl[i0], l1 = kl[i1];
@@ -644,14 +701,21 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect_topk(FinalArgs<T, S
                     const bool desc = (i0 & k2) == 0;
                     if (desc ? lt : (!lt && !(h0 == h1 && l0 == l1))) { kh[i0] = h1; kh[i1] = h0; kl[i0] = l1; kl[i1] = l0; }
                 }
-                __syncthreads();
+                wave_sync();
             }
         }
-        if (tid == 0) sh_cur = cur < K ? cur : K;
-        __syncthreads();
     };
-    auto room_for = [&](int c) {                                   // (block-uniform)
-        if (sh_cur + c > COLLECT_CAP) reduce();
+    auto reduce = [&]() { select_best(); };
+    // one source: c entries, entry i fetched by `get(i, key, low)` (false: not a candidate)
+    auto gather = [&](int c, auto get) {
+        for (int i0 = 0; i0 < c; i0 += WAVE) {
+            if (cur + WAVE > CAPW) reduce();
+            KeyT key = 0; unsigned low = 0u;
+            const bool take = i0 + lane < c && get(i0 + lane, key, low);
+            const unsigned long long m = __ballot(take);
+            if (take) { const int at = cur + __popcll(m & ((1ull << lane) - 1ull)); kh[at] = key; kl[at] = low; }
+            cur += __popcll(m);
+        }
     };
     for (int sp = 0; sp < nsplit; sp++) {
         const int bidx = in_tail ? n_ub1 * g.n_splits + sp * g.tail_ublocks + (g.tail_ublocks - 1 - rel)
@@ -659,39 +723,39 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect_topk(FinalArgs<T, S
         for (int sub = 0; sub < g.nsub; sub++) {
             const size_t wv = (size_t)bidx * nwaves + (size_t)(sub * GROUPS_PER_BLOCK + gi);
             const char *wbase = glists + wv * ((size_t)g.lane_cap * WAVE * (sizeof(S) + 4));
+            // (rm_list.hpp LaneSel: fp32 (score, item) pairs; fp64 the wave's scores, then its item ids)
+            constexpr bool PAIRS = sizeof(S) == 4;
             const S *wsc = (const S *)wbase;
-            const int *wit = (const int *)(wbase + (size_t)g.lane_cap * WAVE * sizeof(S));
+            const int *wit = PAIRS ? (const int *)wbase + 1 : (const int *)(wbase + (size_t)g.lane_cap * WAVE * sizeof(S));
+            constexpr int ES = PAIRS ? 2 : 1;                          // words of S / int from one lane's entry to the next lane's
             for (int l = 0; l < g.lpu; l++) {
-                const int lane = ul + l * g.gu;
-                const int c = lane_cnt[wv * WAVE + lane];
-                room_for(c);
-                for (int i = tid; i < c; i += COLLECT_THREADS) {
-                    const S x = wsc[(size_t)i * WAVE + lane];
-                    const KeyT key = ord_key(x);
-                    if (key >= bound) { const int at = atomicAdd(&sh_cur, 1); kh[at] = key; kl[at] = ~(unsigned)wit[(size_t)i * WAVE + lane]; }
-                }
-                __syncthreads();
+                const int src_lane = ul + l * g.gu;
+                const int c = lane_cnt[wv * WAVE + src_lane];
+                gather(c, [&](int i, KeyT &key, unsigned &low) {
+                    key = ord_key(wsc[((size_t)i * WAVE + src_lane) * ES]);
+                    if (key < bound) return false;
+                    low = ~(unsigned)wit[((size_t)i * WAVE + src_lane) * ES];
+                    return true;
+                });
             }
         }
     }
     if (g.extra_part >= 0) {
         const Entry<S> *px = a.pl + ((size_t)slot * a.n_part + g.extra_part) * K;
-        for (int i0 = 0; i0 < K; i0 += COLLECT_THREADS) {
-            room_for(COLLECT_THREADS);
-            const int i = i0 + tid;
-            if (i < K) {
-                const Entry<S> e = px[i];
-                if (e.idx != IDX_EMPTY) { const int at = atomicAdd(&sh_cur, 1); kh[at] = ord_key(e.s); kl[at] = ~(unsigned)e.idx; }
-            }
-            __syncthreads();
-        }
+        gather(K, [&](int i, KeyT &key, unsigned &low) {
+            const Entry<S> e = px[i];
+            if (e.idx == IDX_EMPTY) return false;
+            key = ord_key(e.s); low = ~(unsigned)e.idx;
+            return true;
+        });
     }
-    reduce();
-    const int got = sh_cur;
+    wave_sync();
+    select_best();
+    sort_kept();
     Entry<S> *M = a.merged + (size_t)u * K;
-    for (int i = tid; i < K; i += COLLECT_THREADS) {
+    for (int i = lane; i < K; i += WAVE) {
         Entry<S> e;
-        if (i < got) { e.s = ord_unkey(kh[i]); e.idx = (int)~kl[i]; }
+        if (i < cur) { e.s = ord_unkey(kh[i]); e.idx = (int)~kl[i]; }
         else { e.s = (S)qnan<float>(); e.idx = -1; }
         M[i] = e;
     }

@@ -58,7 +58,7 @@ struct Switches {
     bool no_train_bits, no_spec, no_side, ext_topk, no_early_bits, no_test_mask, hbm_lists, nsub2, no_pending, no_pos_keys, no_pos_beside,
          no_seed, no_depth_split, rank_generic, no_fused_auc, no_defer_auc, noise_sequential, no_ext_bits, one_context, noise_per_batch,
          host_trace, no_noise_beside_last, no_pack_beside, no_pos_flat;
-    long long free_mb, stream_budget_mb, dense_always_mb, noise_budget_mb, lane_cap_min;      // -1 = not set
+    long long free_mb, stream_budget_mb, dense_always_mb, noise_budget_mb, lane_cap_min, lane_min_k, lane_cap_set;      // -1 = not set
     double batch_users;                                                        // 0 = not set
     int ramp;                                                                  // 0 = not set
     std::string splits;
@@ -77,6 +77,8 @@ struct Switches {
         no_pos_flat = on("RM_DEBUG_NO_POS_FLAT");
         free_mb = num("RM_DEBUG_FREE_MB"); stream_budget_mb = num("RM_STREAM_BUDGET_MB"); dense_always_mb = num("RM_DEBUG_DENSE_ALWAYS_MB");
         noise_budget_mb = num("RM_NOISE_BUDGET_MB");
+        lane_min_k = num("RM_DEBUG_LANE_MIN_K");                // the smallest k_metrics that takes the lane buffers instead of LDS / HBM lists (A/B timing)
+        lane_cap_set = num("RM_DEBUG_LANE_CAP");                // entries per lane buffer (A/B timing; rounded to 16, never below what a selection needs)
         lane_cap_min = num("RM_DEBUG_LANE_CAP_MIN");          // the smallest lane buffers that work: a selection every few tiles (tests)
         const char *b = getenv("RM_BATCH_USERS"); batch_users = b ? atof(b) : 0.0;
         const char *r = getenv("RM_DEBUG_RAMP"); ramp = r ? atoi(r) : 0;
@@ -296,7 +298,7 @@ template <> struct Prec<float> {
     // K > 32: entries per lane buffer of the sweep (rm_list.hpp; a multiple of 16, and a selection's K + slack survivors plus a tile's
     // sixteen appends must fit one lane: 2K + 16), lanes per user
     static int lane_cap(int K) { return (2 * K + 16 + 15) / 16 * 16; }
-    static constexpr int lanes_per_user = 2;
+    static constexpr int lanes_per_user = 2, lane_tile = 16;
 };
 template <> struct Prec<double> {
     static constexpr int GU = GROUP_USERS64;
@@ -317,7 +319,7 @@ template <> struct Prec<double> {
     static void set_ublocks(Sweep64Args &sa, int first, int count) { sa.ublock0 = first; sa.n_ublocks = count; }
     // (four lanes per user: K + slack + a tile's eight appends must fit ONE lane, the user's four hold ~5K together)
     static int lane_cap(int K) { return (K + lane_sel_slack(K) + 8 + 16 + 15) / 16 * 16; }
-    static constexpr int lanes_per_user = 4;
+    static constexpr int lanes_per_user = 4, lane_tile = 8;
 };
 
 inline void check_launch(int rc)
@@ -382,6 +384,45 @@ inline long long stream_budget_bytes(const Workspace &ws)
 {
     if (g_sw.stream_budget_mb >= 0) return g_sw.stream_budget_mb << 20;
     return free_plus_owned(ws, {"stream_scores", "sel_hi", "sel_lo"}) / 3;
+}
+
+// Which top-K scheme a pass takes (rm_sweep.hpp LMODE):
+//   lane lists   per-lane append buffers + lane-parallel selection + k_collect_topk (rm_list.hpp): k_metrics from `lane_min_k` (21; the
+//                replace-the-minimum lists rescan K entries per insert: BASELINE C2's shape took 8.1 / 15.0 / 26.8 ms at K = 20 /
+//                32 / 50 in LDS or HBM lists against 8.1 / 8.7 / 10.0 here, profiles/r6_ksweep_C2.txt) up to what k_collect_topk sorts in LDS (K + one lane buffer <= 4,096 entries: K <= 1,354), while the
+//                buffers -- 8 waves x 64 lanes x lane_cap entries per block of the sweep's grid -- fit a third of the free memory;
+//   lists        below that: in LDS while they fit, else replace-the-minimum in HBM;
+//   ext_topk     beyond: one score row per user + k_select_topk.
+// Entries per lane buffer for item ranges of `range_items` items per user and wave: at least Prec<T>::lane_cap (what a selection
+// needs to make progress), and enough that ONE selection per range is the rule -- the first, when every lane fills up together
+// on the unbounded scores of the first tiles; after it a user holds ~1.25 K survivors and the rest of the range appends
+// ~K ln(range / position of that selection) more, spread over its lanes (+ three standard deviations, + a tile's appends).  A
+// selection reads a wave's buffers once or twice and writes a third of them back scattered, four bytes at a time -- with 2K + 16
+// entries per lane BASELINE C2's shape at K = 100 ran four of them per range and wave, a third of the sweep's wave cycles
+// (profiles/r6_ab_c2.txt).
+template <class T> inline int lane_cap_for(int K, long long range_items)
+{
+    const int base = Prec<T>::lane_cap(K), lpu = Prec<T>::lanes_per_user;
+    const double first = (double)lpu * (base - Prec<T>::lane_tile);                  // items a user has seen at the first selection
+    const double later = (double)K * std::log(std::max(1.0, (double)range_items / std::max(1.0, first)));
+    const double per_lane = (1.25 * K + later) / lpu;
+    long long cap = (long long)(per_lane + 3.0 * std::sqrt(per_lane) + Prec<T>::lane_tile + 1.0);
+    cap = std::max<long long>(base, std::min<long long>(cap, 4LL * base));
+    cap = std::min<long long>((cap + 15) / 16 * 16, (COLLECT_MAX_ENTRIES - K) / 16 * 16);
+    return (int)std::max<long long>(cap, base);
+}
+template <class T> inline long long lane_list_bytes(int K, long long n_blocks) { return n_blocks * (4 * Prec<T>::max_nsub) * WAVE * 2LL * Prec<T>::lane_cap(K) * (long long)(sizeof(T) + 4); }    // (an estimate: lane_cap_for may double the base)
+template <class T> inline bool lane_lists_possible(int K)
+{
+    const long long min_k = g_sw.lane_min_k >= 0 ? g_sw.lane_min_k : 21;
+    return !g_sw.ext_topk && K >= min_k && K + Prec<T>::lane_cap(K) <= COLLECT_MAX_ENTRIES;
+}
+// (the grid of the sweep is only known behind the plan: user blocks of the call, or a few rounds of 256 blocks when there are few)
+template <class T> inline long long lane_blocks_bound(long long m) { return (m + 4 * Prec<T>::GU - 1) / (4 * Prec<T>::GU) + 1024; }
+inline long long lane_budget_bytes(const Workspace &ws) { return free_plus_owned(ws, {"glists", "stream_scores", "sel_hi", "sel_lo"}) / 3; }
+template <class T> inline bool lane_lists_fit(const Workspace &ws, int K, long long m)
+{
+    return lane_lists_possible<T>(K) && lane_list_bytes<T>(K, lane_blocks_bound<T>(m)) <= lane_budget_bytes(ws);
 }
 
 // Dense train rows for the fp32 sweep when they are small (m * n / 8 bytes <= 1 GiB, e.g. 463 MB at BASELINE C2): with ~100
@@ -558,7 +599,8 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     const long long stream_ld_max = ((long long)n + 191) / 192 * 192;             // row stride for either tile size (64 / 96 items)
     // k_metrics beyond the sweep's lists (append buffers + wave compaction reach 256): every user is streamed and
     // k_select_topk picks its top-K from the stored row -- any k_metrics <= n, at one score row of HBM per user
-    const bool ext_topk = K > 256 || g_sw.ext_topk;
+    const bool want_lane = lane_lists_fit<T>(ws, K, c.eval_users >= 0 ? std::min<long long>(c.eval_users, m) : m);
+    const bool ext_topk = (!want_lane && K > 256) || g_sw.ext_topk;
     long long stream_cap = 0;
     if (want_auc || ext_topk) {
         stream_cap = stream_budget_bytes(ws) / (stream_ld_max * (long long)sizeof(T));
@@ -758,7 +800,10 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         return want_auc ? (head + tb - 1) / tb * tb + (size_t)GROUPS_PER_BLOCK * (1 << j) * GU * (sizeof(T) + 4) : head;
     };
     auto lds_need_n = [&](bool with_lists, int ns) { return lds_need_j(with_lists, ns, jmax); };
-    if (!ext_topk && P::max_nsub >= 3 && NG <= 8 && lds_need_n(true, 3) + SYNC_BYTES <= LDS_LIMIT && !g_sw.hbm_lists && !g_sw.nsub2)
+    // (three sub-tiles with the lane buffers of larger k_metrics were built and measured in round 6 -- 162-168 VGPRs, no spills -- and are
+    // SLOWER: a user's candidates are then spread over three waves whose bounds each see a third of the items; BASELINE C2's shape at
+    // K = 100: 13.4 against 12.4 ms, profiles/r6_ab_c2.txt)
+    if (!ext_topk && !want_lane && P::max_nsub >= 3 && NG <= 8 && lds_need_n(true, 3) + SYNC_BYTES <= LDS_LIMIT && !g_sw.hbm_lists && !g_sw.nsub2)
         nsub = 3;
     // (four sub-tiles -- sixteen waves, four per SIMD, 128 registers each -- were built in round 5, passed the parity tests and were
     // 1.9 % SLOWER at BASELINE C2: profiles/r5_ab_c2.txt r5a; the patches are scratch/dropped/r5_nsub4*)
@@ -818,11 +863,11 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     const int n_part = nsub * part_splits + (mask_test ? 1 : 0);
     const int part_extra = mask_test ? 1 : 0;
     auto lds_need = [&](bool with_lists) { return lds_need_n(with_lists, nsub); };
-    const bool list_in_lds = !ext_topk && lds_need(true) + SYNC_BYTES <= LDS_LIMIT && !g_sw.hbm_lists;
+    const bool list_in_lds = !ext_topk && !want_lane && lds_need(true) + SYNC_BYTES <= LDS_LIMIT && !g_sw.hbm_lists;
     size_t lds_total = lds_need(list_in_lds);
     // per-lane pending buffers for top-K candidates behind everything else when 2..8 keys per lane still fit
     // (fp32: not for the append-buffer lists of K > 32, whose appends are already single stores)
-    const bool want_pending = !ext_topk && P::has_pending && (list_in_lds || K <= 32 || P::pending_for_append) && !g_sw.no_pending;
+    const bool want_pending = !ext_topk && !want_lane && P::has_pending && !g_sw.no_pending;
     const size_t per_key = (size_t)n_waves * WAVE * P::pend_key_bytes;            // one key per lane and wave
     int pend_cap = 0; size_t pend_off = 0, sync_off = 0;
     if (P::block_carve) {
@@ -867,7 +912,9 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     fa.heavy_npos = ca.heavy_npos;
     auto launch_top_values = [&]() {
         if (!(fa.ndcg && hp.n_heavy > 0)) return;
-        fa.heavy_ld = std::min(K, HEAVY_TOPV_MAX);
+        // (min(K, longest test row) values per user: with a cap of 256 the rows beyond it fell back to k_finalize's repeated selection on
+        // one thread -- L x positives dependent loads: 160 of the 190 ms of a K = 300 step at BASELINE C2's shape)
+        fa.heavy_ld = std::max(1, std::min(K, hp.max_npos));
         fa.heavy_topv = (T *)ws.get("heavy_topv", sizeof(T) * (size_t)m * (size_t)fa.heavy_ld);
         fa.heavy_nan = (unsigned char *)ws.get("heavy_nan", (size_t)m);
         fa.heavy_users = heavy_users; fa.n_heavy = hp.n_heavy;
@@ -982,8 +1029,13 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         pst = (PartialStat<T> *)ws.get("pst", sizeof(PartialStat<T>) * (size_t)n_slots * n_part);
         typename P::ListT *glists = nullptr;
         const unsigned n_blocks = (unsigned)((n_ublocks - tail_ublocks) * n_splits + tail_ublocks * tail_splits);
-        const bool lane_lists = !list_in_lds && !ext_topk && K > 32;       // per-lane append buffers + k_collect_topk (rm_list.hpp)
-        int lane_cap = lane_lists ? P::lane_cap(K) : 0;
+        const bool lane_lists = want_lane && !ext_topk;                     // per-lane append buffers + k_collect_topk (rm_list.hpp)
+        int lane_cap = lane_lists ? (g_sw.lane_cap_set == 0 ? lane_cap_for<T>(K, (long long)cdiv(tiles_total, n_splits) * 32) : P::lane_cap(K)) : 0;
+        // (never more than a third of the free memory: the base size always fits -- lane_lists_fit has asked)
+        while (lane_lists && lane_cap > P::lane_cap(K) &&
+               (long long)n_blocks * n_waves * WAVE * lane_cap * (long long)(sizeof(T) + 4) > free_plus_owned(ws, {"glists", "stream_scores", "sel_hi", "sel_lo"}) / 3)
+            lane_cap = std::max(P::lane_cap(K), (lane_cap / 2 + 15) / 16 * 16);
+        if (lane_lists && g_sw.lane_cap_set > 0) lane_cap = (int)std::min<long long>(std::max<long long>(P::lane_cap(K), (g_sw.lane_cap_set + 15) / 16 * 16), (COLLECT_MAX_ENTRIES - K) / 16 * 16);
         if (lane_lists && g_sw.lane_cap_min >= 0)        // K + slack survivors and one tile's appends (16: both precisions' bound) in one lane
             lane_cap = std::min(lane_cap, (K + lane_sel_slack(K) + 16 + 1 + 15) / 16 * 16);
         int *lane_cnt = nullptr;
@@ -1002,7 +1054,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         else HIP_CHECK(hipMemsetAsync(thr_shared, 0, sizeof(ThrT) * (size_t)n_slots, stream));
         sa.thr_shared = thr_shared;
         sa.n = n; sa.K = K; sa.ngt = NG; sa.n_slots = n_slots; sa.n_groups = n_groups; sa.n_ublocks = n_ublocks;
-        sa.n_splits = n_splits; sa.tail_ublocks = tail_ublocks; sa.tail_splits = tail_splits; sa.part_splits = part_splits; sa.tiles_total = tiles_total; sa.jmax = jmax; sa.check_nan = check_nan ? 1 : 0; sa.buffered_lists = (K > 32 || ext_topk) ? 1 : 0; sa.ext_topk = ext_topk ? 1 : 0;
+        sa.n_splits = n_splits; sa.tail_ublocks = tail_ublocks; sa.tail_splits = tail_splits; sa.part_splits = part_splits; sa.tiles_total = tiles_total; sa.jmax = jmax; sa.check_nan = check_nan ? 1 : 0; sa.buffered_lists = (want_lane || ext_topk) ? 1 : 0; sa.ext_topk = ext_topk ? 1 : 0;
         sa.Ap = (decltype(sa.Ap))Ap; sa.Bp = (decltype(sa.Bp))Bp; sa.slot_user = slot_user; sa.slot_chunk = slot_chunk;
         sa.train_p = c.train_p; sa.train_i = c.train_i; sa.gj = gj; sa.grow = grow;
         sa.pos_score = pos_score; sa.pos_item = pos_item; sa.hist = hist; sa.glists = glists; sa.lane_cap = lane_cap; sa.lane_cnt = lane_cnt; sa.pl = pl; sa.pst = pst; sa.dump = nullptr;
@@ -1029,7 +1081,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         // the tables per block), the shallow blocks [0, u_split) get their own launch with LDS lists.  The two launches
         // run side by side on two streams so that neither pays a partially filled last round of its own.
         int u_split = 0, j_shallow = -1;
-        if (P::block_carve && !list_in_lds && K <= 32 && want_auc && !g_sw.hbm_lists && !g_sw.no_depth_split) {
+        if (P::block_carve && !list_in_lds && !want_lane && K <= 32 && want_auc && !g_sw.hbm_lists && !g_sw.no_depth_split) {
             for (int j = jmax - 1; j >= 0 && j_shallow < 0; j--)
                 if (lds_need_j(true, nsub, j) + SYNC_BYTES <= LDS_LIMIT) j_shallow = j;
             if (j_shallow >= 0) u_split = hp.class_offset[j_shallow + 1] / (GROUPS_PER_BLOCK * GU);
@@ -1118,7 +1170,10 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         // k_merge_positives, whose part of `pl` -- the streamed users' own test items -- is one of the inputs)
         typedef typename std::remove_pointer<decltype(typename P::Args{}.thr_shared)>::type ThrT;
         fa.collected = 1;
-        hipLaunchKernelGGL((k_collect_topk<T, T, ThrT>), dim3(n_slots), dim3(COLLECT_THREADS), 0, stream, fa, collect.g, collect.glists, collect.lane_cnt, (const ThrT *)collect.thr);
+        if (collect_capw(K, collect.g.lane_cap) == 1024)
+            hipLaunchKernelGGL((k_collect_topk<T, T, ThrT, 1024>), dim3(cdiv(n_slots, 4)), dim3(256), 0, stream, fa, collect.g, collect.glists, collect.lane_cnt, (const ThrT *)collect.thr);
+        else
+            hipLaunchKernelGGL((k_collect_topk<T, T, ThrT, 4096>), dim3(n_slots), dim3(64), 0, stream, fa, collect.g, collect.glists, collect.lane_cnt, (const ThrT *)collect.thr);
     }
     if (n_slots > 0 && ext_topk) {
         int sel_ld = 2;
@@ -1589,7 +1644,11 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     if (forced) bu = g_sw.batch_users;
     long long batch = (long long)std::min<double>(std::max(bu, 1024.0), 2.0e9);
     batch = (batch + 1023) / 1024 * 1024;
-    if (K > 256) {                                                   // one score row per user of the batch (run(): ext_topk),
+    // k_metrics > 256: the lane buffers when they fit at all (run(): want_lane; one block's worth per 4 GU users on top of the grid's
+    // floor -- lane_blocks_bound), sized so that run() finds every batch fitting; else score rows (ext_topk)
+    const long long lane_blocks = K > 256 && lane_lists_possible<T>(K) ? lane_budget_bytes(ws) * 3 / 4 / lane_list_bytes<T>(K, 1) - lane_blocks_bound<T>(0) : 0;
+    if (lane_blocks >= 8) batch = std::max<long long>(1024, std::min<long long>(batch, lane_blocks * 4 * Prec<T>::GU / 1024 * 1024));
+    else if (K > 256) {                                            // one score row per user of the batch (run(): ext_topk),
         const long long row = (((long long)n + 191) / 192 * 192) * (long long)sizeof(T);    // with a margin for what run() allocates first
         batch = std::max<long long>(1, std::min<long long>(batch, stream_budget_bytes(ws) * 3 / 4 / row));
     }
@@ -1624,7 +1683,7 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     std::unique_lock<std::mutex> peer_lock;
     // (not with k_metrics > 256: a batch is then sized by the score rows ONE context may hold -- a third of the free memory --
     // and a second context holding as much again leaves the first one's next batch short: RM_ERR_NOMEM on the third batch)
-    const bool rows_bound = K > 256 || g_sw.ext_topk;
+    const bool rows_bound = K > 256 || g_sw.ext_topk;             // (the lane buffers of k_metrics > 256 are as large)
     if (n_batches > 1 && !rows_bound && !g_sw.one_context) {
         Ctx &pc = peer_context(cx);
         peer_lock = std::unique_lock<std::mutex>(pc.mu);

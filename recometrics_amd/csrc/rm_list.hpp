@@ -10,6 +10,13 @@
 
 namespace rm {
 
+#ifdef RM_STATS
+__device__ unsigned long long g_stats[16];      // timing builds only (scratch/build_abl.py)
+#define RM_SEL_STAT(IDX, VAL) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_stats[IDX], (unsigned long long)(VAL)); } while (0)
+#else
+#define RM_SEL_STAT(IDX, VAL) do {} while (0)
+#endif
+
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -166,9 +173,9 @@ __device__ __forceinline__ void keylist_sort_desc(P L, int K)
 // per wave and item range at BASELINE C2's shape with K = 100, each ~1,000 instructions with the three partner waves of the
 // sub-tile waiting at the next barrier -- the sweep went 6.7 -> 22.7 ms from K = 10 to K = 100, profiles/r5_ab_c2.txt)
 //
-// Every lane owns a buffer of `cap` entries, laid out [entry][64 lanes] (the scores of a wave, then its item ids at the same
-// offsets), and appends each of ITS OWN scores that reaches the user's bound: a compare, two stores under the lane mask and an
-// add per score register -- no ballots, no shuffles to an owner lane.  A user's candidates are the union of the buffers of its
+// Every lane owns a buffer of `cap` entries, laid out [entry][64 lanes] (fp32: (score, item) pairs; fp64: the scores of a wave, then
+// its item ids at the same places), and appends each of ITS OWN scores that reaches the user's bound: a compare, a store or two under
+// the lane mask and an add per score register -- no ballots, no shuffles to an owner lane.  A user's candidates are the union of the buffers of its
 // lanes (two in the fp32 sweep, four in the fp64 one).  When some lane of the wave is a tile away from full, ALL users of the
 // wave raise their bounds together, each lane working on its own buffer (the loops are wave-uniform, the data per lane):
 //   * a bisection for a bound T with K <= #(entries >= T) <= K + slack -- three probes per pass over the buffers (one load,
@@ -193,6 +200,20 @@ template <> struct LaneSel<float> {
     static __device__ __forceinline__ float umin(float x) { return __builtin_fminf(x, __shfl_xor(x, 32)); }
     // (through L2: the entries were stored by this wave, the L1 may hold an older copy of the line)
     static __device__ __forceinline__ float load(const float *p) { return __uint_as_float(__hip_atomic_load((const unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+    // fp32 entries are (score, item) PAIRS, [entry][64 lanes] x 8 bytes: an append is ONE 8-byte store and the packing moves an entry
+    // with one load and one store -- the sweep's epilogues and the selections of a CU's eight waves go through one address unit, and
+    // what they cost there is the number of memory instructions (round 6: scores and items in separate arrays were 10,500 of them per
+    // wave and item range at BASELINE C2's shape with K = 100, two thirds of them the appends' masked 4-byte stores)
+    static constexpr int SS = 128, IS = 128;                        // floats / ints from one entry of a lane to its next
+    static __device__ __forceinline__ void load_entry(const float *sc, const int *, size_t i, float &x, int &id)
+    {
+        const unsigned long long b = __hip_atomic_load((const unsigned long long *)(sc + i * SS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = __uint_as_float((unsigned)b); id = (int)(unsigned)(b >> 32);
+    }
+    static __device__ __forceinline__ void store_entry(float *sc, int *, size_t j, float x, int id)
+    {
+        *(unsigned long long *)(sc + j * SS) = (unsigned long long)__float_as_uint(x) | ((unsigned long long)(unsigned)id << 32);
+    }
     static __device__ __forceinline__ float nan() { return __uint_as_float(0xffffffffu); }
     static __device__ __forceinline__ float ninf() { return __uint_as_float(0xff800000u); }
     static __device__ __forceinline__ float pinf() { return __uint_as_float(0x7f800000u); }
@@ -206,6 +227,13 @@ template <> struct LaneSel<double> {
     static __device__ __forceinline__ double umax(double x) { x = __builtin_fmax(x, __shfl_xor(x, 16)); return __builtin_fmax(x, __shfl_xor(x, 32)); }
     static __device__ __forceinline__ double umin(double x) { x = __builtin_fmin(x, __shfl_xor(x, 16)); return __builtin_fmin(x, __shfl_xor(x, 32)); }
     static __device__ __forceinline__ double load(const double *p) { return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+    // fp64: the scores of a wave ([entry][64 lanes] x 8 bytes), then its item ids ([entry][64 lanes] x 4 bytes)
+    static constexpr int SS = 64, IS = 64;
+    static __device__ __forceinline__ void load_entry(const double *sc, const int *it, size_t i, double &x, int &id)
+    {
+        x = load(sc + i * SS); id = (int)__hip_atomic_load((const unsigned *)(it + i * IS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    static __device__ __forceinline__ void store_entry(double *sc, int *it, size_t j, double x, int id) { sc[j * SS] = x; it[j * IS] = id; }
     static __device__ __forceinline__ double nan() { return __longlong_as_double(-1ll); }
     static __device__ __forceinline__ double ninf() { return __longlong_as_double((long long)0xfff0000000000000ull); }
     static __device__ __forceinline__ double pinf() { return __longlong_as_double(0x7ff0000000000000ll); }
@@ -219,19 +247,31 @@ __device__ __forceinline__ int wave_max_i32(int x)
     return __builtin_amdgcn_readfirstlane(x);
 }
 // slack of a selection: the bisection stops at the first bound that leaves between K and K + slack entries
-__host__ __device__ inline int lane_sel_slack(int K) { return K / 4 > 8 ? K / 4 : 8; }
+// (K / 2: the first pass over the whole buffer probes three guesses from a sample that are a standard deviation of the estimate
+// apart -- ~K / 4 entries at K = 100 -- and one of them lands in a window of K / 2 nineteen times out of twenty; a window of K / 4
+// took 3.7 passes per selection, each 57 KB of a wave's buffers through a memory system every wave of the chip is asking)
+__host__ __device__ inline int lane_sel_slack(int K) { return K / 2 > 8 ? K / 2 : 8; }
 
 // counts of the lane's entries [0, cend) at or above each of three probes (cend a multiple of 16; the slots behind the lane's
-// own count hold NaN, which no compare accepts)
+// own count hold NaN, which no compare accepts).  A pass is bound by the latency of its loads -- the buffers of a CU's waves are
+// far larger than its share of the L2, a round trip is ~2,000 cycles (profiles/r6_ab_c2.txt) -- so 32 are in flight at a time.
 template <class S>
 __device__ __forceinline__ void lane_count3(const S *sc, int cend, S p1, S p2, S p3, int &c1, int &c2, int &c3)
 {
     typedef LaneSel<S> L;
     c1 = 0; c2 = 0; c3 = 0;
-    for (int i = 0; i < cend; i += 16) {
+    int i = 0;
+    for (; i + 32 <= cend; i += 32) {
+        S x[32];
+        #pragma unroll
+        for (int t = 0; t < 32; t++) x[t] = L::load(sc + (size_t)(i + t) * L::SS);
+        #pragma unroll
+        for (int t = 0; t < 32; t++) { c1 += x[t] >= p1; c2 += x[t] >= p2; c3 += x[t] >= p3; }
+    }
+    if (i < cend) {
         S x[16];
         #pragma unroll
-        for (int t = 0; t < 16; t++) x[t] = L::load(sc + (size_t)(i + t) * WAVE);
+        for (int t = 0; t < 16; t++) x[t] = L::load(sc + (size_t)(i + t) * L::SS);
         #pragma unroll
         for (int t = 0; t < 16; t++) { c1 += x[t] >= p1; c2 += x[t] >= p2; c3 += x[t] >= p3; }
     }
@@ -255,7 +295,7 @@ __device__ __forceinline__ void lane_select(S *sc, int *it, int &cnt, const int 
     if (!wave_any(active)) return;
     const int cmax = wave_max_i32(active ? cnt : 0), cmin = -wave_max_i32(active ? -cnt : -0x7fffffff);
     const int cend = (cmax + 15) & ~15;                             // (cap is a multiple of 16)
-    for (int i = cmin; i < cend; i++) if (active && i >= cnt) sc[(size_t)i * WAVE] = L::nan();
+    for (int i = cmin; i < cend; i++) if (active && i >= cnt) sc[(size_t)i * L::SS] = L::nan();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- bracket: #(>= unkey(lo)) >= K, #(>= unkey(hi)) < K.  Every entry is >= the float below the lane's bound: the bound is
     // either the last selection's T, or the float above it when that selection cut exact ties by item (the kept ties sit AT T)
@@ -266,7 +306,7 @@ __device__ __forceinline__ void lane_select(S *sc, int *it, int &cnt, const int 
         for (int i = 0; i < cend; i += 16) {
             S x[16];
             #pragma unroll
-            for (int t = 0; t < 16; t++) x[t] = L::load(sc + (size_t)(i + t) * WAVE);
+            for (int t = 0; t < 16; t++) x[t] = L::load(sc + (size_t)(i + t) * L::SS);
             #pragma unroll
             for (int t = 0; t < 16; t++) mn = x[t] < mn ? x[t] : mn;      // (NaN: compare false)
         }
@@ -276,11 +316,64 @@ __device__ __forceinline__ void lane_select(S *sc, int *it, int &cnt, const int 
     const Key lo0 = lo;
     int cT = C;                                                     // entries at or above unkey(lo) (at lo0: an upper bound, see below)
     bool done = !active;
+    // ---- the first pass's probes from a SAMPLE: every (cend / 32)-th entry of the lane, 32 registers, one round trip.  The sample's
+    // order statistics at the ranks that correspond to ~K + slack / 2 entries of the whole and a standard deviation of the estimate to
+    // either side are found in registers (three bisections in lock-step, no memory traffic).  Whatever the sample says only chooses
+    // WHERE the first pass over the whole buffer probes: the bracket is updated from the true counts alone, so a misleading sample
+    // costs passes, never correctness.  (Without it: ~8 passes of 14 dependent round trips each; with it 2.)
+    Key sk1 = 0, sk2 = 0, sk3 = 0;
+    {
+        constexpr int NS = 32;
+        const int st = cend / NS > 0 ? cend / NS : 1;
+        S xs[NS];
+        #pragma unroll
+        for (int t = 0; t < NS; t++) xs[t] = t * st < cend ? L::load(sc + (size_t)(t * st) * L::SS) : L::nan();
+        int ns = 0;
+        #pragma unroll
+        for (int t = 0; t < NS; t++) ns += xs[t] == xs[t];
+        ns = L::usum(ns);
+        // sample ranks: t2 ~ (K + slack / 2) ns / C, t1 = t2 + e (more entries: the lower key), t3 = t2 - e
+        const float scale = (float)ns / (float)(C > 0 ? C : 1);
+        int t2 = (int)((float)(K + slack / 2) * scale + 0.5f);
+        t2 = t2 < 1 ? 1 : t2;
+        int e = (int)(__builtin_sqrtf((float)t2) + 0.5f);
+        e = e < 1 ? 1 : e;
+        const int tg1 = t2 + e, tg2 = t2, tg3 = t2 - e > 0 ? t2 - e : 1;
+        // three brackets over the sample: #(>= lo_j) >= tg_j > #(>= hi_j)
+        Key l1 = lo, l2 = lo, l3 = lo, h1 = hi, h2 = hi, h3 = hi;
+        bool sdone = !active || ns < tg1;                           // (too few samples at or above the bracket's low end: no guess)
+        for (int sp = 0; sp < 40 && wave_any(!sdone); sp++) {
+            auto mid = [&](Key l, Key h) -> Key {
+                const Key dk = h - l;
+                if (dk <= 1) return l;
+                if (sp < 12) {
+                    const S lf = ord_unkey(l), hf = ord_unkey(h - 1);
+                    if (L::finite(lf) && L::finite(hf)) { const Key m = ord_key(lf + (hf - lf) * (S)0.5); if (m > l && m < h) return m; }
+                }
+                return l + (dk >> 1);
+            };
+            const Key m1 = mid(l1, h1), m2 = mid(l2, h2), m3 = mid(l3, h3);
+            const S f1 = ord_unkey(m1), f2 = ord_unkey(m2), f3 = ord_unkey(m3);
+            int a1 = 0, a2 = 0, a3 = 0;
+            #pragma unroll
+            for (int t = 0; t < NS; t++) { a1 += xs[t] >= f1; a2 += xs[t] >= f2; a3 += xs[t] >= f3; }
+            a1 = L::usum(a1); a2 = L::usum(a2); a3 = L::usum(a3);
+            // (a probe with exactly the wanted count IS an answer: any key between two neighbouring sample values serves)
+            if (h1 - l1 > 1) { if (a1 == tg1) { l1 = m1; h1 = m1 + 1; } else if (a1 > tg1) l1 = m1; else h1 = m1; }
+            if (h2 - l2 > 1) { if (a2 == tg2) { l2 = m2; h2 = m2 + 1; } else if (a2 > tg2) l2 = m2; else h2 = m2; }
+            if (h3 - l3 > 1) { if (a3 == tg3) { l3 = m3; h3 = m3 + 1; } else if (a3 > tg3) l3 = m3; else h3 = m3; }
+            RM_SEL_STAT(1, 1);
+            sdone = sdone || (h1 - l1 <= 1 && h2 - l2 <= 1 && h3 - l3 <= 1);
+            if (sp >= 7) sdone = true;              // (seven halvings of the value range: the probes only say where the first pass looks)
+        }
+        if (active && ns >= tg1) { sk1 = l1; sk2 = l2; sk3 = l3; }
+    }
     for (int pass = 0; wave_any(!done); pass++) {
         Key k1, k2, k3;
         const Key d = hi - lo;                                      // >= 2 while not done
         bool by_value = false;
-        if (pass < 8) {                                             // quartiles in value space
+        if (pass == 0 && sk1 > lo && sk2 >= sk1 && sk3 >= sk2 && sk3 < hi) { k1 = sk1; k2 = sk2; k3 = sk3; by_value = true; }
+        else if (pass < 8) {                                        // quartiles in value space
             const S lf = ord_unkey(lo), hf = ord_unkey(hi - 1);
             if (L::finite(lf) && L::finite(hf)) {
                 const S w = hf - lf;
@@ -293,6 +386,7 @@ __device__ __forceinline__ void lane_select(S *sc, int *it, int &cnt, const int 
             k1 = lo + (q ? q : (Key)1); k2 = lo + (q ? 2 * q : (Key)1); k3 = lo + (q ? 3 * q : (Key)1);
         }
         int c1, c2, c3;
+        RM_SEL_STAT(0, 1);
         lane_count3<S>(sc, cend, ord_unkey(k1), ord_unkey(k2), ord_unkey(k3), c1, c2, c3);
         c1 = L::usum(c1); c2 = L::usum(c2); c3 = L::usum(c3);
         if (!done) {
@@ -310,8 +404,9 @@ __device__ __forceinline__ void lane_select(S *sc, int *it, int &cnt, const int 
     const bool below = active && lo == lo0 && !unbounded;
     bool own_short = false;
     if (wave_any(below)) {
+        RM_SEL_STAT(3, 1);
         int c0 = 0;
-        for (int i = 0; i < cend; i++) { const S x = L::load(sc + (size_t)i * WAVE); c0 += x >= T; }
+        for (int i = 0; i < cend; i++) { const S x = L::load(sc + (size_t)i * L::SS); c0 += x >= T; }
         c0 = L::usum(c0);
         if (below) { cT = c0; own_short = c0 < K; }
     }
@@ -320,17 +415,18 @@ __device__ __forceinline__ void lane_select(S *sc, int *it, int &cnt, const int 
     const bool ties = active && !own_short && cT > K + slack;
     int item_max = IDX_EMPTY;
     if (wave_any(ties)) {
+        RM_SEL_STAT(2, 1);
         const S above = ord_unkey(lo + 1);
         int ngt = 0;
-        for (int i = 0; i < cend; i++) { const S x = L::load(sc + (size_t)i * WAVE); ngt += x >= above; }
+        for (int i = 0; i < cend; i++) { const S x = L::load(sc + (size_t)i * L::SS); ngt += x >= above; }
         const int need = K - L::usum(ngt);                          // >= 1 ties to keep: those with the smallest items
         int ilo = -1, ihi = n_items - 1;                            // #(ties with item <= ilo) < need <= #(... <= ihi)
         while (wave_any(ties && ihi - ilo > 1)) {
             const int im = ilo + ((ihi - ilo) >> 1);
             int c = 0;
             for (int i = 0; i < cend; i++) {
-                const S x = L::load(sc + (size_t)i * WAVE);
-                const int id = lane_sel_load_item(it + (size_t)i * WAVE);
+                const S x = L::load(sc + (size_t)i * L::SS);
+                const int id = lane_sel_load_item(it + (size_t)i * L::IS);
                 c += (x == T) && id <= im;
             }
             c = L::usum(c);
@@ -340,15 +436,15 @@ __device__ __forceinline__ void lane_select(S *sc, int *it, int &cnt, const int 
     }
     // ---- pack the survivors to the front of the lane's own buffer ----
     int j = 0;
-    for (int i = 0; i < cend; i += 8) {
-        S x[8]; int id[8];
+    for (int i = 0; i < cend; i += 16) {
+        S x[16]; int id[16];
         #pragma unroll
-        for (int t = 0; t < 8; t++) { x[t] = L::load(sc + (size_t)(i + t) * WAVE); id[t] = lane_sel_load_item(it + (size_t)(i + t) * WAVE); }
+        for (int t = 0; t < 16; t++) L::load_entry(sc, it, (size_t)(i + t), x[t], id[t]);
         #pragma unroll
-        for (int t = 0; t < 8; t++) {
+        for (int t = 0; t < 16; t++) {
             const bool keep = active && x[t] >= T && (!ties || x[t] > T || id[t] <= item_max);
             if (keep) {
-                if (j != i + t) { sc[(size_t)j * WAVE] = x[t]; it[(size_t)j * WAVE] = id[t]; }
+                if (j != i + t) L::store_entry(sc, it, (size_t)j, x[t], id[t]);
                 j++;
             }
         }
@@ -361,11 +457,18 @@ __device__ __forceinline__ void lane_select(S *sc, int *it, int &cnt, const int 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // survivors in place before anyone appends behind them
 }
+// Out of line (both sweeps): a selection runs two or three times per item range, its working set (a 32-entry sample, 32 loads in
+// flight) would otherwise be added to the register budget of the tile loop -- inlined into the fp32 sweep it pushed the kernels of
+// 24-40 factors from 13 to 110 spilled SGPRs.  Results come back by value (in registers), not through references (scratch).
+template <class S> struct LaneSelResult { int cnt; S thr; typename LaneSel<S>::Key kth_key; };
 template <class S>
-__device__ __attribute__((noinline)) void lane_select_call(S *sc, int *it, int &cnt, const int K, const bool primary, const S thr_in, const S hi_hint,
-                                                           const int n_items, S &thr_out, typename LaneSel<S>::Key &kth_key)
+__device__ __attribute__((noinline)) LaneSelResult<S> lane_select_call(S *sc, int *it, int cnt, const int K, const bool primary, const S thr_in, const S hi_hint,
+                                                                       const int n_items)
 {
-    lane_select<S>(sc, it, cnt, K, primary, thr_in, hi_hint, n_items, thr_out, kth_key);
+    LaneSelResult<S> r;
+    r.cnt = cnt;
+    lane_select<S>(sc, it, r.cnt, K, primary, thr_in, hi_hint, n_items, r.thr, r.kth_key);
+    return r;
 }
 
 } // namespace rm

@@ -230,7 +230,6 @@ __device__ __forceinline__ void auc_pass(const float (&v)[16], unsigned pos_addr
 }
 
 #ifdef RM_STATS
-__device__ unsigned long long g_stats[16];
 #ifdef RM_STATS_TIME_ONLY
 #define RM_STAT(i, x) do {} while (0)
 #else
@@ -371,13 +370,12 @@ void k_sweep(SweepArgs a)
     unsigned long long wkey = 0;                                   // LDS list: key of its worst entry (0 = empty slot)
     // small K in HBM: [K][32 users] replace-the-minimum like the LDS list (cheaper than selections below K ~ 32)
     GblListPtr Lr = (LLDS || buffered) ? nullptr : a.glists + ((size_t)blockIdx.x * NWAVES + wave) * GROUP_USERS * CAP + ul;
-    // K > 32: the wave's lane buffers, [entry][64 lanes]: lane_cap scores, then lane_cap item ids (scalar bases, the lane's next
-    // entry as a 32-bit byte offset: a store is global_store_dword voff, data, sbase -- no 64-bit vector address arithmetic)
+    // K > 32: the wave's lane buffers, [entry][64 lanes] (score, item) pairs (a scalar base, the lane's next entry as a 32-bit byte
+    // offset: an append is global_store_dwordx2 voff, pair, sbase -- no 64-bit vector address arithmetic)
     const int lane_cap = a.lane_cap;
     const char *lb_scores = buffered ? (const char *)a.glists + ((size_t)blockIdx.x * NWAVES + wave) * ((size_t)lane_cap * (WAVE * 8)) : nullptr;
-    const char *lb_items = buffered ? lb_scores + (size_t)lane_cap * (WAVE * 4) : nullptr;
-    unsigned lb_off = (unsigned)lane * 4u;                        // (entries of the lane) * 256 + lane * 4
-    const unsigned lb_trigger = (unsigned)(lane_cap - 15) << 8;   // a tile appends at most 16 per lane: select when cnt > lane_cap - 16
+    unsigned lb_off = (unsigned)lane * 8u;                        // (entries of the lane) * 512 + lane * 8
+    const unsigned lb_trigger = (unsigned)(lane_cap - 15) << 9;   // a tile appends at most 16 per lane: select when cnt > lane_cap - 16
     float ws = neg_inf_f(); int widx = IDX_EMPTY, wpos = 0;
     if (LLDS) {
         if (sub == 0 && h == 0) for (int i = 0; i < K + 2; i++) Ll[i * GROUP_USERS] = 0ull;
@@ -579,15 +577,36 @@ void k_sweep(SweepArgs a)
     // ---- epilogue of one 32-item x 32-user tile ----
     // last key this lane published / observed (lanes that own no list never follow the shared bound: all ones, so that the test
     // below is ONE compare whose lane mask the scalar unit can look at)
+#ifdef RM_STATS
+    unsigned long long st_sel = 0, st_bar = 0, st_app = 0; unsigned st_nsel = 0;
+#endif
     unsigned thr_pub = primary ? 0u : 0xffffffffu;
+    // SELECT WHILE WAITING: a selection is ~100 us of memory traffic during which the three other waves of the sub-tile's barrier
+    // domain run into the next barrier and wait -- each wave's three selections per item range cost the domain twelve stalls
+    // (profiles/r6_ab_c2.txt: 22 % of the wave cycles parked at the barrier, 16 % inside selections).  So a wave that starts a
+    // selection says so in LDS (the domain's epoch word), and a wave that finds the epoch moved while it spins at the barrier -- or at
+    // the end of its own epilogue -- runs ITS selection right then, provided its buffers are at least half full: the domain stalls
+    // once for all four, and every one of them comes back with a tighter bound.
+    LdsU32Ptr sel_epoch = (LdsU32Ptr)(smem + a.sync_off) + 4 + sub;      // (words 4..7: the list locks of the LDS lists, unused here)
+    unsigned sel_seen = 0u;
+    const unsigned lb_half = (unsigned)(lane_cap / 2) << 9;
+    // STAGGER: the sub-tile domains fill their buffers at the same pace, so left alone they select at the same tiles and every wave of
+    // the block sits in memory stalls together (a third of the wave cycles at BASELINE C2's shape with K = 100).  The FIRST selection
+    // of the later sub-tiles comes early -- at 3/4 (and 1/2) of the buffer -- and since the stream position grows by a constant
+    // factor from one selection to the next, the domains stay out of phase: while one waits for memory its SIMD partners compute.
+    unsigned lb_trig_now = sub == 0 ? lb_trigger : (sub == 1 ? (unsigned)(lane_cap - lane_cap / 4) << 9 : lb_half);
     auto lane_bounds = [&]() {
-        int c = (int)(lb_off >> 8);
-        float t_new; unsigned kk;
+#ifdef RM_STATS
+        const unsigned long long lb_t0 = __builtin_readcyclecounter();
+#endif
         // (no entry of the user exceeds the larger of its two lanes' running maxima -- unless the tie noise moved it)
         const float hi_hint = f_noise ? pos_inf_f() : LaneSel<float>::umax(vmax);
-        lane_select<float>((float *)lb_scores + lane, (int *)lb_items + lane, c, K, primary, thr, hi_hint, n, t_new, kk);
-        lb_off = ((unsigned)c << 8) | ((unsigned)lane * 4u);
-        RM_STAT(8, 1);
+        const LaneSelResult<float> sr = lane_select_call<float>((float *)lb_scores + 2 * lane, (int *)lb_scores + 2 * lane + 1, (int)(lb_off >> 9), K, primary, thr, hi_hint, n);
+        const float t_new = sr.thr; const unsigned kk = sr.kth_key;
+        lb_off = ((unsigned)sr.cnt << 9) | ((unsigned)lane * 8u);
+#ifdef RM_STATS
+        st_nsel++; st_sel += __builtin_readcyclecounter() - lb_t0;
+#endif
         if (kk) {
             thr = t_new;
             if (h == 0 && kk > thr_pub) atomicMax(a.thr_shared + slot, kk);
@@ -704,9 +723,12 @@ void k_sweep(SweepArgs a)
         // (a.ext_topk: k_metrics beyond the lists' reach -- every lane streams its scores and k_select_topk picks the top-K)
         const unsigned long long cm = f_ext ? 0ull : __ballot(tmax >= thr);
         RM_STAT(0, 1); RM_STAT(1, cm != 0); RM_STAT(2, __popcll(cm));
+#ifdef RM_STATS
+        const unsigned long long ap_t0 = __builtin_readcyclecounter();
+#endif
         if (buffered) {
-            // K > 32: every lane appends its own candidates to its own buffer (rm_list.hpp): per score register a compare, two
-            // stores under the lane mask, an add -- a register quad without a candidate in any lane is skipped with one test
+            // K > 32: every lane appends its own candidates to its own buffer (rm_list.hpp): per score register a compare, one
+            // 8-byte store under the lane mask, an add -- a register quad without a candidate in any lane is skipped with one test
             if (cm) {
                 const int sbh = sb + 4 * h;
                 #pragma unroll
@@ -715,14 +737,17 @@ void k_sweep(SweepArgs a)
                     #pragma unroll
                     for (int r = 4 * qd; r < 4 * qd + 4; r++) {
                         if (v[r] >= thr) {
-                            const int item = sbh + (r & 3) + 8 * (r >> 2);
-                            asm volatile("global_store_dword %0, %1, %2" :: "v"(lb_off), "v"(v[r]), "s"(lb_scores) : "memory");
-                            asm volatile("global_store_dword %0, %1, %2" :: "v"(lb_off), "v"(item), "s"(lb_items) : "memory");
-                            lb_off += 256u;
+                            u32x2 e;
+                            e.x = __float_as_uint(v[r]); e.y = (unsigned)(sbh + (r & 3) + 8 * (r >> 2));
+                            asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(lb_off), "v"(e), "s"(lb_scores) : "memory");
+                            lb_off += 512u;
                         }
                     }
                 }
             }
+#ifdef RM_STATS
+            st_app += __builtin_readcyclecounter() - ap_t0;
+#endif
         } else
         if (cm && pend_cap) {
             unsigned ov = 0;                                    // score registers that did not fit the lane's buffer
@@ -814,7 +839,19 @@ void k_sweep(SweepArgs a)
 #endif
         // K > 32: some lane is a tile away from a full buffer -> every user of the wave raises its bound (at the END of the
         // epilogue: the tile's scores are dead, their registers hold the selection's loads in flight)
-        if (buffered && wave_any(lb_off >= lb_trigger)) lane_bounds();
+        if (buffered) {
+            const bool own = wave_any(lb_off >= lb_trig_now);
+            unsigned ep = __builtin_amdgcn_readfirstlane(*sel_epoch);
+            if (own || (ep != sel_seen && wave_any(lb_off >= lb_half))) {
+                if (own && ep == sel_seen) {                      // (nobody has asked yet: ask)
+                    if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"((unsigned)(__UINTPTR_TYPE__)sel_epoch), "v"(1u) : "memory");
+                    ep++;
+                }
+                lane_bounds();
+                lb_trig_now = lb_trigger;
+            }
+            sel_seen = ep;
+        }
     };
 
     // ---- main loop: one barrier per tile.  Measured on gfx950 (scratch/coexec2.hip): an f32-input MFMA chain and
@@ -833,7 +870,7 @@ void k_sweep(SweepArgs a)
     // counter per sub-tile is unambiguous: all arrived for unit u  <=>  counter >= 4 (u + 1).
     constexpr unsigned SYNC_WAVES = 4;
     LdsU32Ptr arrive = (LdsU32Ptr)(smem + a.sync_off) + sub;            // (words 4..7 of the area: the groups' list locks)
-    if (tid < 4) ((LdsU32Ptr)(smem + a.sync_off))[tid] = 0u;
+    if (tid < (buffered ? 8 : 4)) ((LdsU32Ptr)(smem + a.sync_off))[tid] = 0u;      // (+ the domains' selection epochs, words 4..7)
     if (ntiles > 0) stage(t0 * NC, 0);
     // first tile's word of the dense train row, shifted so that bit (r & 3) + 8 (r >> 2) is accumulator r's item for this lane half
     unsigned tile_bits = (tb_row && ntiles > 0) ? a.train_bits[tb_idx] >> (4 * h) : 0u;
@@ -861,7 +898,19 @@ void k_sweep(SweepArgs a)
 #if !defined(RM_FULL_BARRIER) && !defined(RM_ABL_NO_BARRIER)
             if (unit > 0) {                                                       // wait half of the split barrier
                 const unsigned target = SYNC_WAVES * (unsigned)unit;
-                while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+#ifdef RM_STATS
+                const unsigned long long bw_t0 = __builtin_readcyclecounter();
+#endif
+                while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (buffered && !DUMP) {                        // a partner is selecting: this wave's turn too (see lane_bounds)
+                        const unsigned ep = __builtin_amdgcn_readfirstlane(*sel_epoch);
+                        if (ep != sel_seen) { sel_seen = ep; if (wave_any(lb_off >= lb_half)) { lane_bounds(); lb_trig_now = lb_trigger; } }
+                    }
+                }
+#ifdef RM_STATS
+                st_bar += __builtin_readcyclecounter() - bw_t0;
+#endif
             }
 #ifndef RM_ABL_NO_PRIO
             // The sub-tile domains progress independently, and the instruction arbiter serves the oldest wave first: left
@@ -989,7 +1038,7 @@ void k_sweep(SweepArgs a)
     } else if (!LLDS && !a.ext_topk) {
         // the lanes' entries stay where they are: k_collect_topk (rm_finalize.hpp) reads the buffers of all item ranges and sub-tile
         // waves of a user and writes its ordered top-K
-        a.lane_cnt[((size_t)blockIdx.x * NWAVES + wave) * WAVE + lane] = (slot_ok && primary) ? (int)(lb_off >> 8) : 0;
+        a.lane_cnt[((size_t)blockIdx.x * NWAVES + wave) * WAVE + lane] = (slot_ok && primary) ? (int)(lb_off >> 9) : 0;
     }
     if (AUC) {
         __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): the asm histogram atomics are invisible to the compiler
@@ -1002,6 +1051,7 @@ void k_sweep(SweepArgs a)
         }
     }
 #ifdef RM_STATS
+    if (lane == 0) { atomicAdd(&g_stats[5], (unsigned long long)st_nsel); atomicAdd(&g_stats[6], st_sel); atomicAdd(&g_stats[7], st_bar); atomicAdd(&g_stats[4], st_app); }
     if (threadIdx.x == 0) {
         const unsigned long long prof_t3 = __builtin_readcyclecounter();
         atomicAdd(&g_stats[10], prof_t1 - prof_t0); atomicAdd(&g_stats[11], prof_t2 - prof_t1); atomicAdd(&g_stats[12], prof_t3 - prof_t2);

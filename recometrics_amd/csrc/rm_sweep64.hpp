@@ -281,13 +281,18 @@ void k_sweep64(Sweep64Args a)
     };
 
     unsigned long long thr_pub = 0;
+    // select while waiting (see the fp32 sweep): the domain's selection epoch in LDS word 4 + sub
+    typedef __attribute__((address_space(3))) unsigned *LdsEpochPtr;
+    LdsEpochPtr sel_epoch = (LdsEpochPtr)(smem + a.sync_off) + 4 + sub;
+    unsigned sel_seen = 0u;
+    const unsigned lb_half = (unsigned)(lane_cap / 2) << 9;
+    unsigned lb_trig_now = sub == 0 ? lb_trigger : (unsigned)(lane_cap - lane_cap / 4) << 9;      // stagger of the two domains: see the fp32 sweep
     auto lane_bounds = [&]() {
-        int c = (int)(lb_off >> 9);
-        double t_new; unsigned long long kk;
         const double hi_hint = f_noise ? pos_inf_d() : LaneSel<double>::umax(vmax);
         // (out of line: inlined, the selection's working set is added to a register budget that is already full at 256 factors)
-        lane_select_call<double>((double *)lb_scores + lane, (int *)lb_items + lane, c, K, primary, thr, hi_hint, n, t_new, kk);
-        lb_off = ((unsigned)c << 9) | ((unsigned)lane * 8u);
+        const LaneSelResult<double> sr = lane_select_call<double>((double *)lb_scores + lane, (int *)lb_items + lane, (int)(lb_off >> 9), K, primary, thr, hi_hint, n);
+        const double t_new = sr.thr; const unsigned long long kk = sr.kth_key;
+        lb_off = ((unsigned)sr.cnt << 9) | ((unsigned)lane * 8u);
         if (kk) {
             thr = t_new;
             if (q == 0 && kk > thr_pub) atomicMax(a.thr_shared + slot, kk);
@@ -450,7 +455,19 @@ void k_sweep64(Sweep64Args a)
             }
         }
         // K > 32: some lane is a tile away from a full buffer -> every user of the wave raises its bound (see the fp32 sweep)
-        if (buffered && wave_any(lb_off >= lb_trigger)) lane_bounds();
+        if (buffered) {
+            const bool own = wave_any(lb_off >= lb_trig_now);
+            unsigned ep = __builtin_amdgcn_readfirstlane(*sel_epoch);
+            if (own || (ep != sel_seen && wave_any(lb_off >= lb_half))) {
+                if (own && ep == sel_seen) {
+                    if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"((unsigned)(__UINTPTR_TYPE__)sel_epoch), "v"(1u) : "memory");
+                    ep++;
+                }
+                lane_bounds();
+                lb_trig_now = lb_trigger;
+            }
+            sel_seen = ep;
+        }
     };
 
     // ---- main loop over tiles, chunks of the factor axis statically unrolled inside; one barrier per chunk.  All waves
@@ -461,7 +478,7 @@ void k_sweep64(Sweep64Args a)
     // next unit touches the buffers; the epilogue in between absorbs the skew between waves
     typedef __attribute__((address_space(3))) unsigned *LdsSyncPtr;
     LdsSyncPtr arrive = (LdsSyncPtr)(smem + a.sync_off) + sub;       // one domain per sub-tile: its four waves
-    if (tid < 4) ((LdsSyncPtr)(smem + a.sync_off))[tid] = 0u;
+    if (tid < 8) ((LdsSyncPtr)(smem + a.sync_off))[tid] = 0u;       // arrival counters, and (words 4..7) the domains' selection epochs
     if (ntiles > 0) stage(t0, 0, 0);
     if (AF_HALF_AHEAD) {                          // first half of chunk 0 (in front of the drain below: nothing is pending at the loop's entry)
         #pragma unroll
@@ -482,7 +499,13 @@ void k_sweep64(Sweep64Args a)
                 if (unit > 0) {
                     const unsigned target = 4u * (unsigned)unit;
 #ifndef RM_ABL_NO_BARRIER                                                 // (timing only: what the coupling of the domain's four waves costs)
-                    while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+                    while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (buffered && !DUMP) {
+                            const unsigned ep = __builtin_amdgcn_readfirstlane(*sel_epoch);
+                            if (ep != sel_seen) { sel_seen = ep; if (wave_any(lb_off >= lb_half)) { lane_bounds(); lb_trig_now = lb_trigger; } }
+                        }
+                    }
 #endif
                 }
                 // second half of this chunk first (it is needed 16 MFMAs from now), then the item tile of the next unit, then
@@ -540,7 +563,13 @@ void k_sweep64(Sweep64Args a)
             const int buf = unit & 1;
             if (unit > 0) {                                                       // wait half of the split barrier
                 const unsigned target = 4u * (unsigned)unit;
-                while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+                while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (buffered && !DUMP) {
+                        const unsigned ep = __builtin_amdgcn_readfirstlane(*sel_epoch);
+                        if (ep != sel_seen) { sel_seen = ep; if (wave_any(lb_off >= lb_half)) { lane_bounds(); lb_trig_now = lb_trigger; } }
+                    }
+                }
             }
             // (the fp32 sweep's priority balancing of the two domains was measured here too: 1.2 % slower at C5, not adopted)
             if (unit + 1 < nunits) {

@@ -3,7 +3,7 @@ The unit is rm_sweep32_n3_s1.hip -- the specialisation BASELINE C2 runs (dense t
 import os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from recometrics_amd import build as B
-B.build()
+B.build(incremental=True)
 os.makedirs("scratch/libs", exist_ok=True)
 UNIT = os.environ.get("ABL_UNIT", "rm_sweep32_n3_s1.hip")
 objs = [os.path.join(B.CSRC, os.path.splitext(s)[0] + ".o") for s in B.SOURCES if s != UNIT]

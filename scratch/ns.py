@@ -35,5 +35,5 @@ if os.environ.get("RM_PRINT_STATS"):
     buf = (ctypes.c_ulonglong * 16)()
     getattr(lib, os.environ.get("RM_STATS_FN", "rm_debug_stats"))(buf, 1)
     runs = steps + 1
-    names = ["wave_steps", "event_steps", "event_lanes", "hit_cells", "hit_lanes", "merges", "merge_iters", "merge_replacing", "cyc_loop_g3s0", "cyc_wait_sync", "cyc_prologue", "cyc_loop", "cyc_epilogue", "tiles", "cyc_loop_sub1", "cyc_loop_sub2"]
+    names = ["full_passes", "sample_passes", "tie_events", "below_events", "append_cycles", "merges_or_selections", "merge_iters_or_selection_cycles", "barrier_wait_cycles", "cyc_loop_g3s0", "cyc_wait_sync", "cyc_prologue", "cyc_loop", "cyc_epilogue", "tiles", "cyc_loop_sub1", "cyc_loop_sub2"]
     print(json.dumps({nm: buf[i] / runs for i, nm in enumerate(names)}))
