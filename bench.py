@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--parity-users", type=int, default=2048, help="users of the timed outputs compared with the reference (0 = skip)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-pointer (PCIe-inclusive) measurement")
     ap.add_argument("--e2e-child", action="store_true", help=argparse.SUPPRESS)      # internal: the host-pointer leg in a process of its own
+    ap.add_argument("--e2e-only", action="store_true", help=argparse.SUPPRESS)       # internal: the child measures the host-pointer call alone (the large shapes)
     ap.add_argument("--sharded-child", type=int, default=0, help=argparse.SUPPRESS)  # internal: rm_set_devices([0..N-1]) against the unsharded call
     ap.add_argument("--no-other", action="store_true", help="skip the compact legs over the other BASELINE configs (C3, C4, C5)")
     return ap.parse_args()
@@ -81,8 +82,9 @@ def host_problem(m, n, k, mean_c, seed, dtype=np.float32, shard=0):
 class DeviceProblem:
     """Synthetic workload resident in HBM (torch tensors are only the memory owner; the hot path gets raw pointers)."""
 
-    def __init__(self, torch, dev, m, n, k, mean_c, seed, K, dtype=np.float32, shard=0, cumulative=False, host=None):
+    def __init__(self, torch, dev, m, n, k, mean_c, seed, K, dtype=np.float32, shard=0, cumulative=False, host=None, metrics=None):
         self.m, self.n, self.k, self.K, self.dtype = m, n, k, K, dtype
+        self.metrics = tuple(metrics) if metrics else None                   # None = all ten; else the names asked for (_binding.METRIC_ORDER's spelling)
         self.host = host if host is not None else host_problem(m, n, k, mean_c, seed, dtype, shard)
         A, B = self.host["A"], self.host["B"]
         (trp, tri), (tep, tei, tev) = self.host["train"], self.host["test"]
@@ -93,9 +95,11 @@ class DeviceProblem:
         self.cumulative = bool(cumulative)
         self.noise = False                                                   # break_ties_with_noise of step() unless it says otherwise
         tdt = torch.float32 if dtype == np.float32 else torch.float64
+        from recometrics_amd._binding import METRIC_ORDER as _ALL
+        asked = [self.metrics is None or name in self.metrics for name in _ALL]
         if not self.cumulative:
             self.out = torch.empty((10, m), dtype=tdt, device=dev)           # per-user metric block
-            self.out_ptrs = lambda o: [o[i].data_ptr() for i in range(10)]     # noqa: E731
+            self.out_ptrs = lambda o: [o[i].data_ptr() if asked[i] else 0 for i in range(10)]     # noqa: E731  (0 = not requested)
         else:                                                                # eight [m, K] blocks, then ROC / PR-AUC [m]
             self.out = torch.empty((8 * K + 2) * m, dtype=tdt, device=dev)
             es = self.out.element_size()
@@ -122,7 +126,7 @@ def load_traffic(workload, users):
     """HBM bytes per sweep launch from the committed PMC run (scratch/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in
     separate rocprofv3 passes, FETCH_SIZE doubled per the gfx950 correction) and the file it was read from -- a constant of
     that profile, not a counter of this run; (None, None) when no matching profile exists."""
-    for rnd in ("r5", "r4", "r3", "r2"):                      # the newest committed profile of this workload and user count
+    for rnd in ("r6", "r5", "r4", "r3", "r2"):                      # the newest committed profile of this workload and user count
         rel = os.path.join("profiles", "%s_traffic_%s.json" % (rnd, workload))
         try:
             d = json.load(open(os.path.join(ROOT, rel)))
@@ -172,13 +176,29 @@ def sub_problem(host, users):
     return host["A"][users], host["B"], (ntrp, ntri), (ntep, ntei, ntev)
 
 
+def masked_problem(host, users):
+    """The WHOLE workload with the test rows of every user outside `users` emptied: the reference skips a user without test items at
+    once (src/recometrics.hpp:439-448), so it only evaluates the sample -- and every sampled user keeps its ORIGINAL index, which is
+    what seeds its tie noise there (mt19937(seed + user), :531).  Train rows and user factors are passed whole (never copied)."""
+    tep, tei, tev = host["test"]
+    m = len(tep) - 1
+    keep = np.zeros(m, bool)
+    keep[users] = True
+    cnt = np.where(keep, np.diff(tep), 0).astype(np.int64)
+    newp = np.zeros(m + 1, np.int64)
+    np.cumsum(cnt, out=newp[1:])
+    idx = np.repeat(tep[:-1].astype(np.int64)[keep] - newp[:-1][keep], cnt[keep]) + np.arange(newp[-1])
+    tri = host["train"][1]
+    return host["A"], host["B"], (host["train"][0], tri if tri.shape[0] else np.zeros(1, np.int32)), (newp.astype(np.int32), tei[idx], tev[idx])
+
+
 def parity_check(prob, out, n_users, noise=False, seed=1, cpu_seconds=15.0, binding=None):
     """verify parity on the same inputs in the same run before accepting a number -- a stratified sample of
     the users of the timed outputs (`out`: the metric block on the device) against the REAL reference compiled by
     oracle/Makefile (oracle/_ref, canonical build) when it is present, else against the restatement: metrics within 1e-5,
-    identical NaN pattern.  With `noise` the reference draws its mt19937(seed + user) tie noise per ORIGINAL user index, so
-    the sample is evaluated user by user range: contiguous runs keep their indices through `user0`-free calls only when they
-    start at 0 -- the noise check therefore uses the first users plus nothing else.
+    identical NaN pattern.  With `noise` the reference draws its mt19937(seed + user) tie noise per ORIGINAL user index: it is
+    handed the whole workload with the test rows of the users outside the sample emptied (`masked_problem`), so the same
+    stratified sample keeps its indices.
     Every sampled user whose metrics differ from the reference's in any BIT (ROC-AUC apart: x87 long double there) must have
     an exactly tied score on one of its positives (deviation D4: the reference leaves tied scores in libstdc++'s order,
     oracle/ties.py) -- `tie_users` counts them, a differing user without such a tie fails the check."""
@@ -188,19 +208,26 @@ def parity_check(prob, out, n_users, noise=False, seed=1, cpu_seconds=15.0, bind
     # a bounded amount of CPU work: the reference evaluates ~7e9 (item x factor) products per second on the box's cores
     # (4,300 users/s at C2), so ~15 s allow 1e11 / (n k) users -- 2,048 at C2 and C3, ~800 at the north-star shape, ~90 at C4
     n_users = int(max(16, min(n_users, cpu_seconds * 7.0e9 / (float(prob.n) * float(prob.k)))))
-    users = np.arange(min(n_users, prob.m)) if noise else stratified_users(host, n_users)
-    A, B, tr, te = sub_problem(host, users)
+    users = stratified_users(host, n_users)
+    # (with the tie noise the reference must see every sampled user under its own index: the whole workload, the other users' test rows emptied)
+    A, B, tr, te = masked_problem(host, users) if noise else sub_problem(host, users)
     impl, kind = (orc.Reference(), "reference") if orc.reference_available() else (orc.Oracle(), "port")
     # (the reference addresses its per-thread scratch as thread * n in int32, src/recometrics.hpp:499: at n = 10M more than 214
     # threads overflow it)
     nthreads = max(1, min(256, os.cpu_count() or 1, (2 ** 31 - 1) // int(B.shape[0])))
-    want = impl.calc(A, B, tr, te, prob.K, nthreads=nthreads, noise=noise, seed=seed, dtype=prob.dtype, cumulative=prob.cumulative)
+    asked = getattr(prob, "metrics", None) or orc.METRICS
+    want = impl.calc(A, B, tr, te, prob.K, metrics=tuple(asked), nthreads=nthreads, noise=noise, seed=seed, dtype=prob.dtype, cumulative=prob.cumulative)
     uidx = torch_index(out, users)
+    if noise:                                                    # from here on the sample as a problem of its own, like the noise-free case
+        want = {name: arr[users] for name, arr in want.items()}
+        A, B, tr, te = sub_problem(host, users)
     info = {"users": int(users.shape[0]), "checker": kind, "streamed_users": int((np.diff(te[0]) > 63).sum()),
-            "cold_users": int((np.diff(tr[0]) == 0).sum()), "sample": "first users" if noise else "stratified"}
+            "cold_users": int((np.diff(tr[0]) == 0).sum()), "sample": "stratified" + (" (original user indices: the reference's noise seeds)" if noise else "")}
     worst = 0.0
     differing = np.zeros(users.shape[0], bool)
     for i, name in enumerate(orc.METRICS):
+        if name not in asked:
+            continue
         w = want[orc.NAMES[name]]
         g = prob.metric(out, i)[uidx].cpu().numpy()
         if not (np.isnan(w) == np.isnan(g)).all():
@@ -257,7 +284,7 @@ def torch_index(out, users):
     return torch.from_numpy(users.astype(np.int64)).to(out.device)
 
 
-def e2e_host_measure(binding, host, k, K, dtype, reps=5):
+def e2e_host_measure(binding, host, k, K, dtype, reps=5, cumulative=False):
     """host arrays in -> host arrays out through rm_calc_metrics_* (H2D of A/B/CSR, device work, D2H
     of the metric block), first call (workspace allocation) and steady state (median)."""
     trp, tri = host["train"]
@@ -268,13 +295,14 @@ def e2e_host_measure(binding, host, k, K, dtype, reps=5):
     def call():
         t0 = time.perf_counter()
         binding.calc_metrics(host["A"], k, host["B"], k, trp, tri if tri.size else np.zeros(1, np.int32), tep, tei, tev,
-                             K, want, False, False, True, 2, 1, 1, 1)
+                             K, want, cumulative, False, True, 2, 1, 1, 1)
         return (time.perf_counter() - t0) * 1e3
     first = call()
     call()                                                     # (the second call still builds things: the peer context of the batch pipeline, its workspace)
     rest = sorted(call() for _ in range(reps + 2))
     steady = rest[len(rest) // 2]
-    return {"first_call_ms": first, "steady_ms": steady, "users_per_s": m / (steady * 1e-3),
+    bytes_in = sum(int(x.nbytes) for x in (host["A"], host["B"], trp, tri, tep, tei, tev))
+    return {"first_call_ms": first, "steady_ms": steady, "users_per_s": m / (steady * 1e-3), "bytes_in": bytes_in,
             "what": "rm_calc_metrics_%s: host pointers in, host pointers out (PCIe-inclusive), in a process of its own WITHOUT torch -- as the "
                     "Cython / Rcpp wrappers would call it (torch's bundled HIP runtime moves pageable memory 3-4x slower than the system's); "
                     "never `value`" % ("f32" if dtype == np.float32 else "f64")}
@@ -329,6 +357,9 @@ def e2e_child_main(args):
         m = args.users
     binding.load()
     host = host_problem(m, n, k, mean_c, seed, dtype)
+    if args.e2e_only:                                          # (the large shapes: three repetitions of a call of a tenth of a second or more)
+        print(json.dumps({"e2e_host": e2e_host_measure(binding, host, k, K, dtype, reps=1, cumulative=args.workload == "C3")}))
+        return
     res = {"e2e_host": e2e_host_measure(binding, host, k, K, dtype)}
     try:
         res["api_default"] = api_default_measure(host, k, K, dtype)
@@ -373,6 +404,22 @@ def sharded_child_main(args):
     print(json.dumps({"devices": devices, "distinct_devices": len(set(devices)), "visible_devices": ndev, "users": m,
                       "bitwise_equal_to_unsharded": bool(same), "unsharded_ms": t_one, "sharded_ms": t_sh,
                       "what": "rm_calc_metrics_* (host pointers) with rm_set_devices(%s) against rm_set_devices([0]); second call of each" % devices}))
+
+
+BIG_HOST_LEGS = (("NS", 32768), ("C3", 125000), ("C4", 8192), ("C5", 16384))
+
+
+def host_leg(early, wname, step_ms):
+    """the `e2e_host` record of a large shape next to its device-resident step: budget = 1.15 x step + input bytes at 45 GB/s"""
+    child = early.get("big_" + wname)
+    if not child:
+        return None
+    rec = dict(child.get("e2e_host", child))
+    if "steady_ms" in rec and step_ms:
+        rec["device_step_ms"] = step_ms
+        rec["budget_ms"] = 1.15 * step_ms + rec.get("bytes_in", 0) / 45e9 * 1e3
+        rec["within_budget"] = rec["steady_ms"] <= rec["budget_ms"]
+    return rec
 
 
 def run_child(args, m, extra, timeout=900, workload=None):
@@ -509,6 +556,17 @@ def main():
                 early["TUT"] = run_child(args, _CFG["TUT"][0], ["--e2e-child"], workload="TUT")
             except Exception as e:      # noqa: BLE001
                 early["TUT"] = {"error": repr(e)}
+        # SURVEY.md 8(d)(i) -- host arrays in, host arrays out -- where the inputs are BIG: the north-star shape (512 MB of item factors),
+        # C3's shard of one GPU (64 MB of user factors, 81 MB of outputs), the C4 and C5 slices of the compact legs (5.12 GB / 1.02 GB of
+        # item factors).  Each call is held against 1.15 x the device-resident step of the same shape + its input bytes at 45 GB/s.
+        if not args.no_extra and not args.no_other:
+            for wname, mo in BIG_HOST_LEGS:
+                if wname == args.workload:
+                    continue
+                try:
+                    early["big_" + wname] = run_child(args, mo, ["--e2e-child", "--e2e-only"], workload=wname)
+                except Exception as e:      # noqa: BLE001
+                    early["big_" + wname] = {"error": repr(e)}
     import torch
     import torch.distributed as dist
     from recometrics_amd import _binding as binding
@@ -679,6 +737,9 @@ def main():
                 td = json.load(open(os.path.join(ROOT, tr_src)))
                 line["north_star_shape"].update({"traffic": tr_b, "traffic_source": tr_src, "hbm_read_GBs": td["hbm_read_bytes"] / (sw2 * 1e-3) / 1e9,
                                                  "hbm_read_frac_of_peak": td["hbm_read_bytes"] / (sw2 * 1e-3) / 1e9 / PEAK_HBM_GBS})
+            hl = host_leg(early, "NS", dt2 / ns_steps * 1e3)
+            if hl:
+                line["north_star_shape"]["e2e_host"] = hl
             if args.parity_users > 0:
                 line["north_star_shape"]["parity"] = parity_check(p2, p2.out, min(args.parity_users, 512), binding=binding)
                 failed = failed or not line["north_star_shape"]["parity"]["ok"]
@@ -726,6 +787,38 @@ def main():
             line["tutorial"] = {"error": repr(e)}
 
     if rank == 0 and world == 1 and not args.no_extra and not args.no_other:
+        # The requests WITHOUT ROC / PR-AUC (the k_sweep<..., AUC = false, ...> family): the API's literal default -- precision,
+        # average_precision, ndcg, tie noise on (recometrics/__init__.py:50-62) -- at BASELINE C2's shape (k = 10) and at the
+        # tutorial's (k = 5), and BASELINE.md section 2's "NS, no AUC" row (the eight top-K metrics at the north-star shape).
+        noauc = {}
+        legs = [("defaults_C2", "C2", None, ("p", "ap", "ndcg"), True, 10, 2, "C2's shape, precision + average_precision + ndcg, k = 10, tie noise on (the API's default request)"),
+                ("defaults_TUT", "TUT", None, ("p", "ap", "ndcg"), True, 10, 2, "the tutorial's shape, precision + average_precision + ndcg, k = 5, tie noise on"),
+                ("NS_no_auc", "NS", 32768, ("p", "tp", "r", "ap", "tap", "ndcg", "hit", "rr"), False, 5, 2, "north-star shape, the eight top-K metrics, K = 10 (BASELINE.md section 2)")]
+        for lname, wname, mo, mets, noise_on, lsteps, lwarm, what in legs:
+            try:
+                m_, no, ko, dto, Ko, co, so = CONFIGS[wname]
+                mo = mo or m_
+                if "prob" in locals() and hasattr(prob, "A"):
+                    del prob.A, prob.B
+                torch.cuda.empty_cache()
+                pn = DeviceProblem(torch, dev, mo, no, ko, co, so, Ko, dto, metrics=mets)
+                pn.noise = noise_on
+                dtn_, swn, prn, fin, _ = measure(torch, dist, binding, pn, lsteps, lwarm, 1, None)
+                tfn = 2.0 * no * ko * mo / (swn * 1e-3) / 1e12
+                noauc[lname] = {"workload": what, "users": mo, "n_items": no, "n_factors": ko, "k_metrics": Ko, "metrics": list(mets), "noise": noise_on,
+                                "steps": lsteps, "warmup": lwarm, "users_per_s": mo * lsteps / dtn_, "ms_per_step": dtn_ / lsteps * 1e3,
+                                "sweep_ms": swn, "prep_ms": prn, "finalize_ms": fin, "mfma_TFLOPs": tfn, "mfma_frac": tfn / PEAK_FP32_MFMA_TFLOPS}
+                if args.parity_users > 0:
+                    noauc[lname]["parity"] = parity_check(pn, pn.out, min(args.parity_users, 1024), noise=noise_on, seed=1, cpu_seconds=5.0, binding=binding)
+                    failed = failed or not noauc[lname]["parity"]["ok"]
+                del pn
+                binding.load().rm_release_workspace()
+                torch.cuda.empty_cache()
+            except Exception as e:      # noqa: BLE001
+                noauc[lname] = {"error": repr(e)}
+        line["no_auc"] = noauc
+
+    if rank == 0 and world == 1 and not args.no_extra and not args.no_other:
         # every other BASELINE config in the same driver-run line, as compact legs: 3 timed steps after 1 warm-up, the sweep's
         # fraction of the MFMA peak, and a parity sample against the compiled reference bounded to ~5 s of CPU work each
         others = {}
@@ -761,6 +854,9 @@ def main():
                     others[wname].update({"traffic": tr_b, "traffic_source": tr_src,
                                           "hbm_read_GBs": td["hbm_read_bytes"] / (swo * 1e-3) / 1e9,
                                           "hbm_read_frac_of_peak": td["hbm_read_bytes"] / (swo * 1e-3) / 1e9 / PEAK_HBM_GBS})
+                hl = host_leg(early, wname, dto_ / 3 * 1e3)
+                if hl:
+                    others[wname]["e2e_host"] = hl
                 if args.parity_users > 0:
                     others[wname]["parity"] = parity_check(po, po.out, min(args.parity_users, 512), cpu_seconds=5.0, binding=binding)
                     failed = failed or not others[wname]["parity"]["ok"]

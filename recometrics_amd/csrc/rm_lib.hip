@@ -96,6 +96,14 @@ inline long long debug_free_cap()
     return g_sw.free_mb >= 0 ? (g_sw.free_mb << 20) : -1;
 }
 
+// RM_HOST_TRACE: host-side time stamps from inside run() (the phases of one batch), picked up by the host entry's trace line
+struct RunTrace {
+    std::mutex mu; std::vector<std::pair<const char *, double>> pts; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void point(const char *what) { std::lock_guard<std::mutex> lk(mu); pts.emplace_back(what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
+};
+RunTrace g_run_trace;
+#define RM_TRACE_POINT(what) do { if (g_sw.host_trace) g_run_trace.point(what); } while (0)
+
 // ---- cached device workspace (per device), so that repeated calls do not pay hipMalloc ----
 struct Workspace {
     std::map<std::string, std::pair<void *, size_t>> bufs;
@@ -393,25 +401,10 @@ inline long long stream_budget_bytes(const Workspace &ws)
 //                buffers -- 8 waves x 64 lanes x lane_cap entries per block of the sweep's grid -- fit a third of the free memory;
 //   lists        below that: in LDS while they fit, else replace-the-minimum in HBM;
 //   ext_topk     beyond: one score row per user + k_select_topk.
-// Entries per lane buffer for item ranges of `range_items` items per user and wave: at least Prec<T>::lane_cap (what a selection
-// needs to make progress), and enough that ONE selection per range is the rule -- the first, when every lane fills up together
-// on the unbounded scores of the first tiles; after it a user holds ~1.25 K survivors and the rest of the range appends
-// ~K ln(range / position of that selection) more, spread over its lanes (+ three standard deviations, + a tile's appends).  A
-// selection reads a wave's buffers once or twice and writes a third of them back scattered, four bytes at a time -- with 2K + 16
-// entries per lane BASELINE C2's shape at K = 100 ran four of them per range and wave, a third of the sweep's wave cycles
-// (profiles/r6_ab_c2.txt).
-template <class T> inline int lane_cap_for(int K, long long range_items)
-{
-    const int base = Prec<T>::lane_cap(K), lpu = Prec<T>::lanes_per_user;
-    const double first = (double)lpu * (base - Prec<T>::lane_tile);                  // items a user has seen at the first selection
-    const double later = (double)K * std::log(std::max(1.0, (double)range_items / std::max(1.0, first)));
-    const double per_lane = (1.25 * K + later) / lpu;
-    long long cap = (long long)(per_lane + 3.0 * std::sqrt(per_lane) + Prec<T>::lane_tile + 1.0);
-    cap = std::max<long long>(base, std::min<long long>(cap, 4LL * base));
-    cap = std::min<long long>((cap + 15) / 16 * 16, (COLLECT_MAX_ENTRIES - K) / 16 * 16);
-    return (int)std::max<long long>(cap, base);
-}
-template <class T> inline long long lane_list_bytes(int K, long long n_blocks) { return n_blocks * (4 * Prec<T>::max_nsub) * WAVE * 2LL * Prec<T>::lane_cap(K) * (long long)(sizeof(T) + 4); }    // (an estimate: lane_cap_for may double the base)
+// (Larger buffers -- sized so that one selection per item range is the rule -- were measured in round 6 and are SLOWER: what a range
+// costs is the entries its selections scan in all, which hardly depends on the size, and larger buffers lose the L2: BASELINE C2's shape
+// at K = 100: 12.9 ms with 304 entries per lane, 12.7 with 448, against 12.4 with the base size and 12.2 with 160; profiles/r6_ab_c2.txt)
+template <class T> inline long long lane_list_bytes(int K, long long n_blocks) { return n_blocks * 8 * WAVE * (long long)Prec<T>::lane_cap(K) * (long long)(sizeof(T) + 4); }
 template <class T> inline bool lane_lists_possible(int K)
 {
     const long long min_k = g_sw.lane_min_k >= 0 ? g_sw.lane_min_k : 21;
@@ -577,6 +570,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     auto join_side = [&]() { HIP_CHECK(hipEventRecord(cx.side_ev[1], cx.side_stream)); HIP_CHECK(hipStreamWaitEvent(stream, cx.side_ev[1], 0)); side_guard.pending = 0; };
     const bool use_side = !g_sw.no_side;
 
+    RM_TRACE_POINT("run: start");
     // ---- plan ----
     int *flags = (int *)ws.get("flags", sizeof(int) * (size_t)m);
     int *user_nslots = (int *)ws.get("user_nslots", sizeof(int) * (size_t)m);
@@ -754,7 +748,9 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             launch_flat(aux2);
             if (use_side) HIP_CHECK(hipEventRecord(cx.pos_ev[1], cx.pos_stream));
         }
+        RM_TRACE_POINT("run: plan chain + side kernels enqueued");
         HIP_CHECK(hipStreamSynchronize(stream));
+        RM_TRACE_POINT("run: plan read back");
         // (the stream has waited for the checks and the maxima: only the dense train rows of the first attempt may still be running on
         // the side stream, only the positives' scores on theirs)
         if (use_side && !(attempt == 0 && bits_early)) side_guard.pending--;
@@ -1030,11 +1026,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         typename P::ListT *glists = nullptr;
         const unsigned n_blocks = (unsigned)((n_ublocks - tail_ublocks) * n_splits + tail_ublocks * tail_splits);
         const bool lane_lists = want_lane && !ext_topk;                     // per-lane append buffers + k_collect_topk (rm_list.hpp)
-        int lane_cap = lane_lists ? (g_sw.lane_cap_set == 0 ? lane_cap_for<T>(K, (long long)cdiv(tiles_total, n_splits) * 32) : P::lane_cap(K)) : 0;
-        // (never more than a third of the free memory: the base size always fits -- lane_lists_fit has asked)
-        while (lane_lists && lane_cap > P::lane_cap(K) &&
-               (long long)n_blocks * n_waves * WAVE * lane_cap * (long long)(sizeof(T) + 4) > free_plus_owned(ws, {"glists", "stream_scores", "sel_hi", "sel_lo"}) / 3)
-            lane_cap = std::max(P::lane_cap(K), (lane_cap / 2 + 15) / 16 * 16);
+        int lane_cap = lane_lists ? P::lane_cap(K) : 0;
         if (lane_lists && g_sw.lane_cap_set > 0) lane_cap = (int)std::min<long long>(std::max<long long>(P::lane_cap(K), (g_sw.lane_cap_set + 15) / 16 * 16), (COLLECT_MAX_ENTRIES - K) / 16 * 16);
         if (lane_lists && g_sw.lane_cap_min >= 0)        // K + slack survivors and one tile's appends (16: both precisions' bound) in one lane
             lane_cap = std::min(lane_cap, (K + lane_sel_slack(K) + 16 + 1 + 15) / 16 * 16);
@@ -1076,6 +1068,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             HIP_CHECK(hipMemcpyAsync(c.flag_count_host, &plan->n_noise_flagged, sizeof(int), hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipEventRecord(c.flags_event, stream));
         }
+        RM_TRACE_POINT("run: preparation enqueued");
         HIP_CHECK(hipEventRecord(g_ev[1], stream));
         // Depth split: when only the deepest user blocks force the lists out of LDS (the allocation is sized per launch,
         // the tables per block), the shallow blocks [0, u_split) get their own launch with LDS lists.  The two launches
@@ -1112,6 +1105,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             // blocks, the side launch ran AFTER the main one instead of beside it: 61 ms of tail.  gpurun_out r2q.)
             dispatch_sweep(want_auc, false, list_in_lds, nsub, NG, dim3(n_blocks), lds_total, stream, sa);
         }
+        RM_TRACE_POINT("run: sweep enqueued");
         HIP_CHECK(hipEventRecord(g_ev[2], stream));
         if (lane_lists) {
             collect.on = true; collect.glists = (const char *)glists; collect.lane_cnt = lane_cnt; collect.thr = (const void *)thr_shared;
@@ -1215,6 +1209,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     if (c.pos_rank)           // (per user, never a memset of the whole array: a batch must not clear what other batches wrote)
         hipLaunchKernelGGL(k_export_pos_rank, dim3(cdiv(m, 128)), dim3(128), 0, stream, c.nnz_test, m, c.test_p, flags, pos_order, rank_sorted, c.pos_rank,
                            (want_auc && n_slots > 0) ? 1 : 0);
+    RM_TRACE_POINT("run: finalisation enqueued");
     HIP_CHECK(hipEventRecord(g_ev[3], stream));
     HIP_CHECK(hipEventRecord(cx.done, stream));
     cx.ev_recorded = true;
@@ -1735,6 +1730,7 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
     };
     // RM_HOST_TRACE (timing studies only): host-side time stamps of the pipeline, printed at the end of the call
     const bool trace = g_sw.host_trace;
+    RM_TRACE_POINT("host entry: batches start");
     std::vector<std::pair<const char *, double>> stamps;
     const auto t_start = std::chrono::steady_clock::now();
     auto stamp = [&](const char *what) { if (trace) stamps.emplace_back(what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count()); };
@@ -1992,6 +1988,11 @@ void run_host_range(const HostCall<T> &h, int u0, int u1, Ctx &cx, hipStream_t s
         std::string line = "rm host trace (" + std::to_string(n_batches) + " batches, ms):";
         for (auto &st : stamps) { char buf[96]; snprintf(buf, sizeof buf, " [%s %.3f]", st.first, st.second); line += buf; }
         fprintf(stderr, "%s\n", line.c_str());
+        std::lock_guard<std::mutex> tl(g_run_trace.mu);
+        std::string l2 = "rm run trace (ms since the library was loaded):";
+        for (auto &pt : g_run_trace.pts) { char buf[112]; snprintf(buf, sizeof buf, " [%s %.3f]", pt.first, pt.second); l2 += buf; }
+        fprintf(stderr, "%s\n", l2.c_str());
+        g_run_trace.pts.clear();
     }
 }
 

@@ -272,8 +272,11 @@ def test_list_schemes_agree(hip, oracle, env, dtype, monkeypatch):
 def test_depth_split_launches_with_a_two_level_grid(hip, oracle, splits, monkeypatch):
     """128 factors, K = 32, users with deep and with shallow positive trees: the LDS lists fit next to the shallow blocks'
     tables only, so the sweep runs as two launches side by side (deep blocks with HBM lists, shallow ones with LDS lists);
-    with a two-level grid the tail user blocks are the shallow launch's first, then the deep one's"""
+    with a two-level grid the tail user blocks are the shallow launch's first, then the deep one's.  (Since round 6 a k_metrics of
+    21 and more takes the lane buffers, and up to 20 the lists fit LDS at every depth: the depth split is what remains when the lane
+    buffers do not fit the device's memory -- here they are switched off.)"""
     from recometrics_amd.synth import make_problem
+    monkeypatch.setenv("RM_DEBUG_LANE_MIN_K", "1000000")
     if splits:
         monkeypatch.setenv("RM_DEBUG_SPLITS", splits)
     pr = make_problem(700, 6000, 128, np.float32, mean_c=120, seed=77)
@@ -695,7 +698,8 @@ def test_baseline_c2_at_its_full_user_count(hip, noise):
     streamed users = 2.8 GB of score rows addressed beyond 2^31 bytes, user batches) at full size, checked against the
     REAL reference (oracle/_ref) on a stratified sample of 2,560 users: heaviest test rows, streamed users, the deepest
     LDS tables, cold and skipped users, the first and last user blocks, a random remainder.  noise=True is the API default
-    (the reference's mt19937(seed + user) stream: the first 1,536 users keep their indices, so the same seed applies)."""
+    (the reference's mt19937(seed + user) stream: it sees the whole workload with the other users' test rows emptied, so the
+    sampled users keep their indices)."""
     import bench
     from oracle.oracle import NAMES, Oracle, Reference, reference_available
     from recometrics_amd.synth import CONFIGS, make_factors, make_interactions
@@ -706,11 +710,18 @@ def test_baseline_c2_at_its_full_user_count(hip, noise):
     host = dict(A=A, B=B, train=(trp, tri), test=(tep, tei, tev))
     want_flags = {name: True for name in hip.METRIC_ORDER}
     outs = hip.calc_metrics(A, k, B, k, trp, tri, tep, tei, tev, K, want_flags, False, noise, True, 2, 1, 1, 77)
-    users = np.arange(1536) if noise else bench.stratified_users(host, 2560)
-    assert noise or ((np.diff(tep)[users] > 63).sum() >= 300 and users[-1] == m - 1)
+    users = bench.stratified_users(host, 2560)
+    assert (np.diff(tep)[users] > 63).sum() >= 300 and users[-1] == m - 1
     sA, sB, str_, ste = bench.sub_problem(host, users)
     impl = Reference() if reference_available() else Oracle()
-    want = impl.calc(sA, sB, str_, ste, K, nthreads=min(256, os.cpu_count() or 1), noise=noise, seed=77, dtype=dtype)
+    if noise:
+        # the reference seeds a user's noise by its ORIGINAL index: it gets the whole workload with the other users' test rows emptied
+        # (it skips a user without test items at once, src/recometrics.hpp:439-448)
+        fA, fB, ftr, fte = bench.masked_problem(host, users)
+        want = impl.calc(fA, fB, ftr, fte, K, nthreads=min(256, os.cpu_count() or 1), noise=True, seed=77, dtype=dtype)
+        want = {name: arr[users] for name, arr in want.items()}
+    else:
+        want = impl.calc(sA, sB, str_, ste, K, nthreads=min(256, os.cpu_count() or 1), noise=noise, seed=77, dtype=dtype)
     differing = np.zeros(users.shape[0], bool)
     for name, arr in zip(hip.METRIC_ORDER, outs):
         assert_close(arr[users], want[NAMES[name]], TOL, "C2 full size, noise=%s: %s" % (noise, name))
@@ -1010,6 +1021,13 @@ def test_baseline_c5_at_its_full_user_count(hip):
     """C5: 200,000 users x 500,000 items x 256 factors fp64, K = 50, all ten metrics, ONE device call"""
     got = _full_m_run("C5", False, 160, 8.0)
     _full_m_asserts(got, 200_000)
+
+
+def test_baseline_c4_at_its_full_user_count(hip):
+    """C4: 100,000 users x 10,000,000 items x 128 factors fp32, K = 100 + ROC / PR-AUC, ONE device call (782 user blocks over a
+    5.12 GB item matrix; the lane buffers and k_collect_topk of k_metrics = 100 at full size; ~2.5 s of device work)"""
+    got = _full_m_run("C4", False, 48, 12.0)
+    _full_m_asserts(got, 100_000)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
