@@ -205,6 +205,7 @@ template <> struct LaneSel<float> {
     // what they cost there is the number of memory instructions (round 6: scores and items in separate arrays were 10,500 of them per
     // wave and item range at BASELINE C2's shape with K = 100, two thirds of them the appends' masked 4-byte stores)
     static constexpr int SS = 128, IS = 128;                        // floats / ints from one entry of a lane to its next
+    static constexpr int BATCH = 32, NSAMPLE = 32;                  // loads in flight per pass over a buffer; entries of the in-register sample
     static __device__ __forceinline__ void load_entry(const float *sc, const int *, size_t i, float &x, int &id)
     {
         const unsigned long long b = __hip_atomic_load((const unsigned long long *)(sc + i * SS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -229,6 +230,9 @@ template <> struct LaneSel<double> {
     static __device__ __forceinline__ double load(const double *p) { return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
     // fp64: the scores of a wave ([entry][64 lanes] x 8 bytes), then its item ids ([entry][64 lanes] x 4 bytes)
     static constexpr int SS = 64, IS = 64;
+    // (half of the fp32 sizes: a score is two registers, and the selection -- a real call out of a kernel with a hundred live registers --
+    // must leave room for them: with 32 + 32 doubles the callee took 209 VGPRs and the 128-factor-chunk kernels faulted, round 6)
+    static constexpr int BATCH = 16, NSAMPLE = 16;
     static __device__ __forceinline__ void load_entry(const double *sc, const int *it, size_t i, double &x, int &id)
     {
         x = load(sc + i * SS); id = (int)__hip_atomic_load((const unsigned *)(it + i * IS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -261,14 +265,15 @@ __device__ __forceinline__ void lane_count3(const S *sc, int cend, S p1, S p2, S
     typedef LaneSel<S> L;
     c1 = 0; c2 = 0; c3 = 0;
     int i = 0;
-    for (; i + 32 <= cend; i += 32) {
-        S x[32];
+    constexpr int B = L::BATCH;
+    for (; i + B <= cend; i += B) {
+        S x[B];
         #pragma unroll
-        for (int t = 0; t < 32; t++) x[t] = L::load(sc + (size_t)(i + t) * L::SS);
+        for (int t = 0; t < B; t++) x[t] = L::load(sc + (size_t)(i + t) * L::SS);
         #pragma unroll
-        for (int t = 0; t < 32; t++) { c1 += x[t] >= p1; c2 += x[t] >= p2; c3 += x[t] >= p3; }
+        for (int t = 0; t < B; t++) { c1 += x[t] >= p1; c2 += x[t] >= p2; c3 += x[t] >= p3; }
     }
-    if (i < cend) {
+    if (B > 16 && i < cend) {
         S x[16];
         #pragma unroll
         for (int t = 0; t < 16; t++) x[t] = L::load(sc + (size_t)(i + t) * L::SS);
@@ -316,14 +321,14 @@ __device__ __forceinline__ void lane_select(S *sc, int *it, int &cnt, const int 
     const Key lo0 = lo;
     int cT = C;                                                     // entries at or above unkey(lo) (at lo0: an upper bound, see below)
     bool done = !active;
-    // ---- the first pass's probes from a SAMPLE: every (cend / 32)-th entry of the lane, 32 registers, one round trip.  The sample's
+    // ---- the first pass's probes from a SAMPLE: every (cend / 32)-th entry of the lane (fp64: every (cend / 16)-th), one round trip.  The sample's
     // order statistics at the ranks that correspond to ~K + slack / 2 entries of the whole and a standard deviation of the estimate to
     // either side are found in registers (three bisections in lock-step, no memory traffic).  Whatever the sample says only chooses
     // WHERE the first pass over the whole buffer probes: the bracket is updated from the true counts alone, so a misleading sample
     // costs passes, never correctness.  (Without it: ~8 passes of 14 dependent round trips each; with it 2.)
     Key sk1 = 0, sk2 = 0, sk3 = 0;
     {
-        constexpr int NS = 32;
+        constexpr int NS = L::NSAMPLE;
         const int st = cend / NS > 0 ? cend / NS : 1;
         S xs[NS];
         #pragma unroll

@@ -594,7 +594,11 @@ void k_sweep(SweepArgs a)
     // the block sits in memory stalls together (a third of the wave cycles at BASELINE C2's shape with K = 100).  The FIRST selection
     // of the later sub-tiles comes early -- at 3/4 (and 1/2) of the buffer -- and since the stream position grows by a constant
     // factor from one selection to the next, the domains stay out of phase: while one waits for memory its SIMD partners compute.
+    // (never later than the level that keeps a tile's sixteen appends inside the buffer: with fewer than 60 entries per lane 3/4 of the
+    // buffer lies beyond it -- found by scratch/fuzz_r6.sh with every k_metrics forced through the lane buffers: a lane ran into the
+    // next wave's rows)
     unsigned lb_trig_now = sub == 0 ? lb_trigger : (sub == 1 ? (unsigned)(lane_cap - lane_cap / 4) << 9 : lb_half);
+    lb_trig_now = lb_trig_now < lb_trigger ? lb_trig_now : lb_trigger;
     auto lane_bounds = [&]() {
 #ifdef RM_STATS
         const unsigned long long lb_t0 = __builtin_readcyclecounter();
@@ -739,7 +743,11 @@ void k_sweep(SweepArgs a)
                         if (v[r] >= thr) {
                             u32x2 e;
                             e.x = __float_as_uint(v[r]); e.y = (unsigned)(sbh + (r & 3) + 8 * (r >> 2));
-                            asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(lb_off), "v"(e), "s"(lb_scores) : "memory");
+                            // (s_nop 4: under register pressure the base pair is an SGPR spill, restored by v_readlane right in front of
+                            // this statement -- a VALU write of an SGPR needs five wait states before a memory instruction reads it, and
+                            // the compiler's hazard recognizer does not look inside inline asm: without them the store went to a stale
+                            // base, a memory fault in exactly the kernels that spill the pair -- 24-40 factors, fp64 beyond 128)
+                            asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2" :: "v"(lb_off), "v"(e), "s"(lb_scores) : "memory");
                             lb_off += 512u;
                         }
                     }

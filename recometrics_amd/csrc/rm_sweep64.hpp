@@ -287,6 +287,7 @@ void k_sweep64(Sweep64Args a)
     unsigned sel_seen = 0u;
     const unsigned lb_half = (unsigned)(lane_cap / 2) << 9;
     unsigned lb_trig_now = sub == 0 ? lb_trigger : (unsigned)(lane_cap - lane_cap / 4) << 9;      // stagger of the two domains: see the fp32 sweep
+    lb_trig_now = lb_trig_now < lb_trigger ? lb_trig_now : lb_trigger;                               // (never beyond the safe level)
     auto lane_bounds = [&]() {
         const double hi_hint = f_noise ? pos_inf_d() : LaneSel<double>::umax(vmax);
         // (out of line: inlined, the selection's working set is added to a register budget that is already full at 256 factors)
@@ -369,8 +370,10 @@ void k_sweep64(Sweep64Args a)
                     if (v[r] >= thr) {
                         const int item = sbq + (r >> 2) * 16 + 4 * (r & 3);
                         const unsigned ioff = lb_off >> 1;
-                        asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(lb_off), "v"(v[r]), "s"(lb_scores) : "memory");
-                        asm volatile("global_store_dword %0, %1, %2" :: "v"(ioff), "v"(item), "s"(lb_items) : "memory");
+                        // (one statement, s_nop 4 in front: a base pair that was spilled is restored by v_readlane right before it, and a
+                        // VALU write of an SGPR needs five wait states before a memory instruction reads it -- see the fp32 sweep)
+                        asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2\n\tglobal_store_dword %3, %4, %5"
+                                     :: "v"(lb_off), "v"(v[r]), "s"(lb_scores), "v"(ioff), "v"(item), "s"(lb_items) : "memory");
                         lb_off += 512u;
                     }
                 }

@@ -44,6 +44,8 @@ for it in range(cases):
         pr["B"] = pr["B"].copy(); pr["B"][rng.random(n) < 0.15] = 0
         dup = rng.random(n) < 0.2
         pr["B"][dup] = pr["B"][rng.integers(0, n, int(dup.sum()))]
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("CASE", it, dict(dtype=dtype.__name__, m=m, n=n, k=k, K=K, mean_c=mean_c, **kw), flush=True)
     try:
         want = oracle.calc(pr["A"], pr["B"], pr["train"], pr["test"], K, dtype=dtype, nthreads=8, **kw)
         got = hip_calc(hip, pr["A"], pr["B"], pr["train"], pr["test"], K, dtype=dtype, **kw)

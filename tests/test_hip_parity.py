@@ -1066,3 +1066,29 @@ def test_lane_selection_cuts_exact_ties_by_item(hip, oracle, dtype, env, monkeyp
     assert (got["topk_idx"] == want["topk_idx"]).all(), "top-K index lists differ"
     assert_same_bits(got["topk_score"], want["topk_score"], "top-K scores")
     assert (got["pos_rank"] == want["pos_rank"]).all(), "positive ranks differ"
+
+
+@pytest.mark.parametrize("dtype,k,K,noise", [(np.float64, 300, 60, True), (np.float64, 200, 33, True), (np.float64, 300, 60, False),
+                                             (np.float32, 40, 33, False), (np.float32, 24, 100, True), (np.float32, 300, 60, True)])
+def test_lane_buffers_in_the_kernels_that_spill_the_buffer_base(hip, oracle, dtype, k, K, noise, monkeypatch):
+    """the sweep kernels whose register pressure spills the lane buffers' base pointer (fp64 with the factor axis in 128-factor chunks
+    and the run-time switches -- tie noise, RM_DEBUG_NO_SPEC --, fp32 at 24-40 factors) restore it with v_readlane right in front of the
+    appends' inline asm: without the wait states inside the statement the stores went to a stale base (memory faults; round 6)"""
+    from recometrics_amd.synth import make_problem
+    if not noise:
+        monkeypatch.setenv("RM_DEBUG_NO_SPEC", "1")
+    pr = make_problem(200, 9000, k, dtype, mean_c=80, seed=900 + k)
+    _check_against_oracle(hip, oracle, pr, K, dtype=dtype, noise=noise)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("K", [1, 3, 8, 21])
+def test_small_lane_buffers_never_run_into_the_next_waves(hip, oracle, dtype, K, monkeypatch):
+    """every k_metrics through the lane buffers (RM_DEBUG_LANE_MIN_K): with fewer than 60 entries per lane the staggered first selection
+    of the second sub-tile (3/4 of the buffer) lay beyond the level that keeps a tile's appends inside the buffer -- lanes overflowed
+    into the next wave's rows and other users lost candidates (found by scratch/fuzz_r6.sh)"""
+    from recometrics_amd.synth import make_problem
+    monkeypatch.setenv("RM_DEBUG_LANE_MIN_K", "1")
+    for seed in (1234, 1235):
+        pr = make_problem(1500, 300, 100 if dtype == np.float32 else 40, dtype, mean_c=50, seed=seed)
+        _check_against_oracle(hip, oracle, pr, K, dtype=dtype)
