@@ -596,7 +596,9 @@ void k_sweep(SweepArgs a)
     // factor from one selection to the next, the domains stay out of phase: while one waits for memory its SIMD partners compute.
     // (never later than the level that keeps a tile's sixteen appends inside the buffer: with fewer than 60 entries per lane 3/4 of the
     // buffer lies beyond it -- found by scratch/fuzz_r6.sh with every k_metrics forced through the lane buffers: a lane ran into the
-    // next wave's rows)
+    // next wave's rows.  Measured and dropped: the first selection as early as it can do anything, at (K + slack) / 2 + 4 entries per
+    // lane instead of a full buffer -- a fifth fewer appends, one more selection: 11.1 against 10.9 ms at BASELINE C2's shape with
+    // K = 100, 17.1 against 15.9 at K = 256; profiles/r6_ab_c2.txt)
     unsigned lb_trig_now = sub == 0 ? lb_trigger : (sub == 1 ? (unsigned)(lane_cap - lane_cap / 4) << 9 : lb_half);
     lb_trig_now = lb_trig_now < lb_trigger ? lb_trig_now : lb_trigger;
     auto lane_bounds = [&]() {
