@@ -736,7 +736,8 @@ def main():
             if tr_b:
                 td = json.load(open(os.path.join(ROOT, tr_src)))
                 line["north_star_shape"].update({"traffic": tr_b, "traffic_source": tr_src, "hbm_read_GBs": td["hbm_read_bytes"] / (sw2 * 1e-3) / 1e9,
-                                                 "hbm_read_frac_of_peak": td["hbm_read_bytes"] / (sw2 * 1e-3) / 1e9 / PEAK_HBM_GBS})
+                                                 "hbm_read_frac_of_peak": td["hbm_read_bytes"] / (sw2 * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                                 "traffic_counts": "L2-miss bytes of the sweep launch: FETCH_SIZE x 2 (the factor for this LDS-DMA pattern: profiles/r6_fetch_calibration.txt) + WRITE_SIZE; Infinity-Cache hits are counted, so this is fabric traffic, an upper bound of the HBM bytes"})
             hl = host_leg(early, "NS", dt2 / ns_steps * 1e3)
             if hl:
                 line["north_star_shape"]["e2e_host"] = hl
@@ -853,7 +854,8 @@ def main():
                     td = json.load(open(os.path.join(ROOT, tr_src)))
                     others[wname].update({"traffic": tr_b, "traffic_source": tr_src,
                                           "hbm_read_GBs": td["hbm_read_bytes"] / (swo * 1e-3) / 1e9,
-                                          "hbm_read_frac_of_peak": td["hbm_read_bytes"] / (swo * 1e-3) / 1e9 / PEAK_HBM_GBS})
+                                          "hbm_read_frac_of_peak": td["hbm_read_bytes"] / (swo * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                          "traffic_counts": "L2-miss bytes of the sweep launch: FETCH_SIZE x 2 (the factor for this LDS-DMA pattern: profiles/r6_fetch_calibration.txt) + WRITE_SIZE; Infinity-Cache hits are counted, so this is fabric traffic, an upper bound of the HBM bytes"})
                 hl = host_leg(early, wname, dto_ / 3 * 1e3)
                 if hl:
                     others[wname]["e2e_host"] = hl
