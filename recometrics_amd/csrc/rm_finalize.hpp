@@ -750,8 +750,10 @@ __global__ __launch_bounds__(CAPW == 1024 ? 256 : 64) void k_collect_topk(FinalA
         });
     }
     wave_sync();
+#ifndef RM_ABL_COLLECT_GATHER_ONLY                             // (timing only, scratch/build_abl.py: what the gather alone costs)
     select_best();
     sort_kept();
+#endif
     Entry<S> *M = a.merged + (size_t)u * K;
     for (int i = lane; i < K; i += WAVE) {
         Entry<S> e;

@@ -395,7 +395,7 @@ inline long long stream_budget_bytes(const Workspace &ws)
 }
 
 // Which top-K scheme a pass takes (rm_sweep.hpp LMODE):
-//   lane lists   per-lane append buffers + lane-parallel selection + k_collect_topk (rm_list.hpp): k_metrics from `lane_min_k` (21; the
+//   lane lists   per-lane append buffers + lane-parallel selection + k_collect_topk (rm_list.hpp): k_metrics from `lane_min_k` (21 / 14; the
 //                replace-the-minimum lists rescan K entries per insert: BASELINE C2's shape took 8.1 / 15.0 / 26.8 ms at K = 20 /
 //                32 / 50 in LDS or HBM lists against 8.1 / 8.7 / 10.0 here, profiles/r6_ksweep_C2.txt) up to what k_collect_topk sorts in LDS (K + one lane buffer <= 4,096 entries: K <= 1,354), while the
 //                buffers -- 8 waves x 64 lanes x lane_cap entries per block of the sweep's grid -- fit a third of the free memory;
@@ -405,17 +405,23 @@ inline long long stream_budget_bytes(const Workspace &ws)
 // costs is the entries its selections scan in all, which hardly depends on the size, and larger buffers lose the L2: BASELINE C2's shape
 // at K = 100: 12.9 ms with 304 entries per lane, 12.7 with 448, against 12.4 with the base size and 12.2 with 160; profiles/r6_ab_c2.txt)
 template <class T> inline long long lane_list_bytes(int K, long long n_blocks) { return n_blocks * 8 * WAVE * (long long)Prec<T>::lane_cap(K) * (long long)(sizeof(T) + 4); }
-template <class T> inline bool lane_lists_possible(int K)
+// (`three_subtiles`: the kernel the replace-the-minimum lists would run on has three sub-tiles per step -- fp32 up to 64 factors -- which
+// the lane buffers do not (a user's candidates over three waves: slower, r6h): there the lists hold out until K = 20.  Where both run
+// two sub-tiles the lane buffers' lighter epilogue wins from K = 14: north-star shape K = 16 77.4 against 78.9 ms, K = 20 77.6 / 79.9,
+// K = 12 77.45 / 77.41; C3 (cumulative K = 20) 110.9 / 115.2, K = 10 equal, K = 5 111.0 / 108.4; profiles/r6_ab_c2.txt r6m)
+template <class T> inline bool lane_lists_possible(int K, bool three_subtiles = false)
 {
-    const long long min_k = g_sw.lane_min_k >= 0 ? g_sw.lane_min_k : 21;
+    // (fp64: every k_metrics -- a user sits on four lanes there and the lists' owner lane collects from all of them: C5's shape K = 5
+    // 73.4 against 74.8 ms, K = 10 73.6 / 76.4, K = 20 75.1 / 84.2; C2's shape in fp64 K = 10 4.50 / 5.22, K = 14 4.50 / 6.28)
+    const long long min_k = g_sw.lane_min_k >= 0 ? g_sw.lane_min_k : (three_subtiles ? 21 : (sizeof(T) == 8 ? 1 : 14));
     return !g_sw.ext_topk && K >= min_k && K + Prec<T>::lane_cap(K) <= COLLECT_MAX_ENTRIES;
 }
 // (the grid of the sweep is only known behind the plan: user blocks of the call, or a few rounds of 256 blocks when there are few)
 template <class T> inline long long lane_blocks_bound(long long m) { return (m + 4 * Prec<T>::GU - 1) / (4 * Prec<T>::GU) + 1024; }
 inline long long lane_budget_bytes(const Workspace &ws) { return free_plus_owned(ws, {"glists", "stream_scores", "sel_hi", "sel_lo"}) / 3; }
-template <class T> inline bool lane_lists_fit(const Workspace &ws, int K, long long m)
+template <class T> inline bool lane_lists_fit(const Workspace &ws, int K, long long m, bool three_subtiles)
 {
-    return lane_lists_possible<T>(K) && lane_list_bytes<T>(K, lane_blocks_bound<T>(m)) <= lane_budget_bytes(ws);
+    return lane_lists_possible<T>(K, three_subtiles) && lane_list_bytes<T>(K, lane_blocks_bound<T>(m)) <= lane_budget_bytes(ws);
 }
 
 // Dense train rows for the fp32 sweep when they are small (m * n / 8 bytes <= 1 GiB, e.g. 463 MB at BASELINE C2): with ~100
@@ -593,7 +599,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
     const long long stream_ld_max = ((long long)n + 191) / 192 * 192;             // row stride for either tile size (64 / 96 items)
     // k_metrics beyond the sweep's lists (append buffers + wave compaction reach 256): every user is streamed and
     // k_select_topk picks its top-K from the stored row -- any k_metrics <= n, at one score row of HBM per user
-    const bool want_lane = lane_lists_fit<T>(ws, K, c.eval_users >= 0 ? std::min<long long>(c.eval_users, m) : m);
+    const bool want_lane = lane_lists_fit<T>(ws, K, c.eval_users >= 0 ? std::min<long long>(c.eval_users, m) : m, P::max_nsub >= 3 && NG <= 8);
     const bool ext_topk = (!want_lane && K > 256) || g_sw.ext_topk;
     long long stream_cap = 0;
     if (want_auc || ext_topk) {

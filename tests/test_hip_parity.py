@@ -264,6 +264,8 @@ def test_list_schemes_agree(hip, oracle, env, dtype, monkeypatch):
     from recometrics_amd.synth import make_problem
     for key, val in env.items():
         monkeypatch.setenv(key, val)
+    if dtype == np.float64 and any(key in env for key in ("RM_DEBUG_NO_PENDING", "RM_DEBUG_HBM_LISTS", "RM_DEBUG_NSUB2")):
+        monkeypatch.setenv("RM_DEBUG_LANE_MIN_K", "1000000")      # (fp64 takes the lane buffers for every k_metrics since round 6: these are the lists' switches)
     pr = make_problem(150, 9000, 48, dtype, mean_c=60, seed=5)
     _check_against_oracle(hip, oracle, pr, 12, dtype=dtype)
 
@@ -1092,3 +1094,18 @@ def test_small_lane_buffers_never_run_into_the_next_waves(hip, oracle, dtype, K,
     for seed in (1234, 1235):
         pr = make_problem(1500, 300, 100 if dtype == np.float32 else 40, dtype, mean_c=50, seed=seed)
         _check_against_oracle(hip, oracle, pr, K, dtype=dtype)
+
+
+@pytest.mark.parametrize("m,n,k,K,mean_c", [
+    (96, 9000, 64, 12, 60),        # fp64 LDS lists + pending buffers
+    (80, 6000, 256, 30, 120),      # fp64 replace-the-minimum lists in HBM (too large for LDS) + pending buffers
+    (500, 3000, 128, 28, 90),      # fp64 depth split: shallow blocks with LDS lists beside deep ones with HBM lists
+    (70, 20000, 256, 50, 50),      # k_metrics = 50 on the HBM lists
+])
+def test_f64_lists_when_the_lane_buffers_are_off(hip, oracle, m, n, k, K, mean_c, monkeypatch):
+    """fp64 takes the lane buffers for every k_metrics since round 6; the replace-the-minimum lists (LDS, HBM, the depth split) remain
+    for lane buffers that do not fit the device's memory -- here with the lane buffers switched off"""
+    from recometrics_amd.synth import make_problem
+    monkeypatch.setenv("RM_DEBUG_LANE_MIN_K", "1000000")
+    pr = make_problem(m, n, k, np.float64, mean_c=mean_c, seed=m + n + 1)
+    _check_against_oracle(hip, oracle, pr, K, dtype=np.float64)
