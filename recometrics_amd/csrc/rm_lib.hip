@@ -99,7 +99,7 @@ inline long long debug_free_cap()
 // RM_HOST_TRACE: host-side time stamps from inside run() (the phases of one batch), picked up by the host entry's trace line
 struct RunTrace {
     std::mutex mu; std::vector<std::pair<const char *, double>> pts; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    void point(const char *what) { std::lock_guard<std::mutex> lk(mu); pts.emplace_back(what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
+    void point(const char *what) { std::lock_guard<std::mutex> lk(mu); if (pts.size() > 4096) pts.clear(); pts.emplace_back(what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
 };
 RunTrace g_run_trace;
 #define RM_TRACE_POINT(what) do { if (g_sw.host_trace) g_run_trace.point(what); } while (0)
