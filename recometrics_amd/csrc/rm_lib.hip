@@ -58,7 +58,7 @@ struct Switches {
     bool no_train_bits, no_spec, no_side, ext_topk, no_early_bits, no_test_mask, hbm_lists, nsub2, no_pending, no_pos_keys, no_pos_beside,
          no_seed, no_depth_split, rank_generic, no_fused_auc, no_defer_auc, noise_sequential, no_ext_bits, one_context, noise_per_batch,
          host_trace, no_noise_beside_last, no_pack_beside, no_pos_flat;
-    long long free_mb, stream_budget_mb, dense_always_mb, noise_budget_mb, lane_cap_min, lane_min_k, lane_cap_set;      // -1 = not set
+    long long free_mb, stream_budget_mb, dense_always_mb, noise_budget_mb, lane_cap_min, lane_min_k, lane_cap_set, sample_seed;      // -1 = not set
     double batch_users;                                                        // 0 = not set
     int ramp;                                                                  // 0 = not set
     std::string splits;
@@ -79,6 +79,7 @@ struct Switches {
         noise_budget_mb = num("RM_NOISE_BUDGET_MB");
         lane_min_k = num("RM_DEBUG_LANE_MIN_K");                // the smallest k_metrics that takes the lane buffers instead of LDS / HBM lists (A/B timing)
         lane_cap_set = num("RM_DEBUG_LANE_CAP");                // entries per lane buffer (A/B timing; rounded to 16, never below what a selection needs)
+        sample_seed = num("RM_DEBUG_SAMPLE_SEED");            // items of the sample that seeds the lane buffers' bounds: 0 = none, else forced to 64 / 256 / 1024 / 2048 / 4096 (A/B timing, tests)
         lane_cap_min = num("RM_DEBUG_LANE_CAP_MIN");          // the smallest lane buffers that work: a selection every few tiles (tests)
         const char *b = getenv("RM_BATCH_USERS"); batch_users = b ? atof(b) : 0.0;
         const char *r = getenv("RM_DEBUG_RAMP"); ramp = r ? atoi(r) : 0;
@@ -481,6 +482,50 @@ inline void set_spec(SweepArgs &sa)
 }
 inline void set_spec(Sweep64Args &sa) { sa.spec = (sa.check_nan || sa.noise_E || sa.ext_topk || g_sw.no_spec) ? 0 : 1; }
 inline void set_ext_bits(SweepArgs &sa, const unsigned *bits, int words) { sa.train_bits = bits; sa.train_words = words; }
+
+// Sample seeds for the lane buffers (k_seed_from_sample): how many items, and the two launches.  fp32 only (the fp64 shapes that take
+// the lane buffers have item axes a sample is a negligible part of, and their selections are not what bounds them).  Not when a
+// score may be non-finite (the NaN check wants every score looked at) and not under the tie noise (the sample is scored without it).
+template <class T> inline int sample_seed_items(const Workspace &ws, int K, int n, long long n_slots, bool off)
+{
+    if (sizeof(T) != 4 || off || g_sw.sample_seed == 0) return 0;
+    int S;
+    if (g_sw.sample_seed > 0) {          // forced (tests, A/B timing): the largest size at or below the value; 64 and 256 for small catalogues
+        S = 64;
+        for (int c : {256, 1024, 2048, 4096}) if (g_sw.sample_seed >= c) S = c;
+    } else {
+        // A sample of S items costs S / n of the sweep's matrix work and gives the K-th best of S as the bound.  Measured at BASELINE
+        // C2's shape (26,744 items; profiles/r6_ab_c2.txt): 1,024 items beat 2,048 up to k_metrics ~ 128, 2,048 beyond.
+        S = K <= 128 ? 1024 : (K <= 512 ? 2048 : 4096);
+        if ((long long)S * 8 > n || K * 2 > S) return 0;
+    }
+    if (S > n || K > S) return 0;
+    if ((long long)sizeof(float) * n_slots * S > free_plus_owned(ws, {"sample_scores"}) / 8) return 0;
+    return S;
+}
+inline void seed_from_sample(const SweepArgs &sa, Workspace &ws, int S, int NG, int n_slots, int n_ublocks, hipStream_t stream)
+{
+    typedef Prec<float> P;
+    float *sample = (float *)ws.get("sample_scores", sizeof(float) * (size_t)n_slots * (size_t)S);
+    SweepArgs sd = sa;
+    sd.n = S; sd.tiles_total = S / TILE_ITEMS; sd.K = 1; sd.n_splits = 1; sd.tail_ublocks = 0; sd.tail_splits = 1; sd.part_splits = 1;
+    sd.buffered_lists = 0; sd.ext_topk = 0; sd.lane_cap = 0; sd.lane_cnt = nullptr; sd.spec = 0; sd.dump = sample;
+    P::set_pending(sd, 0, 0);
+    P::set_sync(sd, (int)P::lds_b(NG));
+    dispatch_sweep(false, true, false, 2, NG, dim3((unsigned)n_ublocks), P::lds_b(NG) + SYNC_BYTES, stream, sd);
+    const dim3 grid((unsigned)cdiv(n_slots, 4)), block(256);
+#define RM_SEED_LAUNCH(NV) hipLaunchKernelGGL(k_seed_from_sample<NV>, grid, block, 0, stream, n_slots, sa.K, sample, sa.slot_user, sa.slot_chunk, sa.train_p, sa.train_i, sa.thr_shared)
+    switch (S) {
+    case 4096: RM_SEED_LAUNCH(64); break;
+    case 2048: RM_SEED_LAUNCH(32); break;
+    case 1024: RM_SEED_LAUNCH(16); break;
+    case 256: RM_SEED_LAUNCH(4); break;
+    default: RM_SEED_LAUNCH(1); break;
+    }
+#undef RM_SEED_LAUNCH
+    check_launch(hipGetLastError());
+}
+inline void seed_from_sample(const Sweep64Args &, Workspace &, int, int, int, int, hipStream_t) {}
 inline void set_ext_bits(Sweep64Args &, const unsigned *, int) {}
 
 // what the plan's validation kernels found wrong with the caller's CSR arrays -> the error the entry points see
@@ -1069,6 +1114,10 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
             HIP_CHECK(hipStreamWaitEvent(stream, cx.side_ev[4], 0));
             side_guard.pending--;
         }
+        // Sample seeds (k_seed_from_sample, rm_prep.hpp): the sweep's DUMP variant scores the first S items for every slot, a
+        // wavefront per slot takes the K-th best candidate of them, and the lane buffers start with a pass rate of K / S.
+        const int sample_S = lane_lists ? sample_seed_items<T>(ws, K, n, n_slots, check_nan || c.noise_E != nullptr) : 0;
+        if (sample_S > 0) seed_from_sample(sa, ws, sample_S, NG, n_slots, n_ublocks, stream);
         if (c.flag_snapshot) {
             HIP_CHECK(hipMemcpyAsync(c.flag_snapshot, c.noise_flag, sizeof(int) * (size_t)m, hipMemcpyDeviceToDevice, stream));
             HIP_CHECK(hipMemcpyAsync(c.flag_count_host, &plan->n_noise_flagged, sizeof(int), hipMemcpyDeviceToHost, stream));

@@ -625,6 +625,14 @@ void k_sweep(SweepArgs a)
         #pragma unroll
         for (int r = 0; r < 16; r++) v[r] = acc[r];
         if (DUMP) {
+            if ((n & 3) == 0) {                                 // a lane's four runs of four items, 16 bytes each (the sample seeds' launch)
+                #pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int item = sb + mfma32_row(4 * q, h);
+                    if (slot_ok && item < n) *(float4 *)(a.dump + (size_t)slot * n + item) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                }
+                return;
+            }
             #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int item = sb + mfma32_row(r, h);
