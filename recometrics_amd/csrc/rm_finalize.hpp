@@ -6,6 +6,7 @@
 // the CPU path uses.  ROC-AUC is formed in fp64 where the reference uses x87 long double (<= 1 ulp(fp64) apart).
 #pragma once
 #include "rm_device.hpp"
+#include <type_traits>
 
 namespace rm {
 
@@ -610,6 +611,7 @@ template <> struct CollectKey<double> { typedef unsigned long long T; };
 inline int collect_capw(int K, int lane_cap) { return K + lane_cap <= 1024 && 2 * K <= 1024 ? 1024 : 4096; }
 constexpr int COLLECT_MAX_ENTRIES = 4096;
 
+inline unsigned collect_grid(long long blocks) { return (unsigned)((blocks + 7) / 8 * 8); }
 template <class T, class S, class ThrT, int CAPW>
 __global__ __launch_bounds__(CAPW == 1024 ? 256 : 64) void k_collect_topk(FinalArgs<T, S> a, CollectGeom g, const char *glists, const int *lane_cnt, const ThrT *thr_shared)
 {
@@ -618,11 +620,20 @@ __global__ __launch_bounds__(CAPW == 1024 ? 256 : 64) void k_collect_topk(FinalA
     __shared__ KeyT kh_all[WPB * CAPW];
     __shared__ unsigned kl_all[WPB * CAPW];
     const int lane = threadIdx.x & 63, wv_in_blk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slot = blockIdx.x * WPB + wv_in_blk;
-    if (slot >= a.n_slots || a.slot_chunk[slot] != 0) return;
+    // Sixteen neighbouring slots sit on neighbouring lanes of the same sweep waves: their entries share 128-byte lines.  Consecutive
+    // block ids go round the eight XCDs, each with an L2 of its own -- in launch order a line was fetched over the fabric once per block
+    // that touches it.  So the blocks of ONE XCD (ids b, b + 8, ...) take consecutive slots: a line comes in once and its other users
+    // find it in that L2 (grid: a multiple of 8 blocks, collect_grid).
+    const int per_xcd = gridDim.x >> 3;
+    const int lblock = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int slot = lblock * WPB + wv_in_blk;
+    if (slot >= a.n_slots) return;
+    // (what a wavefront does per user is a chain of round trips to memory: the loads that depend on the slot alone go out together)
+    const int chunk = a.slot_chunk[slot], u = a.slot_user[slot];
+    const ThrT bound_raw = thr_shared[slot];
+    if (chunk != 0) return;
     KeyT *kh = kh_all + wv_in_blk * CAPW;
     unsigned *kl = kl_all + wv_in_blk * CAPW;
-    const int u = a.slot_user[slot];
     const int K = a.K;
     const int group = slot / g.gu, ul = slot % g.gu, gi = group % GROUPS_PER_BLOCK, blk_u = group / GROUPS_PER_BLOCK;
     const int nwaves = GROUPS_PER_BLOCK * g.nsub;
@@ -630,7 +641,7 @@ __global__ __launch_bounds__(CAPW == 1024 ? 256 : 64) void k_collect_topk(FinalA
     const int rel = blk_u - g.ublock0, n_ub1 = g.n_ublocks - g.tail_ublocks;
     const bool in_tail = rel < g.tail_ublocks;
     const int nsplit = in_tail ? g.tail_splits : g.n_splits;
-    const KeyT bound = (KeyT)thr_shared[slot];                      // (0 = none: below every key)
+    const KeyT bound = (KeyT)bound_raw;                             // (0 = none: below every key)
     int cur = 0;                                                    // entries in LDS (wave-uniform)
     auto wave_sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
     // SELECT, then sort: the K best of the entries [0, cur) packed to the front in their old order.  The K-th best key by a radix
@@ -638,12 +649,19 @@ __global__ __launch_bounds__(CAPW == 1024 ? 256 : 64) void k_collect_topk(FinalA
     // share a dozen leading bits), each a read, a compare and a ballot count per 64 entries -- then, only when more entries tie that
     // key than are wanted, the same descent over the item words of the ties.  (First version: a bitonic sort of EVERYTHING gathered,
     // 440 compare-exchanges per lane for 600 entries where this is ~25 passes of 10 reads and a 28-pass sort of the 128 kept.)
-    auto select_best = [&]() {
+    // (the keys in REGISTERS for the passes: CAPW / 64 per lane, read from LDS once -- a pass per bit that re-read them was a chain of
+    // LDS round trips, ~2,000 cycles per bit for 1,000 entries; the item words only when ties must be cut)
+    // (always inline: out of line the closure -- `cur`, the LDS pointers -- lives in scratch memory, and so does every use of it elsewhere)
+    auto select_best = [&]() __attribute__((always_inline)) {
         if (cur <= K) return;
         wave_sync();
-        const int rows = (cur + WAVE - 1) / WAVE;
+        constexpr int ROWS = CAPW / WAVE;
+        KeyT kr[ROWS];
+        #pragma unroll
+        for (int r = 0; r < ROWS; r++) { const int i = r * WAVE + lane; kr[r] = i < cur ? kh[i] : (KeyT)0; }
         KeyT all_and = ~(KeyT)0, all_or = 0;
-        for (int r = 0; r < rows; r++) { const int i = r * WAVE + lane; if (i < cur) { const KeyT x = kh[i]; all_and &= x; all_or |= x; } }
+        #pragma unroll
+        for (int r = 0; r < ROWS; r++) if (r * WAVE + lane < cur) { all_and &= kr[r]; all_or |= kr[r]; }
         #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { all_and &= __shfl_xor(all_and, d); all_or |= __shfl_xor(all_or, d); }
         const KeyT diff = all_and ^ all_or;
@@ -651,21 +669,24 @@ __global__ __launch_bounds__(CAPW == 1024 ? 256 : 64) void k_collect_topk(FinalA
         int top = BITS - 1;                                         // highest bit in which two keys differ
         while (top >= 0 && !((diff >> top) & 1)) top--;
         KeyT Tk = top >= 0 ? (all_and & ~(((KeyT)2 << top) - 1)) : all_and;      // the shared prefix
+        // (entries beyond `cur` hold key 0: below every candidate, which has a bit set)
         for (int bit = top; bit >= 0; bit--) {
             const KeyT cand = Tk | ((KeyT)1 << bit);
             int c = 0;
-            for (int r = 0; r < rows; r++) { const int i = r * WAVE + lane; c += __popcll(__ballot(i < cur && kh[i] >= cand)); }
+            #pragma unroll
+            for (int r = 0; r < ROWS; r++) c += __popcll(__ballot(kr[r] >= cand));
             if (c >= K) Tk = cand;
         }
         int n_gt = 0, n_eq = 0;
-        for (int r = 0; r < rows; r++) {
-            const int i = r * WAVE + lane;
-            const KeyT x = i < cur ? kh[i] : 0;
-            n_gt += __popcll(__ballot(i < cur && x > Tk)); n_eq += __popcll(__ballot(i < cur && x == Tk));
+        #pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const bool in = r * WAVE + lane < cur;
+            n_gt += __popcll(__ballot(in && kr[r] > Tk)); n_eq += __popcll(__ballot(in && kr[r] == Tk));
         }
         const int need = K - n_gt;                                  // >= 1 of the n_eq ties: those with the largest item words
         unsigned Lk = 0u;
         if (n_eq > need) {
+            const int rows = (cur + WAVE - 1) / WAVE;
             for (int bit = 31; bit >= 0; bit--) {
                 const unsigned cand = Lk | (1u << bit);
                 int c = 0;
@@ -674,9 +695,11 @@ __global__ __launch_bounds__(CAPW == 1024 ? 256 : 64) void k_collect_topk(FinalA
             }
         }
         int out = 0;
-        for (int r = 0; r < rows; r++) {
+        #pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            if (r * WAVE >= cur) break;
             const int i = r * WAVE + lane;
-            const KeyT x = i < cur ? kh[i] : 0; const unsigned y = i < cur ? kl[i] : 0u;
+            const KeyT x = kr[r]; const unsigned y = i < cur ? kl[i] : 0u;
             const bool keep = i < cur && (x > Tk || (x == Tk && y >= Lk));
             const unsigned long long m = __ballot(keep);
             if (keep) { const int at = out + __popcll(m & ((1ull << lane) - 1ull)); kh[at] = x; kl[at] = y; }      // (at <= i: a slot already read)
@@ -685,29 +708,59 @@ __global__ __launch_bounds__(CAPW == 1024 ? 256 : 64) void k_collect_topk(FinalA
         cur = out;
         wave_sync();
     };
-    // sort the entries [0, cur), cur <= K, descending (bitonic network over the next power of two, padded with keys below every real one)
-    auto sort_kept = [&]() {
-        int P = 2;
-        while (P < cur) P <<= 1;
-        for (int i = cur + lane; i < P; i += WAVE) { kh[i] = 0; kl[i] = 0u; }
-        wave_sync();
+    // sort the entries [0, cur), cur <= K, descending: a bitonic network over PR * 64 >= cur elements IN REGISTERS (padded with keys below
+    // every real one) -- element r * 64 + lane in register r: a compare-exchange at distance >= 64 is between two registers of a lane,
+    // below 64 with the lane `lane ^ j` (a shuffle each for the key and the item word).  (First version: in LDS, four reads, four
+    // writes and a fence per stage and pair: 36 stages of round trips for 256 entries.)
+    auto sort_regs = [&](auto pr_tag) __attribute__((always_inline)) {
+        constexpr int PR = decltype(pr_tag)::value, P = PR * WAVE;
+        KeyT h[PR]; unsigned l[PR];
+        #pragma unroll
+        for (int r = 0; r < PR; r++) { const int i = r * WAVE + lane; const bool in = i < cur; h[r] = in ? kh[i] : (KeyT)0; l[r] = in ? kl[i] : 0u; }
+        #pragma unroll
         for (int k2 = 2; k2 <= P; k2 <<= 1) {
+            #pragma unroll
             for (int j = k2 >> 1; j > 0; j >>= 1) {
-                for (int pr = lane; pr < (P >> 1); pr += WAVE) {
-                    const int i0 = ((pr & ~(j - 1)) << 1) | (pr & (j - 1)), i1 = i0 | j;
-                    const KeyT h0 = kh[i0], h1 = kh[i1];
-                    const unsigned l0 = kl[i0], l1 = kl[i1];
-                    const bool lt = h0 < h1 || (h0 == h1 && l0 < l1);         // entry 0 is worse than entry 1
-                    const bool desc = (i0 & k2) == 0;
-                    if (desc ? lt : (!lt && !(h0 == h1 && l0 == l1))) { kh[i0] = h1; kh[i1] = h0; kl[i0] = l1; kl[i1] = l0; }
+                if (j >= WAVE) {
+                    const int jr = j / WAVE;
+                    #pragma unroll
+                    for (int r = 0; r < PR; r++) {
+                        if (r & jr) continue;
+                        const bool desc = (r & (k2 / WAVE)) == 0;
+                        const bool lt = h[r] < h[r | jr] || (h[r] == h[r | jr] && l[r] < l[r | jr]);
+                        if (desc ? lt : !lt) { const KeyT th = h[r]; h[r] = h[r | jr]; h[r | jr] = th; const unsigned tl = l[r]; l[r] = l[r | jr]; l[r | jr] = tl; }
+                    }
+                } else {
+                    #pragma unroll
+                    for (int r = 0; r < PR; r++) {
+                        const KeyT oh = __shfl_xor(h[r], j); const unsigned ol = __shfl_xor(l[r], j);
+                        const bool take_max = ((lane & j) == 0) == ((((r * WAVE) | lane) & k2) == 0);
+                        const bool other_better = oh > h[r] || (oh == h[r] && ol > l[r]);
+                        if (take_max ? other_better : !other_better) { h[r] = oh; l[r] = ol; }
+                    }
                 }
-                wave_sync();
             }
         }
+        #pragma unroll
+        for (int r = 0; r < PR; r++) { kh[r * WAVE + lane] = h[r]; kl[r * WAVE + lane] = l[r]; }
+        wave_sync();
     };
-    auto reduce = [&]() { select_best(); };
+    auto sort_kept = [&]() __attribute__((always_inline)) {
+        wave_sync();
+        if (CAPW == 1024) {                                    // (cur <= K <= 512 here: collect_capw)
+            if (cur <= 64) sort_regs(std::integral_constant<int, 1>{});
+            else if (cur <= 128) sort_regs(std::integral_constant<int, 2>{});
+            else if (cur <= 256) sort_regs(std::integral_constant<int, 4>{});
+            else sort_regs(std::integral_constant<int, 8>{});
+        } else {
+            if (cur <= 512) sort_regs(std::integral_constant<int, 8>{});
+            else if (cur <= 1024) sort_regs(std::integral_constant<int, 16>{});
+            else sort_regs(std::integral_constant<int, 32>{});
+        }
+    };
+    auto reduce = [&]() __attribute__((always_inline)) { select_best(); };
     // one source: c entries, entry i fetched by `get(i, key, low)` (false: not a candidate)
-    auto gather = [&](int c, auto get) {
+    auto gather = [&](int c, auto get) __attribute__((always_inline)) {
         for (int i0 = 0; i0 < c; i0 += WAVE) {
             if (cur + WAVE > CAPW) reduce();
             KeyT key = 0; unsigned low = 0u;
@@ -717,29 +770,37 @@ __global__ __launch_bounds__(CAPW == 1024 ? 256 : 64) void k_collect_topk(FinalA
             cur += __popcll(m);
         }
     };
-    for (int sp = 0; sp < nsplit; sp++) {
-        const int bidx = in_tail ? n_ub1 * g.n_splits + sp * g.tail_ublocks + (g.tail_ublocks - 1 - rel)
-                                 : sp * n_ub1 + (g.n_ublocks - 1 - rel);
-        for (int sub = 0; sub < g.nsub; sub++) {
-            const size_t wv = (size_t)bidx * nwaves + (size_t)(sub * GROUPS_PER_BLOCK + gi);
-            const char *wbase = glists + wv * ((size_t)g.lane_cap * WAVE * (sizeof(S) + 4));
-            // (rm_list.hpp LaneSel: fp32 (score, item) pairs; fp64 the wave's scores, then its item ids)
-            constexpr bool PAIRS = sizeof(S) == 4;
-            const S *wsc = (const S *)wbase;
-            const int *wit = PAIRS ? (const int *)wbase + 1 : (const int *)(wbase + (size_t)g.lane_cap * WAVE * sizeof(S));
-            constexpr int ES = PAIRS ? 2 : 1;                          // words of S / int from one lane's entry to the next lane's
-            for (int l = 0; l < g.lpu; l++) {
+    // The sources: (item range, sub-tile wave, lane of the user) -- FOUR at a time, the same chunk of each in one batch of loads (a
+    // user's entries sit 512 bytes apart: every load is a round trip to L2 or beyond, and source after source a wavefront had one
+    // in flight).  fp32: score and item in one 8-byte load; fp64: the two arrays side by side.
+    constexpr int G = 4;
+    constexpr bool PAIRS = sizeof(S) == 4;                          // (rm_list.hpp LaneSel: fp32 (score, item) pairs; fp64 the wave's scores, then its item ids)
+    const int per_range = g.nsub * g.lpu, nsrc = nsplit * per_range;
+    const char *bs[G]; const int *bi[G]; int cn[G]; int cmax = 0;
+    auto describe = [&](int s0) __attribute__((always_inline)) {
+        cmax = 0;
+        #pragma unroll
+        for (int j = 0; j < G; j++) {
+            const int src = s0 + j;
+            cn[j] = 0; bs[j] = glists; bi[j] = (const int *)glists;
+            if (src < nsrc) {
+                const int sp = src / per_range, rem = src % per_range, sub = rem / g.lpu, l = rem % g.lpu;
+                const int bidx = in_tail ? n_ub1 * g.n_splits + sp * g.tail_ublocks + (g.tail_ublocks - 1 - rel)
+                                         : sp * n_ub1 + (g.n_ublocks - 1 - rel);
+                const size_t wv = (size_t)bidx * nwaves + (size_t)(sub * GROUPS_PER_BLOCK + gi);
                 const int src_lane = ul + l * g.gu;
-                const int c = lane_cnt[wv * WAVE + src_lane];
-                gather(c, [&](int i, KeyT &key, unsigned &low) {
-                    key = ord_key(wsc[((size_t)i * WAVE + src_lane) * ES]);
-                    if (key < bound) return false;
-                    low = ~(unsigned)wit[((size_t)i * WAVE + src_lane) * ES];
-                    return true;
-                });
+                const char *wbase = glists + wv * ((size_t)g.lane_cap * WAVE * (sizeof(S) + 4));
+                cn[j] = lane_cnt[wv * WAVE + src_lane];
+                bs[j] = wbase + (size_t)src_lane * (PAIRS ? 8 : sizeof(S));
+                bi[j] = (const int *)(wbase + (size_t)g.lane_cap * WAVE * sizeof(S)) + src_lane;
             }
         }
-    }
+        #pragma unroll
+        for (int j = 0; j < G; j++) cmax = cn[j] > cmax ? cn[j] : cmax;
+    };
+#ifndef RM_ABL_COLLECT_NO_GATHER
+    describe(0);                                                    // (the first sources' counts are on their way while the user's own test items come in)
+#endif
     if (g.extra_part >= 0) {
         const Entry<S> *px = a.pl + ((size_t)slot * a.n_part + g.extra_part) * K;
         gather(K, [&](int i, KeyT &key, unsigned &low) {
@@ -748,6 +809,41 @@ __global__ __launch_bounds__(CAPW == 1024 ? 256 : 64) void k_collect_topk(FinalA
             key = ord_key(e.s); low = ~(unsigned)e.idx;
             return true;
         });
+    }
+#ifdef RM_ABL_COLLECT_NO_GATHER
+    for (int s0 = 0; s0 < 0; s0 += G) {
+#else
+    for (int s0 = 0; s0 < nsrc; s0 += G) {
+#endif
+        if (s0) describe(s0);
+        // (measured and dropped: two chunks of each source per batch, eight loads in flight -- the room they need in LDS brings the
+        // selection in the middle of the gather forward, 1.9 -> 2.6 ms at BASELINE C2's shape with k_metrics = 100)
+        for (int i0 = 0; i0 < cmax; i0 += WAVE) {
+            if (cur + G * WAVE > CAPW) reduce();
+            const int i = i0 + lane;
+            S sc[G]; int it[G];
+            #pragma unroll
+            for (int j = 0; j < G; j++) {
+                sc[j] = (S)0; it[j] = 0;
+                if (i < cn[j]) {
+                    if (PAIRS) {
+                        const uint2 e = *(const uint2 *)(bs[j] + (size_t)i * (WAVE * 8));
+                        sc[j] = (S)__uint_as_float(e.x); it[j] = (int)e.y;
+                    } else {
+                        sc[j] = *(const S *)(bs[j] + (size_t)i * (WAVE * sizeof(S)));
+                        it[j] = bi[j][(size_t)i * WAVE];
+                    }
+                }
+            }
+            #pragma unroll
+            for (int j = 0; j < G; j++) {
+                const KeyT key = ord_key(sc[j]);
+                const bool take = i < cn[j] && key >= bound;
+                const unsigned long long m = __ballot(take);
+                if (take) { const int at = cur + __popcll(m & ((1ull << lane) - 1ull)); kh[at] = key; kl[at] = ~(unsigned)it[j]; }
+                cur += __popcll(m);
+            }
+        }
     }
     wave_sync();
 #ifndef RM_ABL_COLLECT_GATHER_ONLY                             // (timing only, scratch/build_abl.py: what the gather alone costs)

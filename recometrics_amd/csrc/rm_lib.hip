@@ -1220,9 +1220,9 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         typedef typename std::remove_pointer<decltype(typename P::Args{}.thr_shared)>::type ThrT;
         fa.collected = 1;
         if (collect_capw(K, collect.g.lane_cap) == 1024)
-            hipLaunchKernelGGL((k_collect_topk<T, T, ThrT, 1024>), dim3(cdiv(n_slots, 4)), dim3(256), 0, stream, fa, collect.g, collect.glists, collect.lane_cnt, (const ThrT *)collect.thr);
+            hipLaunchKernelGGL((k_collect_topk<T, T, ThrT, 1024>), dim3(collect_grid(cdiv(n_slots, 4))), dim3(256), 0, stream, fa, collect.g, collect.glists, collect.lane_cnt, (const ThrT *)collect.thr);
         else
-            hipLaunchKernelGGL((k_collect_topk<T, T, ThrT, 4096>), dim3(n_slots), dim3(64), 0, stream, fa, collect.g, collect.glists, collect.lane_cnt, (const ThrT *)collect.thr);
+            hipLaunchKernelGGL((k_collect_topk<T, T, ThrT, 4096>), dim3(collect_grid(n_slots)), dim3(64), 0, stream, fa, collect.g, collect.glists, collect.lane_cnt, (const ThrT *)collect.thr);
     }
     if (n_slots > 0 && ext_topk) {
         int sel_ld = 2;
