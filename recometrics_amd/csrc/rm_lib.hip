@@ -58,7 +58,7 @@ struct Switches {
     bool no_train_bits, no_spec, no_side, ext_topk, no_early_bits, no_test_mask, hbm_lists, nsub2, no_pending, no_pos_keys, no_pos_beside,
          no_seed, no_depth_split, rank_generic, no_fused_auc, no_defer_auc, noise_sequential, no_ext_bits, one_context, noise_per_batch,
          host_trace, no_noise_beside_last, no_pack_beside, no_pos_flat;
-    long long free_mb, stream_budget_mb, dense_always_mb, noise_budget_mb, lane_cap_min, lane_min_k, lane_cap_set, sample_seed;      // -1 = not set
+    long long free_mb, stream_budget_mb, dense_always_mb, noise_budget_mb, lane_cap_min, lane_min_k, lane_cap_set, sample_seed, split_slack;      // -1 = not set
     double batch_users;                                                        // 0 = not set
     int ramp;                                                                  // 0 = not set
     std::string splits;
@@ -80,6 +80,7 @@ struct Switches {
         lane_min_k = num("RM_DEBUG_LANE_MIN_K");                // the smallest k_metrics that takes the lane buffers instead of LDS / HBM lists (A/B timing)
         lane_cap_set = num("RM_DEBUG_LANE_CAP");                // entries per lane buffer (A/B timing; rounded to 16, never below what a selection needs)
         sample_seed = num("RM_DEBUG_SAMPLE_SEED");            // items of the sample that seeds the lane buffers' bounds: 0 = none, else forced to 64 / 256 / 1024 / 2048 / 4096 (A/B timing, tests)
+        split_slack = num("RM_DEBUG_SPLIT_SLACK");            // percent of a round charged to the part that ends the sweep's grid (A/B timing)
         lane_cap_min = num("RM_DEBUG_LANE_CAP_MIN");          // the smallest lane buffers that work: a selection every few tiles (tests)
         const char *b = getenv("RM_BATCH_USERS"); batch_users = b ? atof(b) : 0.0;
         const char *r = getenv("RM_DEBUG_RAMP"); ramp = r ? atoi(r) : 0;
@@ -495,9 +496,10 @@ template <class T> inline int sample_seed_items(const Workspace &ws, int K, int 
         for (int c : {256, 1024, 2048, 4096}) if (g_sw.sample_seed >= c) S = c;
     } else {
         // A sample of S items costs S / n of the sweep's matrix work and gives the K-th best of S as the bound.  Measured at BASELINE
-        // C2's shape (26,744 items; profiles/r6_ab_c2.txt): 1,024 items beat 2,048 up to k_metrics ~ 128, 2,048 beyond.
-        S = K <= 128 ? 1024 : (K <= 512 ? 2048 : 4096);
-        if ((long long)S * 8 > n || K * 2 > S) return 0;
+        // C2's shape (26,744 items; profiles/r6_ab_c2.txt): 1,024 items beat 2,048 up to k_metrics ~ 128, 2,048 beyond, 4,096 from ~ 400.
+        // (k_metrics = 500: sweep 22.5 ms without, 13.9 with 2,048, 10.9 with 4,096 in front of which the sample costs 1.9 ms more; 1,000: 36.8 / 22.8 / 16.0)
+        S = K <= 128 ? 1024 : (K <= 384 ? 2048 : 4096);
+        if ((long long)S * 6 > n || K * 2 > S) return 0;
     }
     if (S > n || K > S) return 0;
     if ((long long)sizeof(float) * n_slots * S > free_plus_owned(ws, {"sample_scores"}) / 8) return 0;
@@ -873,7 +875,10 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         const int max_tail = max_splits;
         const double fixed = 13.0 + 0.004 * std::max(0.25, K / 10.0) * tiles_total;
         auto block = [&](int sct) { return (double)tiles_total / sct + fixed; };
-        auto last = [&](double rounds) { return std::max(std::ceil(rounds - 1e-9), rounds + 0.2); };
+        // (0.2 of a round with the lane buffers, whose blocks differ by their selections; 0.1 with the lists: round 6, scratch/r6_slack.sh --
+        // tutorial shape 2.57 -> 2.54 ms, 20,000 users of C2 1.14 -> 1.11, north-star shape 77.3 -> 77.2; C4 / C5 lose 5 % / 1 % below 0.2)
+        const double slack = g_sw.split_slack >= 0 ? g_sw.split_slack / 100.0 : (want_lane ? 0.2 : 0.1);
+        auto last = [&](double rounds) { return std::max(std::ceil(rounds - 1e-9), rounds + slack); };
         double best = 1e300;
         for (int sct = 1; sct <= max_splits; sct++) {
             const double t1 = last((double)n_ublocks * sct / n_cu) * block(sct);
