@@ -484,12 +484,11 @@ inline void set_spec(SweepArgs &sa)
 inline void set_spec(Sweep64Args &sa) { sa.spec = (sa.check_nan || sa.noise_E || sa.ext_topk || g_sw.no_spec) ? 0 : 1; }
 inline void set_ext_bits(SweepArgs &sa, const unsigned *bits, int words) { sa.train_bits = bits; sa.train_words = words; }
 
-// Sample seeds for the lane buffers (k_seed_from_sample): how many items, and the two launches.  fp32 only (the fp64 shapes that take
-// the lane buffers have item axes a sample is a negligible part of, and their selections are not what bounds them).  Not when a
+// Sample seeds for the lane buffers (k_seed_from_sample): how many items, and the two launches.  Not when a
 // score may be non-finite (the NaN check wants every score looked at) and not under the tie noise (the sample is scored without it).
 template <class T> inline int sample_seed_items(const Workspace &ws, int K, int n, long long n_slots, bool off)
 {
-    if (sizeof(T) != 4 || off || g_sw.sample_seed == 0) return 0;
+    if (off || g_sw.sample_seed == 0) return 0;
     int S;
     if (g_sw.sample_seed > 0) {          // forced (tests, A/B timing): the largest size at or below the value; 64 and 256 for small catalogues
         S = 64;
@@ -500,23 +499,28 @@ template <class T> inline int sample_seed_items(const Workspace &ws, int K, int 
         // (k_metrics = 500: sweep 22.5 ms without, 13.9 with 2,048, 10.9 with 4,096 in front of which the sample costs 1.9 ms more; 1,000: 36.8 / 22.8 / 16.0)
         S = K <= 128 ? 1024 : (K <= 384 ? 2048 : 4096);
         if ((long long)S * 6 > n || K * 2 > S) return 0;
+        // (fp64 takes the lane buffers from k_metrics = 1: at C2's shape in fp64 the sample pays from ~ 16 -- step 19.6 -> 19.0 ms at 20,
+        // 25.9 -> 22.2 at 100, 34.8 -> 30.7 at 256; even at 10)
+        if (sizeof(T) == 8 && K < 16) return 0;
     }
     if (S > n || K > S) return 0;
-    if ((long long)sizeof(float) * n_slots * S > free_plus_owned(ws, {"sample_scores"}) / 8) return 0;
+    if ((long long)sizeof(T) * n_slots * S > free_plus_owned(ws, {"sample_scores"}) / 8) return 0;
     return S;
 }
-inline void seed_from_sample(const SweepArgs &sa, Workspace &ws, int S, int NG, int n_slots, int n_ublocks, hipStream_t stream)
+template <class T, class Args>
+inline void seed_from_sample(const Args &sa, Workspace &ws, int S, int NG, int n_slots, int n_ublocks, hipStream_t stream)
 {
-    typedef Prec<float> P;
-    float *sample = (float *)ws.get("sample_scores", sizeof(float) * (size_t)n_slots * (size_t)S);
-    SweepArgs sd = sa;
+    typedef Prec<T> P;
+    typedef typename std::remove_pointer<decltype(Args{}.thr_shared)>::type ThrT;
+    T *sample = (T *)ws.get("sample_scores", sizeof(T) * (size_t)n_slots * (size_t)S);
+    Args sd = sa;
     sd.n = S; sd.tiles_total = S / TILE_ITEMS; sd.K = 1; sd.n_splits = 1; sd.tail_ublocks = 0; sd.tail_splits = 1; sd.part_splits = 1;
     sd.buffered_lists = 0; sd.ext_topk = 0; sd.lane_cap = 0; sd.lane_cnt = nullptr; sd.spec = 0; sd.dump = sample;
     P::set_pending(sd, 0, 0);
     P::set_sync(sd, (int)P::lds_b(NG));
     dispatch_sweep(false, true, false, 2, NG, dim3((unsigned)n_ublocks), P::lds_b(NG) + SYNC_BYTES, stream, sd);
     const dim3 grid((unsigned)cdiv(n_slots, 4)), block(256);
-#define RM_SEED_LAUNCH(NV) hipLaunchKernelGGL(k_seed_from_sample<NV>, grid, block, 0, stream, n_slots, sa.K, sample, sa.slot_user, sa.slot_chunk, sa.train_p, sa.train_i, sa.thr_shared)
+#define RM_SEED_LAUNCH(NV) hipLaunchKernelGGL((k_seed_from_sample<T, ThrT, NV>), grid, block, 0, stream, n_slots, sa.K, (const T *)sample, sa.slot_user, sa.slot_chunk, sa.train_p, sa.train_i, sa.thr_shared)
     switch (S) {
     case 4096: RM_SEED_LAUNCH(64); break;
     case 2048: RM_SEED_LAUNCH(32); break;
@@ -527,7 +531,6 @@ inline void seed_from_sample(const SweepArgs &sa, Workspace &ws, int S, int NG, 
 #undef RM_SEED_LAUNCH
     check_launch(hipGetLastError());
 }
-inline void seed_from_sample(const Sweep64Args &, Workspace &, int, int, int, int, hipStream_t) {}
 inline void set_ext_bits(Sweep64Args &, const unsigned *, int) {}
 
 // what the plan's validation kernels found wrong with the caller's CSR arrays -> the error the entry points see
@@ -1122,7 +1125,7 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         // Sample seeds (k_seed_from_sample, rm_prep.hpp): the sweep's DUMP variant scores the first S items for every slot, a
         // wavefront per slot takes the K-th best candidate of them, and the lane buffers start with a pass rate of K / S.
         const int sample_S = lane_lists ? sample_seed_items<T>(ws, K, n, n_slots, check_nan || c.noise_E != nullptr) : 0;
-        if (sample_S > 0) seed_from_sample(sa, ws, sample_S, NG, n_slots, n_ublocks, stream);
+        if (sample_S > 0) seed_from_sample<T>(sa, ws, sample_S, NG, n_slots, n_ublocks, stream);
         if (c.flag_snapshot) {
             HIP_CHECK(hipMemcpyAsync(c.flag_snapshot, c.noise_flag, sizeof(int) * (size_t)m, hipMemcpyDeviceToDevice, stream));
             HIP_CHECK(hipMemcpyAsync(c.flag_count_host, &plan->n_noise_flagged, sizeof(int), hipMemcpyDeviceToHost, stream));

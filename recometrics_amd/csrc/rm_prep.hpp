@@ -476,7 +476,7 @@ __global__ void k_seed_thresholds(int n_slots, int stream_slot0, int K, int gu, 
     thr_shared[slot] = seed_of_slot<T, KeyT>(slot, stream_slot0, K, gu, slot_user, slot_chunk, user_nslots, flags, test_p, grow, pos_score, spos_score);
 }
 
-// SAMPLE SEEDS (fp32 lane buffers, short item axes).  A list whose bound starts at -inf appends every score of its first tiles, and its
+// SAMPLE SEEDS (lane buffers, short item axes).  A list whose bound starts at -inf appends every score of its first tiles, and its
 // first selections re-read all of that: at BASELINE C2's shape with k_metrics = 100 the selections were 29 % of the sweep's wave
 // cycles (47 % at 256; profiles/r6_ab_c2.txt).  ANY K candidates of a user bound its K-th best score from below, so the host has the
 // sweep's own kernel score the first `S` items of the catalogue for every slot (its DUMP variant: same packed operands, same
@@ -485,44 +485,46 @@ __global__ void k_seed_thresholds(int n_slots, int stream_slot0, int K, int gu, 
 // row's prefix below S) by a radix descent over the ordered keys -- 32 x NV ballots -- and raises the slot's shared bound to it.
 // The sweep then starts with a pass rate of K / S instead of 1.  (k_seed_thresholds' bounds come from the positives alone: users
 // with fewer than K of them get none.)
-template <int NV>
-__global__ __launch_bounds__(256) void k_seed_from_sample(int n_slots, int K, const float *sample, const int *slot_user, const int *slot_chunk,
-                                                          const int *train_p, const int *train_i, unsigned *thr_shared)
+template <class S, class KeyT, int NV>
+__global__ __launch_bounds__(256) void k_seed_from_sample(int n_slots, int K, const S *sample, const int *slot_user, const int *slot_chunk,
+                                                          const int *train_p, const int *train_i, KeyT *thr_shared)
 {
-    constexpr int S = NV * WAVE;
-    __shared__ unsigned masked[4][S / 32];
+    constexpr int SN = NV * WAVE;
+    __shared__ unsigned masked[4][SN / 32];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int slot = blockIdx.x * 4 + wv;
     if (slot >= n_slots || slot_chunk[slot] != 0) return;
     const int u = slot_user[slot];
     if (u < 0) return;
-    unsigned key[NV];
-    const float *row = sample + (size_t)slot * S;
+    KeyT key[NV];
+    const S *row = sample + (size_t)slot * SN;
     #pragma unroll
-    for (int j = 0; j < NV; j++) { const float x = row[j * WAVE + lane]; key[j] = x == x ? ord_key(x) : 0u; }
-    for (int w = lane; w < S / 32; w += WAVE) masked[wv][w] = 0u;
+    for (int j = 0; j < NV; j++) { const S x = row[j * WAVE + lane]; key[j] = x == x ? (KeyT)ord_key(x) : (KeyT)0; }
+    for (int w = lane; w < SN / 32; w += WAVE) masked[wv][w] = 0u;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
     const int tr0 = train_p[u], tr1 = train_p[u + 1];
-    for (int i0 = tr0; i0 < tr1; i0 += WAVE) {                           // the sorted row's prefix of items below S
-        const int t = i0 + lane < tr1 ? train_i[i0 + lane] : S;
-        if (t >= 0 && t < S) atomicOr(&masked[wv][t >> 5], 1u << (t & 31));
-        if (__ballot(t >= S)) break;
+    for (int i0 = tr0; i0 < tr1; i0 += WAVE) {                           // the sorted row's prefix of items below the sample's end
+        const int t = i0 + lane < tr1 ? train_i[i0 + lane] : SN;
+        if (t >= 0 && t < SN) atomicOr(&masked[wv][t >> 5], 1u << (t & 31));
+        if (__ballot(t >= SN)) break;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
     #pragma unroll
-    for (int j = 0; j < NV; j++) { const int it = j * WAVE + lane; if ((masked[wv][it >> 5] >> (it & 31)) & 1u) key[j] = 0u; }
+    for (int j = 0; j < NV; j++) { const int it = j * WAVE + lane; if ((masked[wv][it >> 5] >> (it & 31)) & 1u) key[j] = 0; }
     // the largest key with at least K keys at or above it (key 0: masked, never counted -- ord_key of a number is never 0)
-    // (SEED_BITS of the key: the bound rounded down to a float with 8 mantissa bits is a bound all the same, 0.4 % further down)
-    constexpr int SEED_BITS = 17;
-    unsigned best = 0u;
-    for (int bit = 31; bit > 31 - SEED_BITS; bit--) {
-        const unsigned probe = best | (1u << bit);
+    // (SEED_BITS of the key -- sign, exponent, 8 bits of the mantissa: the bound rounded down is a bound all the same, 0.4 % further down)
+    constexpr int BITS = (int)sizeof(KeyT) * 8, SEED_BITS = sizeof(S) == 4 ? 17 : 20;
+    KeyT best = 0;
+    for (int bit = BITS - 1; bit > BITS - 1 - SEED_BITS; bit--) {
+        const KeyT probe = best | ((KeyT)1 << bit);
         int cnt = 0;
         #pragma unroll
         for (int j = 0; j < NV; j++) cnt += __popcll(__ballot(key[j] >= probe));
         if (cnt >= K) best = probe;
     }
-    if (best > 0x007fffffu && lane == 0) atomicMax(thr_shared + slot, best);     // (keys at or below -inf's: no bound; below it they are NaNs)
+    // (keys at or below -inf's: no bound; below it they are NaNs)
+    const KeyT ninf_key = sizeof(S) == 4 ? (KeyT)0x007fffffu : (KeyT)0x000fffffffffffffull;
+    if (best > ninf_key && lane == 0) atomicMax(thr_shared + slot, best);
 }
 
 // the tables of sorted positives start as +inf everywhere, their rank histograms as zero: one launch for both arrays

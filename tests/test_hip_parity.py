@@ -1050,7 +1050,8 @@ def test_lane_buffers_and_selections(hip, oracle, dtype, K, env, monkeypatch):
 
 @pytest.mark.parametrize("env", [{}, {"RM_DEBUG_NO_TRAIN_BITS": "1"}, {"RM_DEBUG_SPLITS": "3,2,5", "RM_DEBUG_LANE_CAP_MIN": "1"}, {"RM_DEBUG_NO_SEED": "1"}])
 @pytest.mark.parametrize("sample,K,mean_c", [(64, 21, 20), (64, 60, 300), (256, 33, 70), (256, 200, 70), (1024, 100, 70), (1024, 500, 900), (2048, 256, 70)])
-def test_sample_seeds_of_the_lane_buffers(hip, oracle, sample, K, mean_c, env, monkeypatch):
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_sample_seeds_of_the_lane_buffers(hip, oracle, sample, K, mean_c, env, dtype, monkeypatch):
     """the lane buffers' bounds start at the K-th best candidate of the first `sample` items (k_seed_from_sample over the sweep's own
     scores of them): forced at every sample size, with K close to and beyond what the sample holds once the train items are out
     (no seed then), with the train items masked by the dense rows and by the kernel's own walk of the sparse rows"""
@@ -1059,8 +1060,8 @@ def test_sample_seeds_of_the_lane_buffers(hip, oracle, sample, K, mean_c, env, m
     monkeypatch.setenv("RM_DEBUG_LANE_MIN_K", "1")
     for key, val in env.items():
         monkeypatch.setenv(key, val)
-    pr = make_problem(150, 6000, 40, np.float32, mean_c=mean_c, seed=4000 + sample + K)
-    _check_against_oracle(hip, oracle, pr, K, dtype=np.float32)
+    pr = make_problem(150, 6000, 40 if dtype == np.float32 else 24, dtype, mean_c=mean_c, seed=4000 + sample + K)
+    _check_against_oracle(hip, oracle, pr, K, dtype=dtype)
 
 
 @pytest.mark.parametrize("env", [{}, {"RM_DEBUG_LANE_CAP_MIN": "1"}])
