@@ -608,15 +608,17 @@ struct CollectGeom {
 template <class S> struct CollectKey;
 template <> struct CollectKey<float> { typedef unsigned T; };
 template <> struct CollectKey<double> { typedef unsigned long long T; };
-inline int collect_capw(int K, int lane_cap) { return K + lane_cap <= 1024 && 2 * K <= 1024 ? 1024 : 4096; }
+// (512 entries per wavefront up to K = 128: 16 KB of LDS per block of four users, and the CU holds its 32 wavefronts -- what a wavefront does per
+// user is a chain of round trips to memory, more of them in flight is what helps: 1.43 -> 1.04 ms at BASELINE C2's shape with K = 21, 1.78 -> 1.43 with 100)
+inline int collect_capw(int K, int lane_cap) { return K <= 128 ? 512 : (K + lane_cap <= 1024 && 2 * K <= 1024 ? 1024 : 4096); }
 constexpr int COLLECT_MAX_ENTRIES = 4096;
 
 inline unsigned collect_grid(long long blocks) { return (unsigned)((blocks + 7) / 8 * 8); }
 template <class T, class S, class ThrT, int CAPW>
-__global__ __launch_bounds__(CAPW == 1024 ? 256 : 64) void k_collect_topk(FinalArgs<T, S> a, CollectGeom g, const char *glists, const int *lane_cnt, const ThrT *thr_shared)
+__global__ __launch_bounds__(CAPW <= 1024 ? 256 : 64) void k_collect_topk(FinalArgs<T, S> a, CollectGeom g, const char *glists, const int *lane_cnt, const ThrT *thr_shared)
 {
     typedef typename CollectKey<S>::T KeyT;
-    constexpr int WPB = CAPW == 1024 ? 4 : 1;                      // wavefronts (users) per block
+    constexpr int WPB = CAPW <= 1024 ? 4 : 1;                      // wavefronts (users) per block
     __shared__ KeyT kh_all[WPB * CAPW];
     __shared__ unsigned kl_all[WPB * CAPW];
     const int lane = threadIdx.x & 63, wv_in_blk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -747,7 +749,7 @@ __global__ __launch_bounds__(CAPW == 1024 ? 256 : 64) void k_collect_topk(FinalA
     };
     auto sort_kept = [&]() __attribute__((always_inline)) {
         wave_sync();
-        if (CAPW == 1024) {                                    // (cur <= K <= 512 here: collect_capw)
+        if (CAPW <= 1024) {                                    // (cur <= K <= 512 here: collect_capw)
             if (cur <= 64) sort_regs(std::integral_constant<int, 1>{});
             else if (cur <= 128) sort_regs(std::integral_constant<int, 2>{});
             else if (cur <= 256) sort_regs(std::integral_constant<int, 4>{});
