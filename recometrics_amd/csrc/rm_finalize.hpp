@@ -633,7 +633,8 @@ __global__ __launch_bounds__(CAPW <= 1024 ? 256 : 64) void k_collect_topk(FinalA
     // (what a wavefront does per user is a chain of round trips to memory: the loads that depend on the slot alone go out together)
     const int chunk = a.slot_chunk[slot], u = a.slot_user[slot];
     const ThrT bound_raw = thr_shared[slot];
-    if (chunk != 0) return;
+    // (no early exit for the few slots that are not a user's first: an exit here is a wait for `chunk` in front of every other load)
+    const bool live = chunk == 0;
     KeyT *kh = kh_all + wv_in_blk * CAPW;
     unsigned *kl = kl_all + wv_in_blk * CAPW;
     const int K = a.K;
@@ -792,7 +793,8 @@ __global__ __launch_bounds__(CAPW <= 1024 ? 256 : 64) void k_collect_topk(FinalA
                 const size_t wv = (size_t)bidx * nwaves + (size_t)(sub * GROUPS_PER_BLOCK + gi);
                 const int src_lane = ul + l * g.gu;
                 const char *wbase = glists + wv * ((size_t)g.lane_cap * WAVE * (sizeof(S) + 4));
-                cn[j] = lane_cnt[wv * WAVE + src_lane];
+                const int c = lane_cnt[wv * WAVE + src_lane];          // (loaded whether or not the slot is live: not behind the wait for `chunk`)
+                cn[j] = live ? c : 0;
                 bs[j] = wbase + (size_t)src_lane * (PAIRS ? 8 : sizeof(S));
                 bi[j] = (const int *)(wbase + (size_t)g.lane_cap * WAVE * sizeof(S)) + src_lane;
             }
@@ -805,7 +807,7 @@ __global__ __launch_bounds__(CAPW <= 1024 ? 256 : 64) void k_collect_topk(FinalA
 #endif
     if (g.extra_part >= 0) {
         const Entry<S> *px = a.pl + ((size_t)slot * a.n_part + g.extra_part) * K;
-        gather(K, [&](int i, KeyT &key, unsigned &low) {
+        gather(live ? K : 0, [&](int i, KeyT &key, unsigned &low) {
             const Entry<S> e = px[i];
             if (e.idx == IDX_EMPTY) return false;
             key = ord_key(e.s); low = ~(unsigned)e.idx;
@@ -852,6 +854,7 @@ __global__ __launch_bounds__(CAPW <= 1024 ? 256 : 64) void k_collect_topk(FinalA
     select_best();
     sort_kept();
 #endif
+    if (!live) return;
     Entry<S> *M = a.merged + (size_t)u * K;
     for (int i = lane; i < K; i += WAVE) {
         Entry<S> e;
