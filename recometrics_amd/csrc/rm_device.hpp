@@ -122,6 +122,14 @@ template <> __device__ __forceinline__ double lane_bcast<double>(double v, int s
 __device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
 
 // row of accumulator register r in a 32x32 MFMA result for the lane half h (cdna_hip_programming.md section 3)
+// the kernel's argument struct (its first and only explicit argument) read from the kernarg segment at the point of use: the opaque
+// asm keeps the compiler from merging these loads with the ones at the top of the kernel, whose results would stay in SGPRs until here
+template <class A> __device__ __forceinline__ const A *late_kernargs()
+{
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (const A *)p;
+}
 __device__ __forceinline__ constexpr int mfma32_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 } // namespace rm

@@ -994,6 +994,10 @@ void k_sweep(SweepArgs a)
 #endif
 
     // ---- write this wave's partial: top-K list, validity stats, AUC sum; flush the LDS histogram ----
+    // (the kernel arguments of this part -- six pointers and a handful of counts -- are read AGAIN, from the kernarg segment: loaded at
+    // the top they stay in SGPRs across the whole tile loop of a kernel that spills scalars; rm_device.hpp late_kernargs)
+    {
+    const SweepArgs &a = *late_kernargs<SweepArgs>();
     const int n_part = a.part_splits * NSUB + a.part_extra;
     const int part = split * NSUB + sub;
     {   // lanes u and u+32 hold two halves of the same user's stats
@@ -1067,6 +1071,7 @@ void k_sweep(SweepArgs a)
             const unsigned c = histL[g4 * (PLmax + 1) * GROUP_USERS + rem];
             if (gg < a.n_groups && c) atomicAdd(&a.hist[(a.grow[gg] + gg) * GROUP_USERS + rem], c);
         }
+    }
     }
 #ifdef RM_STATS
     if (lane == 0) { atomicAdd(&g_stats[5], (unsigned long long)st_nsel); atomicAdd(&g_stats[6], st_sel); atomicAdd(&g_stats[7], st_bar); atomicAdd(&g_stats[4], st_app); }

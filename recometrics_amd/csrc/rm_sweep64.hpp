@@ -194,7 +194,7 @@ void k_sweep64(Sweep64Args a)
     // 32-bit byte offset into the scores (the items' offset is half of it)
     const int lane_cap = a.lane_cap;
     const char *lb_scores = buffered ? (const char *)a.glists + ((size_t)blockIdx.x * 8 + wave) * ((size_t)lane_cap * (WAVE * 12)) : nullptr;
-    const char *lb_items = buffered ? lb_scores + (size_t)lane_cap * (WAVE * 8) : nullptr;
+    const unsigned lb_items_disp = (unsigned)lane_cap * (WAVE * 8);      // from the wave's scores to its item ids: ONE scalar, not a second base pair (the kernel spills scalars)
     unsigned lb_off = (unsigned)lane * 8u;                        // (entries of the lane) * 512 + lane * 8
     const unsigned lb_trigger = (unsigned)(lane_cap - 7) << 9;    // a tile appends at most 8 per lane: select when cnt > lane_cap - 8
     double ws = neg_inf_d(); int widx = IDX_EMPTY, wpos = 0;
@@ -285,13 +285,13 @@ void k_sweep64(Sweep64Args a)
     typedef __attribute__((address_space(3))) unsigned *LdsEpochPtr;
     LdsEpochPtr sel_epoch = (LdsEpochPtr)(smem + a.sync_off) + 4 + sub;
     unsigned sel_seen = 0u;
-    const unsigned lb_half = (unsigned)(lane_cap / 2) << 9;
+    const unsigned lb_half = ((lb_trigger + (7u << 9)) >> 10) << 9;      // (lane_cap / 2) << 9
     unsigned lb_trig_now = sub == 0 ? lb_trigger : (unsigned)(lane_cap - lane_cap / 4) << 9;      // stagger of the two domains: see the fp32 sweep
     lb_trig_now = lb_trig_now < lb_trigger ? lb_trig_now : lb_trigger;                               // (never beyond the safe level)
     auto lane_bounds = [&]() {
         const double hi_hint = f_noise ? pos_inf_d() : LaneSel<double>::umax(vmax);
         // (out of line: inlined, the selection's working set is added to a register budget that is already full at 256 factors)
-        const LaneSelResult<double> sr = lane_select_call<double>((double *)lb_scores + lane, (int *)lb_items + lane, (int)(lb_off >> 9), K, primary, thr, hi_hint, n);
+        const LaneSelResult<double> sr = lane_select_call<double>((double *)lb_scores + lane, (int *)(lb_scores + lb_items_disp) + lane, (int)(lb_off >> 9), K, primary, thr, hi_hint, n);
         const double t_new = sr.thr; const unsigned long long kk = sr.kth_key;
         lb_off = ((unsigned)sr.cnt << 9) | ((unsigned)lane * 8u);
         if (kk) {
@@ -369,11 +369,11 @@ void k_sweep64(Sweep64Args a)
                 for (int r = 0; r < 8; r++) {
                     if (v[r] >= thr) {
                         const int item = sbq + (r >> 2) * 16 + 4 * (r & 3);
-                        const unsigned ioff = lb_off >> 1;
+                        const unsigned ioff = (lb_off >> 1) + lb_items_disp;
                         // (one statement, s_nop 4 in front: a base pair that was spilled is restored by v_readlane right before it, and a
                         // VALU write of an SGPR needs five wait states before a memory instruction reads it -- see the fp32 sweep)
                         asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2\n\tglobal_store_dword %3, %4, %5"
-                                     :: "v"(lb_off), "v"(v[r]), "s"(lb_scores), "v"(ioff), "v"(item), "s"(lb_items) : "memory");
+                                     :: "v"(lb_off), "v"(v[r]), "s"(lb_scores), "v"(ioff), "v"(item), "s"(lb_scores) : "memory");
                         lb_off += 512u;
                     }
                 }
@@ -617,6 +617,10 @@ void k_sweep64(Sweep64Args a)
     if (DUMP) return;
     if (pend_cap) merge_pending();
 
+    // What follows reads its kernel arguments AGAIN, from the kernarg segment: loaded at the top they are eight scalar pairs alive across
+    // the whole tile loop of a kernel that spills scalars (k_sweep64<32,true,false,2,1>: 43 spilled SGPRs with them, 22 without).
+    {
+    const Sweep64Args &a = *late_kernargs<Sweep64Args>();
     const int n_part = a.part_splits * 2;
     const int part = split * 2 + sub;
     {   // the four lanes of a user hold four quarters of its stats
@@ -659,6 +663,7 @@ void k_sweep64(Sweep64Args a)
             const unsigned c = histL[g4 * (PLmax + 1) * GU + rem];
             if (gg < a.n_groups && c) atomicAdd(&a.hist[(a.grow[gg] + gg) * GU + rem], c);
         }
+    }
     }
 }
 

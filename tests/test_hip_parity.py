@@ -223,6 +223,8 @@ def test_random_problem_vs_oracle(hip, oracle, m, n, k, K, mean_c):
     (500, 3000, 128, 28, 90),      # fp64 depth split: shallow blocks with LDS lists beside deep ones with HBM lists
     (60, 2000, 600, 10, 40),       # fp64, more than 512 factors
     (100, 3000, 40, 400, 50),      # fp64, k_metrics > 256
+    (90, 2600, 24, 1000, 40),      # fp64, k_collect_topk's largest sort (2,048 entries of 64-bit keys in registers)
+    (90, 2600, 24, 1300, 40),
 ])
 def test_random_problem_vs_oracle_f64(hip, oracle, m, n, k, K, mean_c):
     from recometrics_amd.synth import make_problem
