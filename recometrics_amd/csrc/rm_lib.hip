@@ -364,13 +364,13 @@ inline void pack_operands(const float *A, size_t lda, const float *B, size_t ldb
         }
         if (!tiled) hipLaunchKernelGGL(k_pack_items<float>, dim3(cdiv(bp, 256)), dim3(256), 0, stream, B, ldb, n, k, NG, tile_items, Bp, bp);
     }
-    hipLaunchKernelGGL(k_pack_users<float>, dim3(cdiv(ap, 256)), dim3(256), 0, stream, A, lda, k, NG, slot_user, n_slots, Ap, ap);
+    if (ap > 0) hipLaunchKernelGGL(k_pack_users<float>, dim3(cdiv(ap, 256)), dim3(256), 0, stream, A, lda, k, NG, slot_user, n_slots, Ap, ap);
 }
 inline void pack_operands(const double *A, size_t lda, const double *B, size_t ldb, int n, int k, int NG, int, const int *slot_user,
                           int n_slots, double2 *Ap, long long ap, double2 *Bp, long long bp, hipStream_t stream, bool items = true)
 {
     if (items) hipLaunchKernelGGL(k_pack_items64<double>, dim3(cdiv(bp, 256)), dim3(256), 0, stream, B, ldb, n, k, NG, Bp, bp);
-    hipLaunchKernelGGL(k_pack_users64<double>, dim3(cdiv(ap, 256)), dim3(256), 0, stream, A, lda, k, NG, slot_user, n_slots, Ap, ap);
+    if (ap > 0) hipLaunchKernelGGL(k_pack_users64<double>, dim3(cdiv(ap, 256)), dim3(256), 0, stream, A, lda, k, NG, slot_user, n_slots, Ap, ap);
 }
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
@@ -483,10 +483,11 @@ inline void set_spec(SweepArgs &sa)
 }
 inline void set_spec(Sweep64Args &sa) { sa.spec = (sa.check_nan || sa.noise_E || sa.ext_topk || g_sw.no_spec) ? 0 : 1; }
 inline void set_ext_bits(SweepArgs &sa, const unsigned *bits, int words) { sa.train_bits = bits; sa.train_words = words; }
+inline void set_ext_bits(Sweep64Args &, const unsigned *, int) {}
 
 // Sample seeds for the lane buffers (k_seed_from_sample): how many items, and the two launches.  Not when a
 // score may be non-finite (the NaN check wants every score looked at) and not under the tie noise (the sample is scored without it).
-template <class T> inline int sample_seed_items(const Workspace &ws, int K, int n, long long n_slots, bool off)
+template <class T> inline int sample_seed_items(const Workspace &ws, int K, int n, long long n_slots, bool off, bool lists = false)
 {
     if (off || g_sw.sample_seed == 0) return 0;
     int S;
@@ -498,6 +499,11 @@ template <class T> inline int sample_seed_items(const Workspace &ws, int K, int 
         // C2's shape (26,744 items; profiles/r6_ab_c2.txt): 1,024 items beat 2,048 up to k_metrics ~ 128, 2,048 beyond, 4,096 from ~ 400.
         // (k_metrics = 500: sweep 22.5 ms without, 13.9 with 2,048, 10.9 with 4,096 in front of which the sample costs 1.9 ms more; 1,000: 36.8 / 22.8 / 16.0)
         S = K <= 128 ? 1024 : (K <= 384 ? 2048 : 4096);
+        // The replace-the-minimum lists (fp32, k_metrics below the lane buffers') rescan their K entries per insert, and most inserts come
+        // while the bound is still low: a sample of 256 pays from K = 12 -- C2's shape, M users/s without / with: K = 11 17.3 / 17.0, 12 16.6 / 16.8,
+        // 14 15.8 / 16.5, 16 15.0 / 15.7, 18 14.7 / 15.2 (1,024 items: the same within 1 %); at K = 10 the sweep goes 6.34 -> 6.24 ms and the
+        // sample costs 0.14
+        if (lists) { if (K < 12) return 0; S = 256; }
         if ((long long)S * 6 > n || K * 2 > S) return 0;
         // (fp64 takes the lane buffers from k_metrics = 1: at C2's shape in fp64 the sample pays from ~ 16 -- step 19.6 -> 19.0 ms at 20,
         // 25.9 -> 22.2 at 100, 34.8 -> 30.7 at 256; even at 10)
@@ -508,7 +514,7 @@ template <class T> inline int sample_seed_items(const Workspace &ws, int K, int 
     return S;
 }
 template <class T, class Args>
-inline void seed_from_sample(const Args &sa, Workspace &ws, int S, int NG, int n_slots, int n_ublocks, hipStream_t stream)
+inline void seed_from_sample(const Args &sa, Workspace &ws, int S, int NG, int n_slots, int n_ublocks, hipStream_t stream, const void *items64 = nullptr, void *lists = nullptr)
 {
     typedef Prec<T> P;
     typedef typename std::remove_pointer<decltype(Args{}.thr_shared)>::type ThrT;
@@ -516,6 +522,9 @@ inline void seed_from_sample(const Args &sa, Workspace &ws, int S, int NG, int n
     Args sd = sa;
     sd.n = S; sd.tiles_total = S / TILE_ITEMS; sd.K = 1; sd.n_splits = 1; sd.tail_ublocks = 0; sd.tail_splits = 1; sd.part_splits = 1;
     sd.buffered_lists = 0; sd.ext_topk = 0; sd.lane_cap = 0; sd.lane_cnt = nullptr; sd.spec = 0; sd.dump = sample;
+    // (a sweep with three sub-tiles per step has its item image in 96-item tiles and its dense train rows in words of them: the DUMP
+    // variant, two sub-tiles, gets an image of the sample of its own and no dense rows -- the seed kernel walks the sparse rows)
+    if (items64) { sd.Bp = (decltype(sd.Bp))items64; sd.glists = (decltype(sd.glists))lists; set_ext_bits(sd, nullptr, 0); }
     P::set_pending(sd, 0, 0);
     P::set_sync(sd, (int)P::lds_b(NG));
     dispatch_sweep(false, true, false, 2, NG, dim3((unsigned)n_ublocks), P::lds_b(NG) + SYNC_BYTES, stream, sd);
@@ -531,7 +540,6 @@ inline void seed_from_sample(const Args &sa, Workspace &ws, int S, int NG, int n
 #undef RM_SEED_LAUNCH
     check_launch(hipGetLastError());
 }
-inline void set_ext_bits(Sweep64Args &, const unsigned *, int) {}
 
 // what the plan's validation kernels found wrong with the caller's CSR arrays -> the error the entry points see
 template <class T>
@@ -1124,8 +1132,16 @@ void run(const Call<T> &c, hipStream_t stream, Ctx &cx)
         }
         // Sample seeds (k_seed_from_sample, rm_prep.hpp): the sweep's DUMP variant scores the first S items for every slot, a
         // wavefront per slot takes the K-th best candidate of them, and the lane buffers start with a pass rate of K / S.
-        const int sample_S = lane_lists ? sample_seed_items<T>(ws, K, n, n_slots, check_nan || c.noise_E != nullptr) : 0;
-        if (sample_S > 0) seed_from_sample<T>(sa, ws, sample_S, NG, n_slots, n_ublocks, stream);
+        const bool sample_lists = !lane_lists && !ext_topk && sizeof(T) == 4;      // (the LDS / HBM lists: seeded as well, from a smaller sample)
+        const int sample_S = (lane_lists || sample_lists) ? sample_seed_items<T>(ws, K, n, n_slots, check_nan || c.noise_E != nullptr, sample_lists) : 0;
+        if (sample_S > 0 && !sample_lists) seed_from_sample<T>(sa, ws, sample_S, NG, n_slots, n_ublocks, stream);
+        else if (sample_S > 0) {
+            const long long units = P::items_units(sample_S / TILE_ITEMS, NG);
+            typename P::PackT *Bs = (typename P::PackT *)ws.get("sample_items", 16 * (size_t)units);
+            void *Ls = ws.get("sample_lists", sizeof(typename P::ListT) * (size_t)n_ublocks * 8 * GU * (2 + 32));
+            pack_operands(c.A, c.lda, c.B, c.ldb, sample_S, k, NG, TILE_ITEMS, slot_user, 0, Ap, 0, Bs, units, stream, true);
+            seed_from_sample<T>(sa, ws, sample_S, NG, n_slots, n_ublocks, stream, Bs, Ls);
+        }
         if (c.flag_snapshot) {
             HIP_CHECK(hipMemcpyAsync(c.flag_snapshot, c.noise_flag, sizeof(int) * (size_t)m, hipMemcpyDeviceToDevice, stream));
             HIP_CHECK(hipMemcpyAsync(c.flag_count_host, &plan->n_noise_flagged, sizeof(int), hipMemcpyDeviceToHost, stream));

@@ -1066,6 +1066,22 @@ def test_sample_seeds_of_the_lane_buffers(hip, oracle, sample, K, mean_c, env, d
     _check_against_oracle(hip, oracle, pr, K, dtype=dtype)
 
 
+@pytest.mark.parametrize("env", [{}, {"RM_DEBUG_HBM_LISTS": "1"}, {"RM_DEBUG_NSUB2": "1", "RM_DEBUG_NO_TRAIN_BITS": "1"}, {"RM_DEBUG_SPLITS": "3,2,5"}])
+@pytest.mark.parametrize("sample,K,k,m,mean_c", [(64, 5, 40, 150, 20), (64, 12, 64, 150, 70), (256, 18, 16, 150, 70), (256, 13, 128, 150, 70), (256, 30, 40, 150, 900),
+                                                  (64, 20, 128, 900, 90)])
+def test_sample_seeds_of_the_lists(hip, oracle, sample, K, k, m, mean_c, env, monkeypatch):
+    """the replace-the-minimum lists start from the sample's bound as well (by default from k_metrics = 12 with 256 items): forced here at
+    every k_metrics, with three sub-tiles per step (the sample's DUMP launch then has an item image of its own and walks the sparse
+    train rows), two, lists in HBM, several item ranges, the depth split's two launches (900 users, 128 factors)"""
+    from recometrics_amd.synth import make_problem
+    monkeypatch.setenv("RM_DEBUG_SAMPLE_SEED", str(sample))
+    monkeypatch.setenv("RM_DEBUG_LANE_MIN_K", "1000000")
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    pr = make_problem(m, 5000, k, np.float32, mean_c=mean_c, seed=5000 + sample + K)
+    _check_against_oracle(hip, oracle, pr, K, dtype=np.float32)
+
+
 @pytest.mark.parametrize("env", [{}, {"RM_DEBUG_LANE_CAP_MIN": "1"}])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_lane_selection_cuts_exact_ties_by_item(hip, oracle, dtype, env, monkeypatch):
