@@ -805,15 +805,20 @@ __global__ __launch_bounds__(CAPW <= 1024 ? 256 : 64) void k_collect_topk(FinalA
 #ifndef RM_ABL_COLLECT_NO_GATHER
     describe(0);                                                    // (the first sources' counts are on their way while the user's own test items come in)
 #endif
+#ifndef RM_ABL_COLLECT_NO_EXTRA
     if (g.extra_part >= 0) {
         const Entry<S> *px = a.pl + ((size_t)slot * a.n_part + g.extra_part) * K;
         gather(live ? K : 0, [&](int i, KeyT &key, unsigned &low) {
             const Entry<S> e = px[i];
+#ifdef RM_ABL_COLLECT_EXTRA_DISCARD
+            if (e.idx != -77) return false;
+#endif
             if (e.idx == IDX_EMPTY) return false;
             key = ord_key(e.s); low = ~(unsigned)e.idx;
             return true;
         });
     }
+#endif
 #ifdef RM_ABL_COLLECT_NO_GATHER
     for (int s0 = 0; s0 < 0; s0 += G) {
 #else
@@ -855,6 +860,9 @@ __global__ __launch_bounds__(CAPW <= 1024 ? 256 : 64) void k_collect_topk(FinalA
     sort_kept();
 #endif
     if (!live) return;
+#ifdef RM_ABL_COLLECT_NO_WRITE
+    if (cur != 12345) return;
+#endif
     Entry<S> *M = a.merged + (size_t)u * K;
     for (int i = lane; i < K; i += WAVE) {
         Entry<S> e;
