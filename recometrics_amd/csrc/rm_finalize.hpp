@@ -613,6 +613,12 @@ template <> struct CollectKey<double> { typedef unsigned long long T; };
 inline int collect_capw(int K, int lane_cap) { return K <= 128 ? 512 : (K + lane_cap <= 1024 && 2 * K <= 1024 ? 1024 : 4096); }
 constexpr int COLLECT_MAX_ENTRIES = 4096;
 
+#ifdef RM_CSTATS
+__device__ unsigned long long g_cstats[16];                    // timing build: cycle counters of k_collect_topk's phases, summed over the wavefronts
+#define RM_CSTAT(IDX, T0) do { const unsigned long long t_now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g_cstats[IDX], t_now - (T0)); (T0) = t_now; } while (0)
+#else
+#define RM_CSTAT(IDX, T0) do { } while (0)
+#endif
 inline unsigned collect_grid(long long blocks) { return (unsigned)((blocks + 7) / 8 * 8); }
 template <class T, class S, class ThrT, int CAPW>
 __global__ __launch_bounds__(CAPW <= 1024 ? 256 : 64) void k_collect_topk(FinalArgs<T, S> a, CollectGeom g, const char *glists, const int *lane_cnt, const ThrT *thr_shared)
@@ -630,11 +636,18 @@ __global__ __launch_bounds__(CAPW <= 1024 ? 256 : 64) void k_collect_topk(FinalA
     const int lblock = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     const int slot = lblock * WPB + wv_in_blk;
     if (slot >= a.n_slots) return;
+#ifdef RM_CSTATS
+    unsigned long long ct = __builtin_readcyclecounter();
+#endif
     // (what a wavefront does per user is a chain of round trips to memory: the loads that depend on the slot alone go out together)
     const int chunk = a.slot_chunk[slot], u = a.slot_user[slot];
     const ThrT bound_raw = thr_shared[slot];
     // (no early exit for the few slots that are not a user's first: an exit here is a wait for `chunk` in front of every other load)
     const bool live = chunk == 0;
+#ifdef RM_CSTATS
+    asm volatile("" :: "s"(chunk), "s"(u));
+    RM_CSTAT(0, ct);
+#endif
     KeyT *kh = kh_all + wv_in_blk * CAPW;
     unsigned *kl = kl_all + wv_in_blk * CAPW;
     const int K = a.K;
@@ -780,27 +793,33 @@ __global__ __launch_bounds__(CAPW <= 1024 ? 256 : 64) void k_collect_topk(FinalA
     constexpr bool PAIRS = sizeof(S) == 4;                          // (rm_list.hpp LaneSel: fp32 (score, item) pairs; fp64 the wave's scores, then its item ids)
     const int per_range = g.nsub * g.lpu, nsrc = nsplit * per_range;
     const char *bs[G]; const int *bi[G]; int cn[G]; int cmax = 0;
+    // (the four counts in ONE round trip: every address is computed first -- a source beyond the last reads entry 0 and is masked
+    // afterwards --, then the four loads go out back to back.  The kernel runs beside k_rank_streamed, which streams 3 GB at BASELINE C2's
+    // shape: a round trip to memory takes ~5 us there, and a wavefront's life is the number of them it makes one after the other;
+    // timing build with cycle counters per phase, profiles/r6_ab_c2.txt r6w)
     auto describe = [&](int s0) __attribute__((always_inline)) {
-        cmax = 0;
+        size_t cidx[G]; bool on[G];
         #pragma unroll
         for (int j = 0; j < G; j++) {
             const int src = s0 + j;
-            cn[j] = 0; bs[j] = glists; bi[j] = (const int *)glists;
-            if (src < nsrc) {
-                const int sp = src / per_range, rem = src % per_range, sub = rem / g.lpu, l = rem % g.lpu;
-                const int bidx = in_tail ? n_ub1 * g.n_splits + sp * g.tail_ublocks + (g.tail_ublocks - 1 - rel)
-                                         : sp * n_ub1 + (g.n_ublocks - 1 - rel);
-                const size_t wv = (size_t)bidx * nwaves + (size_t)(sub * GROUPS_PER_BLOCK + gi);
-                const int src_lane = ul + l * g.gu;
-                const char *wbase = glists + wv * ((size_t)g.lane_cap * WAVE * (sizeof(S) + 4));
-                const int c = lane_cnt[wv * WAVE + src_lane];          // (loaded whether or not the slot is live: not behind the wait for `chunk`)
-                cn[j] = live ? c : 0;
-                bs[j] = wbase + (size_t)src_lane * (PAIRS ? 8 : sizeof(S));
-                bi[j] = (const int *)(wbase + (size_t)g.lane_cap * WAVE * sizeof(S)) + src_lane;
-            }
+            on[j] = src < nsrc;
+            const int srcc = on[j] ? src : 0;
+            const int sp = srcc / per_range, rem = srcc % per_range, sub = rem / g.lpu, l = rem % g.lpu;
+            const int bidx = in_tail ? n_ub1 * g.n_splits + sp * g.tail_ublocks + (g.tail_ublocks - 1 - rel)
+                                     : sp * n_ub1 + (g.n_ublocks - 1 - rel);
+            const size_t wv = (size_t)bidx * nwaves + (size_t)(sub * GROUPS_PER_BLOCK + gi);
+            const int src_lane = ul + l * g.gu;
+            const char *wbase = glists + wv * ((size_t)g.lane_cap * WAVE * (sizeof(S) + 4));
+            cidx[j] = wv * WAVE + src_lane;
+            bs[j] = wbase + (size_t)src_lane * (PAIRS ? 8 : sizeof(S));
+            bi[j] = (const int *)(wbase + (size_t)g.lane_cap * WAVE * sizeof(S)) + src_lane;
         }
+        int c[G];
         #pragma unroll
-        for (int j = 0; j < G; j++) cmax = cn[j] > cmax ? cn[j] : cmax;
+        for (int j = 0; j < G; j++) c[j] = lane_cnt[cidx[j]];
+        cmax = 0;
+        #pragma unroll
+        for (int j = 0; j < G; j++) { cn[j] = (live && on[j]) ? c[j] : 0; cmax = cn[j] > cmax ? cn[j] : cmax; }
     };
 #ifndef RM_ABL_COLLECT_NO_GATHER
     describe(0);                                                    // (the first sources' counts are on their way while the user's own test items come in)
@@ -809,7 +828,8 @@ __global__ __launch_bounds__(CAPW <= 1024 ? 256 : 64) void k_collect_topk(FinalA
     if (g.extra_part >= 0) {
         const Entry<S> *px = a.pl + ((size_t)slot * a.n_part + g.extra_part) * K;
         gather(live ? K : 0, [&](int i, KeyT &key, unsigned &low) {
-            const Entry<S> e = px[i];
+            Entry<S> e;                                             // (score and item in one load: the item alone first was a round trip more)
+            __builtin_memcpy(&e, px + i, sizeof(e));
 #ifdef RM_ABL_COLLECT_EXTRA_DISCARD
             if (e.idx != -77) return false;
 #endif
@@ -819,6 +839,7 @@ __global__ __launch_bounds__(CAPW <= 1024 ? 256 : 64) void k_collect_topk(FinalA
         });
     }
 #endif
+    RM_CSTAT(1, ct);
 #ifdef RM_ABL_COLLECT_NO_GATHER
     for (int s0 = 0; s0 < 0; s0 += G) {
 #else
@@ -855,10 +876,12 @@ __global__ __launch_bounds__(CAPW <= 1024 ? 256 : 64) void k_collect_topk(FinalA
         }
     }
     wave_sync();
+    RM_CSTAT(2, ct);
 #ifndef RM_ABL_COLLECT_GATHER_ONLY                             // (timing only, scratch/build_abl.py: what the gather alone costs)
     select_best();
     sort_kept();
 #endif
+    RM_CSTAT(3, ct);
     if (!live) return;
 #ifdef RM_ABL_COLLECT_NO_WRITE
     if (cur != 12345) return;
@@ -870,6 +893,11 @@ __global__ __launch_bounds__(CAPW <= 1024 ? 256 : 64) void k_collect_topk(FinalA
         else { e.s = (S)qnan<float>(); e.idx = -1; }
         M[i] = e;
     }
+#ifdef RM_CSTATS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RM_CSTAT(4, ct);
+    if (lane == 0) atomicAdd(&g_cstats[5], 1ull);
+#endif
 }
 
 template <class T, class S>

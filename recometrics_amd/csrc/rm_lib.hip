@@ -2262,6 +2262,14 @@ void debug_scores(const T *A, size_t lda, const T *B, size_t ldb, int m, int n, 
 
 } // namespace
 
+#ifdef RM_CSTATS
+extern "C" int rm_debug_stats_collect(unsigned long long *out, int reset)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(rm::g_cstats), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(rm::g_cstats), z, sizeof(z)); }
+    return 0;
+}
+#endif
 // =====================================================================================================================
 // C-ABI
 // =====================================================================================================================
