@@ -397,7 +397,7 @@ inline long long stream_budget_bytes(const Workspace &ws)
 }
 
 // Which top-K scheme a pass takes (rm_sweep.hpp LMODE):
-//   lane lists   per-lane append buffers + lane-parallel selection + k_collect_topk (rm_list.hpp): k_metrics from `lane_min_k` (19 / 14; the
+//   lane lists   per-lane append buffers + lane-parallel selection + k_collect_topk (rm_list.hpp): k_metrics from `lane_min_k` (20 / 14; the
 //                replace-the-minimum lists rescan K entries per insert: BASELINE C2's shape took 8.1 / 15.0 / 26.8 ms at K = 20 /
 //                32 / 50 in LDS or HBM lists against 8.1 / 8.7 / 10.0 here, profiles/r6_ksweep_C2.txt) up to what k_collect_topk sorts in LDS (K + one lane buffer <= 4,096 entries: K <= 1,354), while the
 //                buffers -- 8 waves x 64 lanes x lane_cap entries per block of the sweep's grid -- fit a third of the free memory;
@@ -415,7 +415,7 @@ template <class T> inline bool lane_lists_possible(int K, bool three_subtiles = 
 {
     // (fp64: every k_metrics -- a user sits on four lanes there and the lists' owner lane collects from all of them: C5's shape K = 5
     // 73.4 against 74.8 ms, K = 10 73.6 / 76.4, K = 20 75.1 / 84.2; C2's shape in fp64 K = 10 4.50 / 5.22, K = 14 4.50 / 6.28)
-    const long long min_k = g_sw.lane_min_k >= 0 ? g_sw.lane_min_k : (three_subtiles ? 19 : (sizeof(T) == 8 ? 1 : 14));
+    const long long min_k = g_sw.lane_min_k >= 0 ? g_sw.lane_min_k : (three_subtiles ? 20 : (sizeof(T) == 8 ? 1 : 14));
     return !g_sw.ext_topk && K >= min_k && K + Prec<T>::lane_cap(K) <= COLLECT_MAX_ENTRIES;
 }
 // (the grid of the sweep is only known behind the plan: user blocks of the call, or a few rounds of 256 blocks when there are few)
